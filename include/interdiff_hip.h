@@ -1,0 +1,226 @@
+/*
+ * interdiff_hip.h -- C-ABI of the MI355X-native InterDiff denoising-sampler hot path.
+ *
+ * The reference (Sirui-Xu/InterDiff) has no FFI: its seams are Python callables on torch
+ * tensors.  This library is what a binding for those seams would load:
+ * every entry point below names the reference callable it replaces (file:line relative to
+ * /root/reference/interdiff).  INTEGRATION.md shows the ctypes stub for each.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (gfx950 HBM) unless its name starts with h_;
+ *  - tensors are dense, row-major, fp32 unless stated; shapes are given in comments;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *    enqueued asynchronously on it, nothing synchronises, nothing allocates: scratch comes
+ *    from the caller (`ws`, sized by the matching *_workspace_bytes function);
+ *  - return value: 0 on success, a negative code on error (IDF_E_*); no exceptions, no
+ *    callbacks, no global state => safe to capture in a hipGraph;
+ *  - inputs are borrowed; outputs are caller-allocated.
+ */
+#ifndef INTERDIFF_HIP_H
+#define INTERDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDF_OK            0
+#define IDF_E_INVAL      -22   /* bad shape / null pointer / unsupported size            */
+#define IDF_E_NOMEM      -12   /* workspace too small                                     */
+#define IDF_E_LAUNCH     -5    /* hipGetLastError() != hipSuccess after a launch          */
+
+int         interdiff_abi_version(void);          /* bumped on any signature change       */
+const char *interdiff_build_info(void);           /* "gfx950 hipcc ..."                   */
+
+/* ------------------------------------------------------------------------------------
+ * Rotation conversions  (pytorch3d.transforms 0.7.2 semantics; eval_smpl_short.py:18,
+ * 33,65-66,90-91,157-162; model/diffusion_smpl.py:212-213).  n = number of rotations.
+ * quaternions are (w,x,y,z); matrices row-major 3x3; rot6d = first two ROWS.
+ * ---------------------------------------------------------------------------------- */
+int interdiff_rotation_6d_to_matrix   (const float *d6, float *m,  int64_t n, void *stream);
+int interdiff_matrix_to_rotation_6d   (const float *m,  float *d6, int64_t n, void *stream);
+int interdiff_matrix_to_axis_angle    (const float *m,  float *aa, int64_t n, void *stream);
+int interdiff_axis_angle_to_matrix    (const float *aa, float *m,  int64_t n, void *stream);
+int interdiff_axis_angle_to_quaternion(const float *aa, float *q,  int64_t n, void *stream);
+int interdiff_rotation_6d_to_axis_angle(const float *d6, float *aa, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * SMPL-H forward kinematics + linear blend skinning
+ * replaces SMPL_Layer.forward  (libsmpl/smplpytorch/pytorch/smpl_layer.py:72-175).
+ *
+ * The model is passed as PACKED constants built once on the host
+ * (interdiff_amd/smpl.py: pack_smpl_model):
+ *   blend   [3V][KB]   KB = round_up(9(J-1)+n_betas+1, 8): per output coordinate the row
+ *                      [posedirs(9(J-1)) | shapedirs(n_betas) | v_template | 0-pad]
+ *   jt      [J][3]     J_regressor . v_template
+ *   js      [J][3][n_betas]  J_regressor . shapedirs
+ *   parents [J] int32  (parents[0] ignored)
+ *   skin_idx[V][S] int32, skin_w [V][S]   ELL form of the skinning weights (zeros dropped,
+ *                      padded with weight 0 / index 0); S = max non-zeros per vertex
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t V, J, n_betas, KB, S;
+    const float   *blend;
+    const float   *jt;
+    const float   *js;
+    const int32_t *parents;
+    const int32_t *skin_idx;
+    const float   *skin_w;
+} idf_smpl_model;
+
+size_t interdiff_smpl_workspace_bytes(const idf_smpl_model *m, int64_t N);
+/* pose [N,3J] axis-angle, betas [N,n_betas], trans [N,3] -> verts [N,V,3], jtr [N,J,3],
+ * v_posed [N,V,3] (may be NULL). */
+int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose, const float *betas,
+                           const float *trans, int64_t N, float *verts, float *jtr,
+                           float *v_posed, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Geometry
+ * vertex_normals        replaces data/tools.py:4-40   (faces NOT repeated per frame)
+ *   adj_ptr [V+1], adj_face [nnz], adj_corner [nnz] (uint8 as int32): vertex->incident
+ *   faces in the reference's accumulation order (corner 1, corner 2, corner 0; ascending
+ *   face index inside each) -- built by interdiff_amd/geometry.py: build_vertex_adjacency.
+ * nn_argmin / point2point_signed replace tools.py:11-76 + chamfer_distance (brute force,
+ *   d2 = (dx*dx+dy*dy)+dz*dz without FMA, lowest index wins ties).
+ * ---------------------------------------------------------------------------------- */
+int interdiff_vertex_normals(const float *verts, int64_t N, int32_t V, const int32_t *faces,
+                             const int32_t *adj_ptr, const int32_t *adj_face,
+                             const int32_t *adj_corner, float *normals, void *stream);
+/* q [N,Pq,3], r [N,Pr,3] -> idx int32 [N,Pq] : nearest r for every q */
+int interdiff_nn_argmin(const float *q, int32_t Pq, const float *r, int32_t Pr, int64_t N,
+                        int32_t *idx, void *stream);
+/* x [N,P1,3], y [N,P2,3], optional normals (NULL = unsigned).  Outputs as tools.py:73-76:
+ * y2x_signed [N,P2], x2y_signed [N,P1], yidx [N,P2], xidx [N,P1], y2x [N,P2,3], x2y [N,P1,3]
+ * (vector outputs may be NULL). */
+int interdiff_point2point_signed(const float *x, int32_t P1, const float *y, int32_t P2, int64_t N,
+                                 const float *x_normals, const float *y_normals,
+                                 float *y2x_signed, float *x2y_signed, int32_t *yidx, int32_t *xidx,
+                                 float *y2x, float *x2y, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * MDM denoiser, decoder path   replaces MDM.forward / _decode
+ * (model/diffusion_smpl.py:226-246; layers [std, QaN x6, std], sublayers.py:206-375).
+ *
+ * Weights are packed once from a state_dict with the reference's key names
+ * (interdiff_amd/mdm.py: pack_mdm_weights) into ONE fp32 arena; idf_mdm_weights holds
+ * offsets (in floats) into it.  Token rows are clip-major: row = b*T + t.
+ * ---------------------------------------------------------------------------------- */
+#define IDF_MDM_LAYERS 8
+#define IDF_MDM_D      256
+#define IDF_MDM_FF     1024
+#define IDF_MDM_HEADS  4
+#define IDF_MDM_NQ     10      /* learned queries per QaN layer                          */
+#define IDF_MDM_MEM    10      /* memory (past) tokens                                   */
+
+typedef struct {
+    int64_t is_qan;            /* 0: torch TransformerDecoderLayer, 1: QaN               */
+    int64_t sa_in_w, sa_in_b, sa_out_w, sa_out_b;   /* std only: [768,256],[768],[256,256],[256] */
+    int64_t qc, wk;            /* QaN only: Qc [NQ][3][256] (pre-rotated, pre-scaled), wk [NQ] */
+    int64_t ca_q_w, ca_q_b;    /* cross-attn query proj [256,256],[256]                  */
+    int64_t ca_kv_w, ca_kv_b;  /* cross-attn key|value proj [512,256],[512]              */
+    int64_t ca_out_w, ca_out_b;
+    int64_t ff1_w, ff1_b, ff2_w, ff2_b;             /* [1024,256],[1024],[256,1024],[256] */
+    int64_t ln_w[3], ln_b[3];
+} idf_mdm_layer;
+
+typedef struct {
+    int32_t C;                 /* token width (144)                                      */
+    int32_t n_steps;           /* rows of temb_table                                     */
+    const float *arena;
+    int64_t in_w, in_b;        /* [256][C] = [bodyEmbedding | objEmbedding], summed bias  */
+    int64_t out_w, out_b;      /* [C][256] = [bodyFinalLinear ; objFinalLinear]          */
+    int64_t temb_table;        /* [n_steps][256] = time_embed(pe[t]) (weights-only const) */
+    int64_t pe;                /* [max_T][256] positional table rows 0..max_T-1          */
+    int32_t max_T, _pad;
+    idf_mdm_layer layer[IDF_MDM_LAYERS];
+} idf_mdm_weights;
+
+/* per-sample constants derived from the memory `cond` (constant over all steps): for every
+ * layer and clip the folded cross-attention operands
+ *   G  [L][B][40][256]  (scores = x . G^T + g0, 40 = heads*MEM, pre-scaled by 1/sqrt(64))
+ *   g0 [L][B][40]
+ *   VW [L][B][40][256]  (out = P . VW + out_bias)
+ * cond [MEM,B,256] (reference layout).  `memctx` must hold interdiff_mdm_memctx_floats(B). */
+size_t interdiff_mdm_memctx_floats(int32_t B);
+size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T);
+int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B,
+                                 float *memctx, void *ws, size_t ws_bytes, void *stream);
+/* x [B,1,C,T], ts int64 [B] -> x0 [B,1,C,T] */
+int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x,
+                          const int64_t *ts, int32_t B, int32_t T, float *x0,
+                          void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sampler step   replaces p_mean_variance's inpainting + q_posterior mean and p_sample's
+ * noise add (diffusion/gaussian_diffusion.py:307-311,374,532-547):
+ *   x0   = mask ? gt : x0                      (mask [n] uint8, may be NULL)
+ *   x    = c1*x0 + c2*x + sigma*eps            (sigma = 0 at t == 0)
+ * eps comes from `noise` [n] when non-NULL, else from the counter-based generator
+ * (Philox4x32-10 + Box-Muller) keyed by (seed, step_index, element).
+ * `inpaint_only` != 0 applies just the first line (used before the correction hook).
+ * ---------------------------------------------------------------------------------- */
+int interdiff_inpaint(float *x0, const float *gt, const uint8_t *mask, int64_t n, void *stream);
+int interdiff_posterior_step(float *x, const float *x0, const float *noise, int64_t n,
+                             float c1, float c2, float sigma, uint64_t seed, uint64_t step_index,
+                             void *stream);
+int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,
+ * eval branch) with BatchNorm folded into the 1x1 convolutions at pack time
+ * (interdiff_amd/objprojector.py: pack_objprojector).  arena layout: see that file.
+ * obj_angles [T,B,6], obj_trans [T,B,3], markers [T,B,P,3] (P = 67), contact int32 [B,P]
+ * -> out [T,B,9].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t T, past_len, P, n_pre;
+    const float *arena;
+    int64_t dct_pad;           /* [n_pre][past_len]  DCT with the idx_pad frames folded in */
+    int64_t dct;               /* [n_pre][T]                                             */
+    int64_t idct;              /* [T][n_pre]                                             */
+    int64_t hand_bonus;        /* [P] 0.5 on hand markers                                */
+    int64_t layer[12];         /* 3 stacks x 4 layers; each: see pack_objprojector       */
+    int32_t cin[12], cout[12];
+} idf_objproj;
+
+int interdiff_objprojector_sample(const idf_objproj *op, const float *obj_angles,
+                                  const float *obj_trans, const float *markers,
+                                  const int32_t *contact, int32_t B, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * denoised_fn, fused   replaces eval_smpl_short.py:84-130 for one gated step.
+ * x0 [B,1,144,T] is updated in place.  hand_pose [T,B,90] (already idx-padded),
+ * beta [T,B,10], obj_points [B,P,3], gt [B,1,144,T], markers_idx int32 [67].
+ * Optional debug outputs (may be NULL): condition uint8 [B], contact int32 [B,67],
+ * distance [B], loss [B].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    const idf_smpl_model *smpl;
+    const idf_objproj    *objproj;
+    const int32_t *faces;      /* [F][3] */
+    const int32_t *adj_ptr, *adj_face, *adj_corner;
+    const int32_t *markers_idx;
+    int32_t n_markers, n_points, past_len, _pad;
+} idf_correction_ctx;
+
+size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);
+int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt,
+                         const float *hand_pose, const float *beta, const float *obj_points,
+                         int32_t B, int32_t T, float blend_t /* t/1000 */,
+                         uint8_t *condition, int32_t *contact, float *distance, float *loss,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* Evaluation metrics (eval_smpl_short.py:24-81) on future frames; each output [B]. */
+int interdiff_metrics(const idf_correction_ctx *c, const float *obj_pred, const float *jtr,
+                      const float *body_trans, const float *obj_gt, const float *jtr_gt,
+                      const float *body_trans_gt, const float *verts, const float *obj_points,
+                      int32_t B, int32_t T, int32_t J, float *out6 /* [6][B] */,
+                      void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTERDIFF_HIP_H */

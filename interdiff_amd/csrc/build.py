@@ -1,0 +1,52 @@
+"""Build libinterdiff_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m interdiff_amd.csrc.build [--force]
+
+One translation unit per .hip file, objects cached next to the sources (git-ignored), linked
+into interdiff_amd/csrc/libinterdiff_hip.so -- in-tree so that it travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libinterdiff_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+    hdrs.append(os.path.join(HERE, '..', '..', 'include', 'interdiff_hip.h'))
+    objs, jobs = [], []
+    for s in sources():
+        src, obj = os.path.join(HERE, s), os.path.join(HERE, s[:-4] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,122 @@
+// DDPM reverse-step update (rows S4-S5 of SURVEY.md §8): inpainting of the x0 prediction,
+// posterior mean and the noise add, one HBM pass each (elementwise, 16 B per lane).
+// Reference behaviour: diffusion/gaussian_diffusion.py:307-311 (inpaint), :374 + :253-275
+// (posterior mean = c1*x0 + c2*x_t), :532-547 (sample = mean + (t!=0) exp(.5 logvar) eps).
+// The reference draws eps with torch's global generator (one randn_like per step); here eps
+// is either handed in (deterministic parity runs) or produced in-kernel by Philox4x32-10 +
+// Box-Muller keyed by (seed, step, element), so no noise tensor ever round-trips HBM.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+// four N(0,1) draws for element group g of step `step`
+__device__ __forceinline__ float4 randn4(uint64_t seed, uint64_t step, uint64_t g) {
+    uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // (0,1] uniforms -> Box-Muller
+    const float u0 = ((float)(c0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c2 >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c3 >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, co0, s1, co1;
+    sincosf(6.283185307179586f * u1, &s0, &co0);
+    sincosf(6.283185307179586f * u3, &s1, &co1);
+    return make_float4(r0 * co0, r0 * s0, r1 * co1, r1 * s1);
+}
+
+__global__ __launch_bounds__(256) void inpaint_kernel(float *__restrict__ x0, const float *__restrict__ gt,
+                                                      const uint8_t *__restrict__ mask, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (mask[i]) x0[i] = gt[i];
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(256) void posterior_kernel(float *__restrict__ x, const float *__restrict__ x0,
+                                                        const float *__restrict__ noise, int64_t n, float c1, float c2,
+                                                        float sigma, uint64_t seed, uint64_t step) {
+    const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+        const int64_t i = g * 4;
+        float4 e;
+        if constexpr (GEN) e = randn4(seed, step, (uint64_t)g);
+        if (i + 3 < n) {
+            float4 xv = *reinterpret_cast<float4 *>(x + i);
+            const float4 pv = *reinterpret_cast<const float4 *>(x0 + i);
+            if constexpr (!GEN) e = *reinterpret_cast<const float4 *>(noise + i);
+            xv.x = c1 * pv.x + c2 * xv.x + sigma * e.x;
+            xv.y = c1 * pv.y + c2 * xv.y + sigma * e.y;
+            xv.z = c1 * pv.z + c2 * xv.z + sigma * e.z;
+            xv.w = c1 * pv.w + c2 * xv.w + sigma * e.w;
+            *reinterpret_cast<float4 *>(x + i) = xv;
+        } else {
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+            for (int k = 0; k < 4 && i + k < n; ++k)
+                x[i + k] = c1 * x0[i + k] + c2 * x[i + k] + sigma * (GEN ? ev[k] : noise[i + k]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int64_t n, uint64_t seed, uint64_t step) {
+    const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+        const float4 e = randn4(seed, step, (uint64_t)g);
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+        for (int k = 0; k < 4 && g * 4 + k < n; ++k) out[g * 4 + k] = ev[k];
+    }
+}
+
+inline unsigned grid_for(int64_t work) {
+    int64_t b = idf_cdiv(work, 256);
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int interdiff_inpaint(float *x0, const float *gt, const uint8_t *mask, int64_t n, void *stream) {
+    if (!x0 || !gt || !mask || n < 0) return IDF_E_INVAL;
+    if (n == 0) return IDF_OK;
+    hipLaunchKernelGGL(inpaint_kernel, dim3(grid_for(n)), dim3(256), 0, idf_stream(stream), x0, gt, mask, n);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
+extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *noise, int64_t n, float c1, float c2,
+                                        float sigma, uint64_t seed, uint64_t step_index, void *stream) {
+    if (!x || !x0 || n < 0) return IDF_E_INVAL;
+    if (n == 0) return IDF_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(noise)) & 15)
+        return IDF_E_INVAL;
+    const unsigned g = grid_for((n + 3) / 4);
+    if (noise)
+        hipLaunchKernelGGL((posterior_kernel<false>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2,
+                           sigma, seed, step_index);
+    else
+        hipLaunchKernelGGL((posterior_kernel<true>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2, sigma,
+                           seed, step_index);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
+extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream) {
+    if (!out || n < 0) return IDF_E_INVAL;
+    if (n == 0) return IDF_OK;
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, idf_stream(stream), out, n, seed, step_index);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
+extern "C" int interdiff_abi_version(void) { return 1; }
+extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 1"; }

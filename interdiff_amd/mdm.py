@@ -1,0 +1,189 @@
+"""Host side of the MDM denoiser seam: ``model(x, ts, y=...) -> x0``.
+
+Mirrors the reference's call surface (model/diffusion_smpl.py:239-246 ``MDM.forward``; invoked
+by the sampler as ``model(x, t, **model_kwargs)``, diffusion/gaussian_diffusion.py:305) on top
+of ``interdiff_mdm_forward`` / ``interdiff_mdm_prepare_memory`` (include/interdiff_hip.h).
+Weights are packed ONCE from a state_dict that uses the reference's key names.
+
+Weights-only constants folded at pack time (host, once):
+  * Qc[n][j][:]  : the 10 learned queries, per-head unit-normalised and /sqrt(64)
+                   (sublayers.py:18-35), times LocalAttention's scale 256^-0.5, rotated by the
+                   rotary position embedding difference (2 - j) so that
+                   logit[t,n,j] = <Qc[n,j], x[t+j-1]>   (SURVEY.md appendix B.2);
+  * temb[t][:]   : time_embed(pe[t]) for every diffusion step (layers.py:42-43) -- depends on
+                   the weights and t only;
+  * W_in = [bodyEmbedding | objEmbedding] (transposed), W_out = [bodyFinalLinear ; objFinalLinear].
+"""
+import ctypes as C
+import math
+import numpy as np
+import torch
+from . import _lib
+
+D, FF, HEADS, NQ, MEM, LAYERS = 256, 1024, 4, 10, 10, 8
+QAN_LAYERS = (1, 2, 3, 4, 5, 6)
+ROTARY_DEFAULT = True
+
+
+def positional_table(max_len=5000, d=D):
+    """PositionalEncoding.pe (layers.py:14-19), computed the same way (torch fp32 on the host)."""
+    pe = torch.zeros(max_len, d)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2).float() * (-np.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div)
+    pe[:, 1::2] = torch.cos(position * div)
+    return pe.numpy()
+
+
+def qan_constants(queries, rotary=ROTARY_DEFAULT, heads=HEADS):
+    """queries [NQ, D] -> Qc [NQ, 3, D] float32 (float64 arithmetic on the host)."""
+    q = np.asarray(queries, dtype=np.float64)
+    n, d = q.shape
+    qh = q.reshape(n, heads, d // heads)
+    qh = qh / (np.sqrt((qh * qh).sum(-1, keepdims=True)) + 1e-6) / math.sqrt(d // heads)
+    q = qh.reshape(n, d) * d ** -0.5
+    out = np.empty((n, 3, d))
+    if not rotary:
+        out[:] = q[:, None, :]
+        return out.astype(np.float32)
+    inv = 1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=np.float64) / d))
+    theta = np.concatenate([inv, inv])
+    half = d // 2
+    rot = np.concatenate([-q[:, half:], q[:, :half]], axis=1)
+    for j in range(3):
+        p = 2 - j                      # <R_2 q, R_j k> = <R_{2-j} q, k>
+        out[:, j] = q * np.cos(p * theta) + rot * np.sin(p * theta)
+    return out.astype(np.float32)
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+class _Arena:
+    def __init__(self):
+        self.parts, self.n = [], 0
+
+    def add(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+        off = self.n
+        pad = (-a.size) % 64
+        self.parts.append(a)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.n += a.size + pad
+        return off
+
+    def tensor(self, device):
+        return torch.from_numpy(np.concatenate(self.parts)).to(device)
+
+
+def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT):
+    """state_dict (reference key names, tensors or arrays) -> (MdmWeights struct, arena tensor)."""
+    g = lambda k: _np(sd[k]).astype(np.float32)
+    ar = _Arena()
+    w = _lib.MdmWeights()
+    win = np.concatenate([g('bodyEmbedding.weight'), g('objEmbedding.weight')], axis=1)      # [256, C]
+    w.C = win.shape[1]
+    w.in_w = ar.add(win.T)
+    w.in_b = ar.add(g('bodyEmbedding.bias') + g('objEmbedding.bias'))
+    w.out_w = ar.add(np.concatenate([g('bodyFinalLinear.weight'), g('objFinalLinear.weight')], axis=0))
+    w.out_b = ar.add(np.concatenate([g('bodyFinalLinear.bias'), g('objFinalLinear.bias')]))
+    pe = g('PositionalEmbedding.pe')[:, 0] if 'PositionalEmbedding.pe' in sd else positional_table()
+    if n_steps > pe.shape[0] or max_T > pe.shape[0]:
+        raise ValueError('positional table too short')
+    # time embedding table (torch fp32 on the host, same op order as TimestepEmbedder)
+    t0w, t0b = torch.from_numpy(g('embedTimeStep.time_embed.0.weight')), torch.from_numpy(g('embedTimeStep.time_embed.0.bias'))
+    t2w, t2b = torch.from_numpy(g('embedTimeStep.time_embed.2.weight')), torch.from_numpy(g('embedTimeStep.time_embed.2.bias'))
+    h = torch.from_numpy(pe[:n_steps].copy()) @ t0w.T + t0b
+    temb = torch.nn.functional.silu(h) @ t2w.T + t2b
+    w.n_steps = n_steps
+    w.temb_table = ar.add(temb.numpy())
+    w.max_T = max_T
+    w.pe = ar.add(pe[:max_T])
+    for l in range(LAYERS):
+        p, ly = 'decoder.layers.%d.' % l, w.layer[l]
+        ly.is_qan = 1 if (p + 'queries') in sd else 0
+        if ly.is_qan:
+            ly.qc = ar.add(qan_constants(g(p + 'queries'), rotary))
+            ly.wk = ar.add(g(p + 'wk').reshape(-1))
+        else:
+            ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
+            ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
+            ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
+            ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
+        cw, cb = g(p + 'multihead_attn.in_proj_weight'), g(p + 'multihead_attn.in_proj_bias')
+        ly.ca_q_w, ly.ca_q_b = ar.add(cw[:D]), ar.add(cb[:D])
+        ly.ca_kv_w, ly.ca_kv_b = ar.add(cw[D:]), ar.add(cb[D:])
+        ly.ca_out_w = ar.add(g(p + 'multihead_attn.out_proj.weight'))
+        ly.ca_out_b = ar.add(g(p + 'multihead_attn.out_proj.bias'))
+        ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
+        ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
+        for k in range(3):
+            ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
+            ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
+    arena = ar.tensor(device)
+    w.arena = arena.data_ptr()
+    return w, arena
+
+
+class MDM:
+    """Drop-in for the reference denoiser at the sampler seam: ``MDM(state_dict)(x, ts, y={'cond': ...})``."""
+
+    def __init__(self, state_dict, device='cuda', n_steps=1000, rotary=ROTARY_DEFAULT):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
+        self._mem_key, self._memctx, self._ws = None, None, None
+
+    # -- nn.Module-ish surface the sampler touches (gaussian_diffusion.py:688-689, eval_smpl_short.py:428)
+    def parameters(self):
+        yield self.arena
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def _workspace(self, B, T):
+        need = self.lib.interdiff_mdm_workspace_bytes(B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def prepare_memory(self, cond):
+        """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands."""
+        if cond.shape[0] != MEM or cond.shape[2] != D:
+            raise ValueError('cond must be [%d,B,%d]' % (MEM, D))
+        B = cond.shape[1]
+        cond = cond.contiguous()
+        memctx = torch.empty(self.lib.interdiff_mdm_memctx_floats(B), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, 16)
+        _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
+                                                         _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),
+                   'mdm_prepare_memory')
+        self._mem_key = (cond.data_ptr(), cond._version, tuple(cond.shape))
+        self._memctx = memctx
+        return memctx
+
+    def forward(self, x, timesteps, y=None, out=None):
+        if y is None or 'cond' not in y:
+            raise ValueError("model_kwargs['y']['cond'] is required")
+        cond = y['cond']
+        if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
+            self.prepare_memory(cond)
+        B, one, Cc, T = x.shape
+        if one != 1 or Cc != self.w.C:
+            raise ValueError('x must be [B,1,%d,T]' % self.w.C)
+        x = x.contiguous()
+        ts = timesteps.to(torch.int64).contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        ws = self._workspace(B, T)
+        _lib.check(self.lib.interdiff_mdm_forward(C.byref(self.w), _lib.dptr(self._memctx), _lib.dptr(x, torch.float32),
+                                                  _lib.dptr(ts, torch.int64), B, T, _lib.dptr(out, torch.float32),
+                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_forward')
+        return out
+
+    __call__ = forward

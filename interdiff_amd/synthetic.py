@@ -1,0 +1,163 @@
+"""Deterministic synthetic stand-ins for the assets the reference cannot ship
+(``diffusion.ckpt`` missing, SMPL-H ``.pkl`` licensed) and for
+BEHAVE-shaped clips.
+
+numpy-only (legacy ``RandomState`` => bit-identical across machines), so that
+the build container (golden generation against the reference), the tests and
+``bench.py`` on the GPU box all see exactly the same weights and inputs.
+Nothing here is on the hot path.
+"""
+import numpy as np
+
+# SMPL-H kinematic tree (public model metadata; reference reads it from
+# kintree_table[0], smpl_layer.py:67-69).  parents[0] is the root marker.
+SMPLH_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+                 20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35,
+                 21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50]
+
+N_LAYERS, QAN_LAYERS = 8, (1, 2, 3, 4, 5, 6)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------
+# denoiser weights (key names + shapes of the reference MDM, decoder path only:
+# model/diffusion_smpl.py:13-17,73-120,177-179)
+# ----------------------------------------------------------------------------
+def mdm_state_dict(seed=233, d=256, ff=1024, n_body=135, n_obj=9, n_queries=10):
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def linear(name, out_f, in_f):
+        b = 1.0 / np.sqrt(in_f)
+        sd[name + '.weight'] = _f32(rs.uniform(-b, b, (out_f, in_f)))
+        sd[name + '.bias'] = _f32(rs.uniform(-b, b, (out_f,)))
+
+    def norm(name):
+        sd[name + '.weight'] = _f32(1.0 + 0.1 * rs.standard_normal(d))
+        sd[name + '.bias'] = _f32(0.1 * rs.standard_normal(d))
+
+    def mha(name):
+        b = np.sqrt(6.0 / (d + 3 * d))
+        sd[name + '.in_proj_weight'] = _f32(rs.uniform(-b, b, (3 * d, d)))
+        sd[name + '.in_proj_bias'] = _f32(0.02 * rs.standard_normal(3 * d))
+        linear(name + '.out_proj', d, d)
+
+    linear('bodyEmbedding', d, n_body)
+    linear('objEmbedding', d, n_obj)
+    linear('embedTimeStep.time_embed.0', d, d)
+    linear('embedTimeStep.time_embed.2', d, d)
+    for l in range(N_LAYERS):
+        p = 'decoder.layers.%d' % l
+        if l in QAN_LAYERS:
+            sd[p + '.queries'] = _f32(rs.normal(-1.0 / np.sqrt(d), 1.0 / np.sqrt(d), (n_queries, d)))
+            sd[p + '.wk'] = _f32(rs.normal(-1.0 / np.sqrt(n_queries), 1.0 / np.sqrt(n_queries), (n_queries, 1)))
+        else:
+            mha(p + '.self_attn')
+        mha(p + '.multihead_attn')
+        linear(p + '.linear1', ff, d)
+        linear(p + '.linear2', d, ff)
+        for k in (1, 2, 3):
+            norm(p + '.norm%d' % k)
+    linear('bodyFinalLinear', n_body, d)
+    linear('objFinalLinear', n_obj, d)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# SMPL-H shaped body model (buffers of smpl_layer.py:47-69)
+# ----------------------------------------------------------------------------
+def smplh_model(seed=7, V=6890, F=13776, n_betas=10):
+    rs = np.random.RandomState(seed)
+    parents = list(SMPLH_PARENTS)
+    J = len(parents)
+    # rest skeleton: child = parent + offset, hands get short bones
+    rest = np.zeros((J, 3))
+    for j in range(1, J):
+        scale = 0.03 if j >= 22 else 0.18
+        rest[j] = rest[parents[j]] + scale * rs.standard_normal(3)
+    # vertices clustered around a primary joint
+    prim = rs.randint(0, J, size=V)
+    prim[:J] = np.arange(J)                                    # every joint owns >= 1 vertex
+    v_template = rest[prim] + 0.04 * rs.standard_normal((V, 3))
+    # skinning weights: primary + up to 3 relatives (parent, grand-parent, random)
+    weights = np.zeros((V, J))
+    par = np.array([max(p, 0) for p in parents])
+    others = np.stack([par[prim], par[par[prim]], rs.randint(0, J, size=V)], axis=1)
+    w = np.concatenate([rs.uniform(0.5, 1.0, (V, 1)), rs.uniform(0.0, 0.3, (V, 3))], axis=1)
+    w[rs.uniform(size=(V, 4)) < 0.15] = 0.0                     # some vertices have < 4 bones
+    w[:, 0] = np.maximum(w[:, 0], 0.2)
+    for c, col in enumerate([prim, others[:, 0], others[:, 1], others[:, 2]]):
+        np.add.at(weights, (np.arange(V), col), w[:, c])
+    weights /= weights.sum(1, keepdims=True)
+    # joint regressor: each joint from 32 vertices of its own cluster (falls back to random)
+    Jreg = np.zeros((J, V))
+    for j in range(J):
+        own = np.nonzero(prim == j)[0]
+        pick = own[:32] if len(own) >= 8 else rs.randint(0, V, size=32)
+        Jreg[j, pick] = rs.uniform(0.5, 1.5, size=len(pick))
+    Jreg /= Jreg.sum(1, keepdims=True)
+    # random but valid (non-degenerate index) triangles touching every vertex
+    faces = np.stack([rs.permutation(F) % V, rs.randint(0, V, F), rs.randint(0, V, F)], axis=1)
+    bad = (faces[:, 0] == faces[:, 1]) | (faces[:, 1] == faces[:, 2]) | (faces[:, 0] == faces[:, 2])
+    faces[bad] = np.stack([faces[bad, 0], (faces[bad, 0] + 1) % V, (faces[bad, 0] + 2) % V], axis=1)
+    return dict(
+        v_template=_f32(v_template),
+        shapedirs=_f32(0.01 * rs.standard_normal((V, 3, n_betas))),
+        posedirs=_f32(2e-3 * rs.standard_normal((V, 3, 9 * (J - 1)))),
+        J_regressor=_f32(Jreg),
+        weights=_f32(weights),
+        faces=np.ascontiguousarray(faces, dtype=np.int64),
+        parents=np.array(parents, dtype=np.int64),
+    )
+
+
+# ----------------------------------------------------------------------------
+# clips
+# ----------------------------------------------------------------------------
+def aa_to_matrix(aa):
+    """Rodrigues, float64 numpy; aa [...,3] -> [...,3,3] (host-side data prep only)."""
+    th = np.linalg.norm(aa, axis=-1, keepdims=True)
+    k = aa / np.maximum(th, 1e-12)
+    K = np.zeros(aa.shape[:-1] + (3, 3))
+    K[..., 0, 1], K[..., 0, 2] = -k[..., 2], k[..., 1]
+    K[..., 1, 0], K[..., 1, 2] = k[..., 2], -k[..., 0]
+    K[..., 2, 0], K[..., 2, 1] = -k[..., 1], k[..., 0]
+    s, c = np.sin(th)[..., None], np.cos(th)[..., None]
+    return np.eye(3) + s * K + (1 - c) * (K @ K)
+
+
+def matrix_to_6d(m):
+    return m[..., :2, :].reshape(m.shape[:-2] + (6,))
+
+
+def make_clip_batch(seed=233, B=16, T=100, past_len=10, n_points=2048, d=256, n_mem=10):
+    """BEHAVE-shaped synthetic batch; all float32 numpy.
+
+    gt [B,1,144,T]  tokens: 22x rot6d | body trans | obj rot6d | obj trans
+    cond [n_mem,B,d], hand_pose [T,B,90], beta [T,B,10] (constant over time),
+    obj_points [B,n_points,3], noise [B,1,144,T]."""
+    rs = np.random.RandomState(seed)
+
+    def walk(shape0, scale, step):
+        x0 = scale * rs.standard_normal((1,) + shape0)
+        return x0 + np.cumsum(step * rs.standard_normal((T,) + shape0), axis=0)
+    body_aa = walk((B, 22, 3), 0.3, 0.02)
+    body_tr = walk((B, 3), 0.1, 0.016)
+    obj_aa = walk((B, 3), 1.0, 0.03)
+    off = 0.35 * rs.standard_normal((1, B, 3))
+    obj_tr = body_tr + off + np.cumsum(0.01 * rs.standard_normal((T, B, 3)), axis=0)
+    gt = np.concatenate([matrix_to_6d(aa_to_matrix(body_aa)).reshape(T, B, 132), body_tr,
+                         matrix_to_6d(aa_to_matrix(obj_aa)), obj_tr], axis=2)         # [T,B,144]
+    beta = np.repeat(rs.standard_normal((1, B, 10)), T, axis=0)
+    return dict(
+        gt=_f32(gt.transpose(1, 2, 0)[:, None]),
+        cond=_f32(rs.standard_normal((n_mem, B, d))),
+        hand_pose=_f32(0.1 * rs.standard_normal((T, B, 90))),
+        beta=_f32(beta),
+        obj_points=_f32(rs.uniform(-0.2, 0.2, (B, n_points, 3))),
+        noise=_f32(rs.standard_normal((B, 1, 144, T))),
+        past_len=past_len,
+    )

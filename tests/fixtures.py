@@ -1,0 +1,126 @@
+"""Seeded input builders shared by tests/golden/make_golden.py (which feeds them to
+the reference) and by the tests (which feed the SAME inputs to the oracle and to
+the HIP path).  numpy RandomState streams only, so every machine sees the same
+numbers.  Torch CPU tensors out."""
+import os
+import functools
+import numpy as np
+import torch
+from interdiff_amd import synthetic as syn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+PAST = 10
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _randn(rs, *shape):
+    return _t(rs.standard_normal(shape).astype(np.float32))
+
+
+@functools.lru_cache(None)
+def mdm_weights():
+    return {k: _t(v) for k, v in syn.mdm_state_dict(seed=233).items()}
+
+
+@functools.lru_cache(None)
+def smpl_model():
+    return {k: _t(v) for k, v in syn.smplh_model(seed=7).items()}
+
+
+@functools.lru_cache(None)
+def objproj_weights():
+    z = golden('correction_ckpt.npz')
+    return {k: _t(z[k]) for k in z.files}
+
+
+def vertex_subset():
+    from oracle.correction import MARKERS67
+    return sorted(set(range(0, 6890, 13)) | set(MARKERS67))
+
+
+def mdm_inputs(B, T):
+    rs = np.random.RandomState(1000 + 37 * B + T)
+    ts = _t(rs.randint(0, 1000, size=B).astype(np.int64))
+    ts[0] = 999
+    return _randn(rs, B, 1, 144, T), ts, _randn(rs, PAST, B, 256)
+
+
+def smpl_inputs(N):
+    rs = np.random.RandomState(2000 + N)
+    pose = 0.4 * _randn(rs, N, 156)
+    pose[0] = 0.0                       # exercises the +1e-8 Rodrigues quirk at zero rotation
+    pose[1, :3] = _t(np.array([3.0, 0.6, -0.4], dtype=np.float32))   # root angle near pi (BEHAVE-like)
+    return pose, _randn(rs, N, 10), _randn(rs, N, 3)
+
+
+def p2p_inputs(N=3, P1=700, P2=300):
+    rs = np.random.RandomState(3000)
+    x, y = 0.5 * _randn(rs, N, P1, 3), 0.5 * _randn(rs, N, P2, 3)
+    y[0, 5] = x[0, 17]                  # zero distance
+    x[1, 40] = x[1, 3]                  # exact tie -> lowest index must win
+    xn = _randn(rs, N, P1, 3)
+    return x, y, xn / xn.norm(dim=-1, keepdim=True)
+
+
+def objproj_inputs(T, B):
+    rs = np.random.RandomState(4000 + T)
+    contact = torch.zeros(B, 67, dtype=torch.int64)
+    contact[1, 20], contact[1, 10], contact[1, 30] = 3, 3, 3     # hand marker 10 wins via +0.5
+    if B > 2:
+        contact[2, 5] = 2
+    return _randn(rs, T, B, 6), _randn(rs, T, B, 3), _randn(rs, T, B, 67, 3), contact
+
+
+def _clip(seed, B, T, P):
+    bt = syn.make_clip_batch(seed=seed, B=B, T=T, past_len=PAST, n_points=P)
+    return {k: (_t(v) if isinstance(v, np.ndarray) else v) for k, v in bt.items()}
+
+
+def model_kwargs_y(bt, T):
+    """The tensor entries of model_kwargs['y'] (eval_smpl_short.py:138-150); the caller adds
+    'smpl' and 'obj_model' in its own representation."""
+    pad = list(range(PAST)) + [PAST - 1] * (T - PAST)
+    mask = torch.ones_like(bt['gt'], dtype=torch.bool)
+    mask[..., PAST:] = False
+    return dict(cond=bt['cond'], inpainted_motion=bt['gt'], inpainting_mask=mask,
+                hand_pose=bt['hand_pose'][pad], beta=bt['beta'], obj_points=bt['obj_points'])
+
+
+DFN_SHAPE = (14, 3, 256)               # T, B, P
+DFN_TS = (500, 250, 0, 499, 550)
+
+
+def denoised_fn_inputs():
+    T, B, P = DFN_SHAPE
+    bt = _clip(5, B, T, P)
+    rs = np.random.RandomState(5000)
+    x = bt['gt'] + 0.05 * _randn(rs, *bt['gt'].shape)
+    x[0, 0, 141:144, :] += 3.0          # clip 0: object far away -> no contact
+    return x, model_kwargs_y(bt, T)
+
+
+LOOP_SHAPE = (12, 2, 64)               # T, B, P : tiny clip, full 1000 steps
+LOOP_DUMPS = [0, 498, 499, 549, 899, 999]
+
+
+class NoiseStream:
+    """Sequential N(0,1) draws; draw k is what the reference's k-th randn_like returned."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+
+    def next_like(self, x):
+        return _randn(self.rs, *x.shape)
+
+
+def loop_inputs():
+    T, B, P = LOOP_SHAPE
+    bt = _clip(11, B, T, P)
+    return bt['noise'], model_kwargs_y(bt, T), NoiseStream(6000)

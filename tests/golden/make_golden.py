@@ -1,0 +1,174 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's
+own source (imported read-only from /root/reference through refshim.py).
+
+Run in the build container only:   python tests/golden/make_golden.py
+Inputs are re-derivable from seeds (interdiff_amd/synthetic.py + the seeded
+torch generators below); the fixtures store the seeds' products that are
+cheap to store plus the reference outputs (sub-sampled where large).
+
+What each fixture pins (reference file:line in brackets):
+  schedule.npz     coefficient tables of SpacedDiffusion(cosine,1000) and (cosine,50)
+                   [diffusion/gaussian_diffusion.py:161-199, respace.py:73-87]
+  mdm.npz          MDM.forward on B=2,T=12 and B=3,T=35  [model/diffusion_smpl.py:239-246]
+  smpl.npz         SMPL_Layer.forward, vertex_normals    [smpl_layer.py:72-175, data/tools.py:4-40]
+  p2p.npz          tools.point2point_signed around the NN stub [tools.py:11-76]
+  objproj.npz      ObjProjector.sample with the REAL checkpoint [model/correction_smpl.py:79-138]
+  correction_ckpt.npz  the real ObjProjector weights (checkpoints/correction.ckpt) as plain arrays
+  denoised_fn.npz  eval_smpl_short.denoised_fn            [eval_smpl_short.py:84-130]
+  loop.npz         GaussianDiffusion.p_sample_loop, full 1000 steps, with the reference MDM and
+                   the reference denoised_fn, injected per-step noise [gaussian_diffusion.py:598-736]
+"""
+import os
+import sys
+import warnings
+from argparse import Namespace
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+warnings.filterwarnings('ignore')
+import refshim                                    # noqa: E402
+from interdiff_amd import synthetic as syn        # noqa: E402
+from tests import fixtures as fx                  # noqa: E402  (shared seeded input builders)
+
+torch.set_grad_enabled(False)
+np_ = lambda t: t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('%-22s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def ref_diffusion(steps):
+    gd = refshim.load('diffusion.gaussian_diffusion')
+    rsp = refshim.load('diffusion.respace')
+    return rsp.SpacedDiffusion(
+        use_timesteps=rsp.space_timesteps(steps, [steps]),
+        betas=gd.get_named_beta_schedule('cosine', steps, 1.),
+        model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+        loss_type=gd.LossType.MSE, rescale_timesteps=False, lambda_vel=1.)
+
+
+def ref_mdm():
+    m = refshim.load('model.diffusion_smpl')
+    args = Namespace(embedding_dim=256, smpl_dim=132, use_pointnet2=1, dropout=0.1, num_heads=4,
+                     ff_size=1024, activation='gelu', latent_usage='memory', future_len=25,
+                     cond_mask_prob=0)
+    net = m.MDM(args).eval()
+    missing, unexpected = net.load_state_dict(fx.mdm_weights(), strict=False)
+    assert not unexpected
+    assert all(k.startswith(('encoder', 'pcEmb', 'finalLinear', 'bodyFuture', 'objFuture', 'PositionalEmbedding',
+                             'embedTimeStep.sequence_pos_encoder')) for k in missing), missing
+    return net
+
+
+def ref_smpl(model):
+    sl = refshim.load('libsmpl.smplpytorch.pytorch.smpl_layer')
+    L = sl.SMPL_Layer.__new__(sl.SMPL_Layer)          # bypass the chumpy .pkl loader
+    torch.nn.Module.__init__(L)
+    L.hands, L.center_idx = True, None
+    L.register_buffer('th_betas', torch.zeros(1, 10))
+    for a, b in (('th_shapedirs', 'shapedirs'), ('th_posedirs', 'posedirs'), ('th_J_regressor', 'J_regressor'),
+                 ('th_weights', 'weights'), ('th_faces', 'faces')):
+        L.register_buffer(a, model[b])
+    L.register_buffer('th_v_template', model['v_template'][None])
+    L.kintree_parents = [int(p) for p in model['parents']]
+    L.num_joints = len(L.kintree_parents)
+    return L
+
+
+def ref_objproj(T, past_len=10):
+    cm = refshim.load('model.correction_smpl')
+    a = Namespace(embedding_dim=64, dct=10, num_verts=67, dropout=0.1, past_len=past_len, future_len=T - past_len)
+    op = cm.ObjProjector(a).eval()
+    op.load_state_dict(fx.objproj_weights())
+    return op
+
+
+def main():
+    # ---- real correction checkpoint -> plain arrays (must exist before fx.objproj_weights())
+    ck = torch.load('/root/reference/interdiff/checkpoints/correction.ckpt', map_location='cpu', weights_only=False)
+    save('correction_ckpt.npz', **{k[len('model.'):]: np_(v) for k, v in ck['state_dict'].items()})
+
+    # ---- schedule
+    out = {}
+    for steps in (1000, 50):
+        d = ref_diffusion(steps)
+        for k in ('betas', 'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped',
+                  'posterior_variance', 'alphas_cumprod'):
+            out['%s_%d' % (k, steps)] = getattr(d, k)
+        assert d.timestep_map == list(range(steps))
+    save('schedule.npz', **out)
+
+    # ---- MDM forward
+    net = ref_mdm()
+    out = {}
+    for tag, (B, T) in (('a', (2, 12)), ('b', (3, 35))):
+        x, ts, cond = fx.mdm_inputs(B, T)
+        out['out_' + tag] = np_(net(x, ts, y={'cond': cond}))
+    save('mdm.npz', **out)
+
+    # ---- SMPL + normals (full-size model, few frames; outputs sub-sampled)
+    model = fx.smpl_model()
+    L = ref_smpl(model)
+    dt = refshim.load('data.tools')
+    pose, betas, trans = fx.smpl_inputs(4)
+    verts, jtr, v_posed, _ = L(pose, th_betas=betas, th_trans=trans)
+    normals = dt.vertex_normals(verts, model['faces'][None].repeat(4, 1, 1))
+    sub = fx.vertex_subset()
+    save('smpl.npz', verts=np_(verts[:, sub]), jtr=np_(jtr), v_posed=np_(v_posed[:, sub]), normals=np_(normals[:, sub]))
+
+    # ---- point2point_signed (reference code around the NN stub)
+    tools = refshim.load('tools')
+    x, y, xn = fx.p2p_inputs()
+    r = tools.point2point_signed(x, y, x_normals=xn, return_vector=True)
+    save('p2p.npz', y2x_signed=np_(r[0]), x2y_signed=np_(r[1]), yidx=np_(r[2]).astype(np.int64),
+         xidx=np_(r[3]).astype(np.int64), y2x=np_(r[4]), x2y=np_(r[5]))
+
+    # ---- ObjProjector.sample, real weights
+    out = {}
+    for tag, (T, B) in (('a', (35, 3)), ('b', (100, 2))):
+        oa, ot, hv, contact = fx.objproj_inputs(T, B)
+        out['out_' + tag] = np_(ref_objproj(T).sample(oa, ot, hv, contact))
+    save('objproj.npz', **out)
+
+    # ---- denoised_fn
+    ev = refshim.load('eval_smpl_short')
+    T, B, P = fx.DFN_SHAPE
+    ev.args = Namespace(smpl_dim=132, past_len=10)
+
+    class Holder:
+        pass
+    om = Holder()
+    om.model = ref_objproj(T)
+    x, y = fx.denoised_fn_inputs()
+    yref = dict(y, smpl=L, obj_model=om)
+    out = {}
+    for tval in fx.DFN_TS:
+        out['out_t%d' % tval] = np_(ev.denoised_fn(x.clone(), torch.full((B,), tval, dtype=torch.int64), {'y': yref}))
+    save('denoised_fn.npz', **out)
+
+    # ---- full 1000-step loop: reference sampler + reference MDM + reference denoised_fn
+    gd = refshim.load('diffusion.gaussian_diffusion')
+    T, B, P = fx.LOOP_SHAPE
+    ev.args = Namespace(smpl_dim=132, past_len=10)
+    om.model = ref_objproj(T)
+    noise, y, stream = fx.loop_inputs()
+    yref = dict(y, smpl=L, obj_model=om)
+    real_randn_like = gd.th.randn_like
+    gd.th.randn_like = lambda x: stream.next_like(x)           # inject the per-step noise
+    try:
+        d = ref_diffusion(1000)
+        dumps = d.p_sample_loop(net, tuple(noise.shape), clip_denoised=False, noise=noise.clone(),
+                                model_kwargs={'y': yref}, denoised_fn=ev.denoised_fn, dump_steps=fx.LOOP_DUMPS)
+    finally:
+        gd.th.randn_like = real_randn_like
+    save('loop.npz', **{'dump_%d' % s: np_(v) for s, v in zip(fx.LOOP_DUMPS, dumps)})
+
+
+if __name__ == '__main__':
+    main()

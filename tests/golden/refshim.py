@@ -1,0 +1,90 @@
+"""Import the REFERENCE's own source (read-only, /root/reference/interdiff) so
+that ``make_golden.py`` can run it and record golden vectors.
+
+Only usable in the build container: /root/reference does not exist on the GPU
+box, and nothing at test/bench run time imports this module.
+
+The reference's third-party deps are absent here (pytorch3d, local_attention,
+pointnet2_ops, chamfer_distance, torchvision, chumpy, cv2, smplx, ...); they
+are replaced by ``sys.modules`` stubs.  Where a stub has to COMPUTE something
+(pytorch3d.transforms, LocalAttention, stochastic_depth) it uses the oracle's
+restatement -- so goldens recorded through those stubs pin the reference's own
+code AROUND them, not the third-party arithmetic itself ("parity unpinned"
+pieces, see oracle/__init__.py).
+"""
+import os
+import sys
+import types
+import importlib
+
+REF = '/root/reference/interdiff'
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+
+
+def available():
+    return os.path.isdir(REF)
+
+
+def install():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    from oracle import rotations, local_attn
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    p3d = mod('pytorch3d')
+    p3d.transforms = mod('pytorch3d.transforms', **{k: getattr(rotations, k) for k in (
+        'axis_angle_to_matrix', 'matrix_to_axis_angle', 'rotation_6d_to_matrix',
+        'matrix_to_rotation_6d', 'axis_angle_to_quaternion', 'quaternion_to_matrix',
+        'matrix_to_quaternion', 'quaternion_to_axis_angle')})
+    mod('local_attention', LocalAttention=local_attn.LocalAttention)
+    tv = mod('torchvision')
+    tv.ops = mod('torchvision.ops',
+                 stochastic_depth=lambda x, p, mode, training=True: x if (p == 0.0 or not training) else (_ for _ in ()).throw(NotImplementedError()))
+
+    class _SA(torch.nn.Module):            # encoder-only dependency ("next" row); never called
+        def __init__(self, *a, **k):
+            super().__init__()
+    pn = mod('pointnet2_ops')
+    pn.pointnet2_modules = mod('pointnet2_ops.pointnet2_modules', PointnetSAModuleMSG=_SA)
+    mod('smplx')
+    ch = mod('chumpy', Ch=object)          # loader-only dep; class body never runs
+    ch.ch = mod('chumpy.ch', MatVecMult=object)
+    mod('cv2')
+
+    # --- nearest neighbour CUDA op (tools.py:9,45-47): indices from the oracle's brute force
+    from oracle import geometry
+
+    class ChamferDistance:
+        def __call__(self, x, y, x_normals=None, y_normals=None):
+            return None, None, geometry.nn_argmin(x, y).int(), geometry.nn_argmin(y, x).int()
+    mod('chamfer_distance', ChamferDistance=ChamferDistance)
+    p3d.loss = mod('pytorch3d.loss')
+    p3d.ops = mod('pytorch3d.ops', cot_laplacian=None)
+    p3d.structures = mod('pytorch3d.structures', Meshes=None)
+    hbp = mod('human_body_prior')
+    hbp.tools = mod('human_body_prior.tools', tgm_conversion=None)
+
+    # --- everything eval_smpl_short.py imports at module level but the hot path never touches
+    pl = mod('pytorch_lightning', seed_everything=lambda *a, **k: None, LightningModule=torch.nn.Module)
+    pl.loggers = mod('pytorch_lightning.loggers')
+    ps = mod('psbody')
+    ps.mesh = mod('psbody.mesh', Mesh=None)
+    mod('data.dataset_smpl', Dataset=None, OBJECT_PATH='')
+    rd = mod('render')
+    rd.mesh_viz = mod('render.mesh_viz', visualize_body_obj=None)
+    mod('train_correction_smpl', LitInteraction=None)
+    mod('train_diffusion_smpl', LitInteraction=None)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def load(name):
+    """e.g. load('diffusion.gaussian_diffusion'), load('model.sublayers')."""
+    install()
+    return importlib.import_module(name)

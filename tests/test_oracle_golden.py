@@ -1,0 +1,144 @@
+"""Pin the oracle (CPU restatement) against golden vectors recorded from the
+reference's OWN source (tests/golden/make_golden.py) and against the known
+answers / closed-form identities of SURVEY.md §8(c).  CPU only."""
+import numpy as np
+import torch
+import pytest
+from tests import fixtures as fx
+from oracle import diffusion as odf, denoiser as oden, smpl as osmpl, geometry as ogeo
+from oracle import objprojector as oobj, correction as ocor, rotations as R
+
+torch.set_grad_enabled(False)
+
+
+def close(a, b, tol, what=''):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    assert err <= tol, '%s rel err %.3e > %.1e' % (what, err, tol)
+
+
+def test_schedule_tables_and_known_answers():
+    z = fx.golden('schedule.npz')
+    for steps in (1000, 50):
+        s = odf.make_schedule(steps)
+        for k in ('betas', 'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped',
+                  'posterior_variance', 'alphas_cumprod'):
+            np.testing.assert_allclose(s[k], z['%s_%d' % (k, steps)], rtol=0, atol=1e-15)
+    s = odf.make_schedule(1000)                                   # SURVEY.md §8(c) known answers
+    assert abs(s['betas'][0] - 4.12842248e-05) < 1e-12 and s['betas'][-1] == 0.999
+    np.testing.assert_allclose(s['posterior_mean_coef1'][[0, 1, 500, 999]],
+                               [1, 0.52778141, 0.00436787, 0.00155689], atol=1e-8)
+    np.testing.assert_allclose(s['posterior_log_variance_clipped'][[0, 1, 500, 999]],
+                               [-10.7340825, -10.7340825, -5.76162185, -1.00292667e-3], atol=1e-7)
+    assert s['posterior_mean_coef2'][0] == 0.0
+
+
+def test_rotation_identities():
+    g = torch.Generator().manual_seed(0)
+    aa = torch.randn(500, 3, generator=g, dtype=torch.float64)
+    M = R.axis_angle_to_matrix(aa)
+    close(M @ M.transpose(-1, -2), torch.eye(3, dtype=torch.float64).expand_as(M), 1e-12, 'orthonormal')
+    close(R.rotation_6d_to_matrix(R.matrix_to_rotation_6d(M)), M, 1e-12, '6d round trip')
+    close(R.axis_angle_to_matrix(R.matrix_to_axis_angle(M)), M, 1e-9, 'aa round trip')
+    close(R.rodrigues_smpl(aa), M, 1e-7, 'SMPL rodrigues == pytorch3d rotation (up to the 1e-8 quirk)')
+    z = torch.zeros(1, 3)
+    close(R.rodrigues_smpl(z), torch.eye(3)[None], 1e-7, 'zero rotation through the +1e-8 quirk')
+    close(R.axis_angle_to_matrix(z), torch.eye(3)[None], 0, 'zero rotation series branch')
+    # scipy as an independent witness
+    from scipy.spatial.transform import Rotation
+    close(M, torch.from_numpy(Rotation.from_rotvec(aa.numpy()).as_matrix()), 1e-12, 'vs scipy')
+
+
+def test_dct_is_orthonormal():
+    for N in (35, 100):
+        d, i = oobj.dct_matrices(N)
+        np.testing.assert_allclose(d @ i, np.eye(N), atol=1e-12)
+        np.testing.assert_allclose(i, d.T, atol=1e-12)
+
+
+def test_mdm_forward():
+    z = fx.golden('mdm.npz')
+    for tag, (B, T) in (('a', (2, 12)), ('b', (3, 35))):
+        x, ts, cond = fx.mdm_inputs(B, T)
+        close(oden.mdm_forward(fx.mdm_weights(), x, ts, cond), z['out_' + tag], 2e-5, 'mdm ' + tag)
+
+
+def test_qan_closed_form_matches_local_attention():
+    """The fused form the HIP kernel uses (constant pre-rotated queries, 3-tap
+    stencil) equals the literal LocalAttention pipeline."""
+    sd, p = fx.mdm_weights(), 'decoder.layers.3'
+    x = torch.randn(9, 2, 256, generator=torch.Generator().manual_seed(1))
+    lit = oden.qan_block(x, sd, p, rotary=True)
+    from interdiff_amd.mdm import qan_constants
+    Qc = torch.from_numpy(qan_constants(sd[p + '.queries'].numpy(), rotary=True))     # [Nq,3,D]
+    T = x.shape[0]
+    xp = torch.cat([torch.zeros(1, 2, 256), x, torch.zeros(1, 2, 256)])
+    nb = torch.stack([xp[0:T], xp[1:T + 1], xp[2:T + 2]], dim=2)                       # [T,B,3,D]
+    logit = torch.einsum('tbjd,njd->tbnj', nb, Qc)
+    valid = torch.ones(T, 3, dtype=torch.bool)
+    valid[0, 0] = valid[-1, 2] = False
+    logit = logit.masked_fill(~valid[:, None, None, :], -torch.finfo(torch.float32).max)
+    c = torch.einsum('tbnj,n->tbj', torch.softmax(logit, -1), sd[p + '.wk'][:, 0])
+    close(torch.einsum('tbj,tbjd->tbd', c, nb), lit, 2e-5, 'qan closed form')
+
+
+def test_smpl_and_normals():
+    z = fx.golden('smpl.npz')
+    model, sub = fx.smpl_model(), fx.vertex_subset()
+    verts, jtr, v_posed = osmpl.smpl_forward(model, *fx.smpl_inputs(4))
+    close(verts[:, sub], z['verts'], 2e-6, 'verts')
+    close(jtr, z['jtr'], 2e-6, 'jtr')
+    close(v_posed[:, sub], z['v_posed'], 2e-6, 'v_posed')
+    close(ogeo.vertex_normals(verts, model['faces'])[:, sub], z['normals'], 1e-4, 'normals')
+    # identity pose: LBS reduces to v_shaped + trans (SURVEY.md §4 closed form)
+    pose, betas, trans = fx.smpl_inputs(4)
+    v0, _, vp0 = osmpl.smpl_forward(model, torch.zeros_like(pose), betas, trans)
+    close(v0, vp0 + trans[:, None], 1e-5, 'identity pose')
+
+
+def test_point2point_signed():
+    z = fx.golden('p2p.npz')
+    x, y, xn = fx.p2p_inputs()
+    r = ogeo.point2point_signed(x, y, x_normals=xn, return_vector=True)
+    assert torch.equal(r[2], torch.from_numpy(z['yidx'])) and torch.equal(r[3], torch.from_numpy(z['xidx']))
+    assert r[3][1, 40] == r[3][1, 3] and r[2][0, 5] == 17
+    for got, k in zip((r[0], r[1], r[4], r[5]), ('y2x_signed', 'x2y_signed', 'y2x', 'x2y')):
+        close(got, z[k], 1e-6, k)
+    with pytest.raises(ValueError):
+        ogeo.point2point_signed(x, y[:2])
+
+
+def test_objprojector_real_checkpoint():
+    z = fx.golden('objproj.npz')
+    for tag, (T, B) in (('a', (35, 3)), ('b', (100, 2))):
+        oa, ot, hv, contact = fx.objproj_inputs(T, B)
+        close(oobj.objprojector_sample(fx.objproj_weights(), oa, ot, hv, contact, fx.PAST), z['out_' + tag], 1e-5, tag)
+
+
+def _y(y):
+    return dict(y, smpl=fx.smpl_model(), obj_model=fx.objproj_weights())
+
+
+def test_denoised_fn():
+    z = fx.golden('denoised_fn.npz')
+    x, y = fx.denoised_fn_inputs()
+    B = x.shape[0]
+    for tval in fx.DFN_TS:
+        got = ocor.denoised_fn(x.clone(), torch.full((B,), tval, dtype=torch.int64), {'y': _y(y)}, past_len=fx.PAST)
+        close(got, z['out_t%d' % tval], 1e-5, 't=%d' % tval)
+    assert np.array_equal(z['out_t499'], x.numpy()) and not np.array_equal(z['out_t500'], x.numpy())
+
+
+def test_full_1000_step_loop():
+    """Oracle sampler + oracle denoiser + oracle correction vs the reference's own
+    p_sample_loop / MDM / denoised_fn over the full 1000 steps (11 corrections)."""
+    z = fx.golden('loop.npz')
+    noise, y, stream = fx.loop_inputs()
+    sd = fx.mdm_weights()
+    model = lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond'])
+    dumps = odf.p_sample_loop(model, tuple(noise.shape), odf.make_schedule(1000), noise.clone(),
+                              lambda i, x: stream.next_like(x), {'y': _y(y)},
+                              denoised_fn=lambda x, t, kw: ocor.denoised_fn(x, t, kw, past_len=fx.PAST),
+                              dump_steps=fx.LOOP_DUMPS)
+    for s, d in zip(fx.LOOP_DUMPS, dumps):
+        close(d, z['dump_%d' % s], 2e-4, 'loop index %d' % s)

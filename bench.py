@@ -1,0 +1,195 @@
+"""bench.py -- denoising-sampler throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one DDPM reverse step (p_sample: denoiser forward + x0-inpainting + [gated correction] +
+posterior update with in-kernel noise) over one batch of B=16 BEHAVE-shaped synthetic clips of T=100
+frames per GPU (BASELINE config #2: eval_smpl_short.py, B=16, T=100, 1000-step DDPM, correction mode).
+The timed region runs the first K iterations of the 1000-step loop (t = 999 .. 1000-K); the default
+K=1000 is one complete sample: 989 plain steps + the 11 correction steps (t in {500,450,..,0}) and the
+once-per-sample memory folding.  Inputs are resident in HBM before the clock starts.
+
+value = frame-steps/s = K * B_total * T / wall  (whole job, all ranks; weak scaling: B=16 per GPU).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from interdiff_amd import synthetic as syn, _lib, dist as idist   # noqa: E402
+from interdiff_amd.mdm import MDM                                  # noqa: E402
+from interdiff_amd.smpl import SMPL_Layer                          # noqa: E402
+from interdiff_amd.objprojector import ObjProjector                # noqa: E402
+from interdiff_amd.correction import HipCorrection                 # noqa: E402
+from interdiff_amd.diffusion import create_gaussian_diffusion      # noqa: E402
+
+B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
+# algorithmic FLOP per token of one denoiser step and of the kernels bench reports on
+FLOP_PER_TOKEN = 11978752 + 2048 * T
+FFN_GEMM_FLOP_PER_TOKEN = 2 * 256 * 1024                    # one of the two FFN GEMMs
+PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
+
+
+def tt(d, dev=None):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+            if dev is not None:
+                v = v.to(dev)
+        out[k] = v
+    return out
+
+
+def build_world(dev, rank):
+    sd = syn.mdm_state_dict(233)
+    smpl_np = syn.smplh_model(7)
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'correction_ckpt.npz'))      # real ObjProjector weights
+    osd = {k: z[k] for k in z.files}
+    model = MDM(sd, device=dev, n_steps=STEPS)
+    smpl = SMPL_Layer(smpl_np, device=dev)
+    corr = HipCorrection(smpl, ObjProjector(osd, T=T, past_len=PAST, device=dev), n_points=P, past_len=PAST, device=dev)
+    bt = tt(syn.make_clip_batch(seed=233 + rank, B=B_PER_GPU, T=T, past_len=PAST, n_points=P), dev)
+    pad = list(range(PAST)) + [PAST - 1] * (T - PAST)
+    mask = torch.ones_like(bt['gt'], dtype=torch.bool)
+    mask[..., PAST:] = False
+    y = dict(cond=bt['cond'], inpainted_motion=bt['gt'], inpainting_mask=mask, hand_pose=bt['hand_pose'][pad].contiguous(),
+             beta=bt['beta'], obj_points=bt['obj_points'])
+    return model, corr, bt, y, (sd, smpl_np, osd)
+
+
+def run_steps(diff, model, corr, bt, y, n_steps, seed):
+    return diff.p_sample_loop(model, tuple(bt['noise'].shape), noise=bt['noise'], clip_denoised=False,
+                              model_kwargs={'y': y}, denoised_fn=corr, seed=seed, n_steps=n_steps)
+
+
+def kernel_profile(diff, model, corr, bt, y, n_steps=30):
+    """Second, instrumented pass: HIP events around every launch (on the launch stream) -> ms per kernel kind."""
+    lib = _lib.load()
+    _lib.check(lib.interdiff_profile_begin(200000))
+    run_steps(diff, model, corr, bt, y, n_steps, seed=1)
+    x = bt['noise'].clone()
+    corr.apply(x, 500, y)                                   # one correction call so its kernels are sampled too
+    ms = (C.c_double * len(_lib.KERNEL_KINDS))()
+    cnt = (C.c_int64 * len(_lib.KERNEL_KINDS))()
+    _lib.check(lib.interdiff_profile_end(ms, cnt))
+    return {k: dict(ms_total=ms[i], launches=int(cnt[i]), us_avg=(1e3 * ms[i] / cnt[i]) if cnt[i] else None)
+            for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
+
+
+def cpu_baseline(assets, bt_cpu, y_cpu):
+    """The oracle (CPU restatement of the reference path), timed on this box's host cores, bounded sample:
+    2 plain denoiser steps at the full B=16,T=100 batch + 1 correction call on 2 of the 16 clips (x8)."""
+    from oracle import diffusion as odf, denoiser as oden, correction as ocor
+    sd, smpl_np, osd = assets
+    sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sched = odf.make_schedule(STEPS)
+    x = bt_cpu['noise'].clone()
+    ts = torch.full((B_PER_GPU,), 999, dtype=torch.int64)
+
+    def plain():
+        x0 = oden.mdm_forward(sd_t, x, ts, y_cpu['cond'])
+        x0 = x0 * (~y_cpu['inpainting_mask']) + y_cpu['inpainted_motion'] * y_cpu['inpainting_mask']
+        return float(sched['posterior_mean_coef1'][999]) * x0 + float(sched['posterior_mean_coef2'][999]) * x + 0.1 * torch.randn_like(x)
+    plain()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        plain()
+    t_plain = (time.perf_counter() - t0) / 2
+    nb = 2
+    ysub = {k: (v[:, :nb] if k in ('cond', 'hand_pose', 'beta') else v[:nb]) if isinstance(v, torch.Tensor) else v
+            for k, v in y_cpu.items()}
+    ysub.update(smpl={k: torch.from_numpy(v) for k, v in smpl_np.items()}, obj_model={k: torch.from_numpy(v) for k, v in osd.items()})
+    t0 = time.perf_counter()
+    ocor.denoised_fn(bt_cpu['gt'][:nb].clone(), torch.full((nb,), 500, dtype=torch.int64), {'y': ysub}, past_len=PAST)
+    t_corr = (time.perf_counter() - t0) * (B_PER_GPU / nb)
+    steps_per_s = STEPS / ((STEPS - 11) * t_plain + 11 * (t_plain + t_corr))
+    return dict(value=steps_per_s * B_PER_GPU * T, unit='frame-steps/s', cores=cores, kind='port',
+                sample='2 plain steps at B=16,T=100 (%.2f s/step) + 1 correction call on 2 of 16 clips scaled x8 (%.1f s/call); '
+                       'blended over 989 plain + 11 corrected steps; torch CPU fp32, %d threads' % (t_plain, t_corr, cores),
+                steps_per_sec=steps_per_s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=STEPS)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    rank, world, local = idist.init_from_env('nccl' if args.gpus > 1 else None)
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    K = max(1, min(args.steps, STEPS))
+    model, corr, bt, y, assets = build_world(dev, rank)
+    diff = create_gaussian_diffusion('cosine', STEPS)
+
+    # untimed warm-up: W plain steps + one correction call (first-use allocations, code objects)
+    run_steps(diff, model, corr, bt, y, max(1, args.warmup), seed=7)
+    corr.apply(bt['noise'].clone(), 500, y)
+    torch.cuda.synchronize()
+
+    idist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model._mem_key = None                                   # the once-per-sample memory folding is inside the clock
+    out = run_steps(diff, model, corr, bt, y, K, seed=233)
+    torch.cuda.synchronize()
+    idist.barrier()
+    wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all()
+
+    prof = None
+    if rank == 0 and not args.no_kernel_profile:
+        prof = kernel_profile(diff, model, corr, bt, y)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(assets, tt({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in bt.items()}),
+                           {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in y.items()})
+    if rank != 0:
+        return
+    Btot = B_PER_GPU * world
+    n_corr = sum(1 for i in range(STEPS - 1, STEPS - 1 - K, -1) if i <= 500 and i % 50 == 0)
+    line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=K * Btot * T / wall,
+                unit='frame-steps/s', n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=1e3 * wall / K,
+                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                steps_per_sec=K / wall,
+                config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
+                                     '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
+                                     'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
+                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, parallelism='clips sharded x%d' % world))
+    if prof:
+        dom = 'gemm_ffn2' if 'gemm_ffn2' in prof else max(prof, key=lambda k: prof[k]['ms_total'])
+        us = prof[dom]['us_avg']
+        flops = FFN_GEMM_FLOP_PER_TOKEN * B_PER_GPU * T
+        ach = flops / (us * 1e-6) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom)
+        line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
+                                traffic=traffic, us_per_launch=us, algorithmic_flop_per_launch=flops)
+        dn = sum(v['ms_total'] for k, v in prof.items() if k.startswith(('embed', 'gemm', 'self_attn', 'rowblock')))
+        nfw = prof['embed']['launches']
+        line['denoiser_forward'] = dict(us=1e3 * dn / nfw, achieved_tflops=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12,
+                                        frac_of_f32_mfma_peak=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+        line['kernels_us'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}
+    if cpu:
+        line['cpu_baseline'] = cpu
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -220,6 +220,23 @@ int interdiff_metrics(const idf_correction_ctx *c, const float *obj_pred, const 
                       int32_t B, int32_t T, int32_t J, float *out6 /* [6][B] */,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Live per-kernel timing for bench.py's `roofline` block (not on the product path).
+ * Between profile_begin and profile_end every kernel launch of the library is preceded by a
+ * hipEventRecord on its stream; profile_end synchronises and attributes the time between
+ * consecutive events to the kernel kind of the first (IDF_K_*).  ms/count arrays have
+ * IDF_K_COUNT entries.
+ * ---------------------------------------------------------------------------------- */
+enum {
+    IDF_K_EMBED = 0, IDF_K_GEMM_QKV, IDF_K_SELF_ATTN, IDF_K_GEMM_OUTPROJ, IDF_K_ROWBLOCK_QAN,
+    IDF_K_ROWBLOCK_STD, IDF_K_GEMM_FFN1, IDF_K_GEMM_FFN2, IDF_K_GEMM_HEADS, IDF_K_MEM_PREP,
+    IDF_K_INPAINT, IDF_K_POSTERIOR, IDF_K_CORR_PREPARE, IDF_K_SMPL_POSE, IDF_K_SMPL_BLEND_SKIN,
+    IDF_K_CORR_CONTACT, IDF_K_CORR_REDUCE, IDF_K_OBJPROJ, IDF_K_CORR_BLEND, IDF_K_OTHER,
+    IDF_K_COUNT
+};
+int interdiff_profile_begin(int32_t capacity);
+int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kind);
+
 #ifdef __cplusplus
 }
 #endif

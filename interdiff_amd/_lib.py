@@ -77,7 +77,13 @@ _SIGS = {
                                        vp, vp, vp, vp, vp, sz, vp]),
     'interdiff_metrics': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                     vp, vp, sz, vp]),
+    'interdiff_profile_begin': (C.c_int, [i32]),
+    'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+
+KERNEL_KINDS = ('embed', 'gemm_qkv', 'self_attn', 'gemm_outproj', 'rowblock_qan', 'rowblock_std', 'gemm_ffn1', 'gemm_ffn2',
+                'gemm_heads', 'mem_prep', 'inpaint', 'posterior', 'corr_prepare', 'smpl_pose', 'smpl_blend_skin',
+                'corr_contact', 'corr_reduce', 'objproj', 'corr_blend', 'other')
 
 _lib = None
 

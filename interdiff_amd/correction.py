@@ -1,0 +1,77 @@
+"""Correction-hook seam: ``denoised_fn(x, t, model_kwargs) -> x`` (eval_smpl_short.py:84-130) on the fused
+``interdiff_correction`` entry point.  ``HipCorrection`` owns the packed SMPL model, mesh adjacency,
+ObjProjector and workspace; calling it mutates and returns ``x`` like the reference does (:129-130)."""
+import ctypes as C
+import numpy as np
+import torch
+from . import _lib
+from .geometry import MeshTopology
+
+MARKERS67 = [3470, 3171, 3327, 857, 1812, 628, 182, 3116, 3040, 239,
+             1666, 1725, 0, 2174, 1568, 1368, 3387, 2112, 1053, 1058,
+             3336, 3346, 1323, 2108, 3122, 3314, 1252, 1082, 1861, 1454,
+             850, 2224, 3233, 1769, 6728, 4343, 5273, 4116, 3694, 6399,
+             6540, 6488, 3749, 5135, 5194, 3512, 5635, 5210, 4360, 4841,
+             6786, 5573, 4538, 4544, 6736, 6747, 4804, 5568, 6544, 6682,
+             5322, 4927, 5686, 4598, 6633, 3506, 3508]      # markerset_ssm67_smplh, data/utils.py:232-238
+
+
+def correction_gate(t0):
+    """eval_smpl_short.py:85: the hook only acts for t <= 500 and t % 50 == 0."""
+    return not (t0 > 500 or t0 % 50 != 0)
+
+
+class HipCorrection:
+    def __init__(self, smpl_layer, objprojector, n_points=2048, past_len=10, markers=MARKERS67, device='cuda'):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.smpl, self.objproj, self.past_len = smpl_layer, objprojector, past_len
+        self.topo = MeshTopology(smpl_layer.th_faces, smpl_layer.cmodel.V, self.device)
+        self.markers_idx = torch.tensor(list(markers), dtype=torch.int32, device=self.device)
+        ctx = _lib.CorrectionCtx()
+        ctx.smpl = C.pointer(smpl_layer.cmodel)
+        ctx.objproj = C.pointer(objprojector.cop)
+        ctx.faces, ctx.adj_ptr = self.topo.faces.data_ptr(), self.topo.adj_ptr.data_ptr()
+        ctx.adj_face, ctx.adj_corner = self.topo.adj_face.data_ptr(), self.topo.adj_corner.data_ptr()
+        ctx.markers_idx = self.markers_idx.data_ptr()
+        ctx.n_markers, ctx.n_points, ctx.past_len = len(markers), n_points, past_len
+        self.ctx = ctx
+        self._ws = None
+        self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call
+
+    def _workspace(self, B, T):
+        need = self.lib.interdiff_correction_workspace_bytes(C.byref(self.ctx), B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def apply(self, x, t0, y):
+        """Run the correction unconditionally for timestep value t0 (host int); x [B,1,144,T] in place."""
+        B, _, Cc, T = x.shape
+        if not x.is_contiguous():
+            raise ValueError('x must be contiguous (it is updated in place)')
+        if y['obj_points'].shape[1] != self.ctx.n_points:
+            raise ValueError('obj_points must have %d points' % self.ctx.n_points)
+        gt = y['inpainted_motion'].contiguous()
+        hp, beta, pts = y['hand_pose'].contiguous().float(), y['beta'].contiguous().float(), y['obj_points'].contiguous().float()
+        ws = self._workspace(B, T)
+        dbg = [None] * 4
+        if self.debug is not None:
+            dbg = [torch.empty(B, dtype=torch.uint8, device=self.device), torch.empty(B, len(MARKERS67), dtype=torch.int32, device=self.device),
+                   torch.empty(B, device=self.device), torch.empty(B, device=self.device)]
+        blend_t = float(np.float32(t0) / np.float32(1000))                      # hard-coded 1000, :128
+        _lib.check(self.lib.interdiff_correction(C.byref(self.ctx), _lib.dptr(x, torch.float32), _lib.dptr(gt, torch.float32),
+                                                 _lib.dptr(hp), _lib.dptr(beta), _lib.dptr(pts), B, T, blend_t,
+                                                 *[_lib.dptr(d, allow_none=True) for d in dbg], _lib.dptr(ws), ws.numel(),
+                                                 _lib.stream()), 'correction')
+        if self.debug is not None:
+            self.debug.update(condition=dbg[0], contact=dbg[1], distance=dbg[2], loss=dbg[3])
+        return x
+
+    def __call__(self, x, t, model_kwargs):
+        t0 = getattr(t, 'host_value', None)
+        if t0 is None:
+            t0 = int(t[0])                      # device sync, like the reference's `t[0] > 500`
+        if not correction_gate(t0):
+            return x
+        return self.apply(x, t0, model_kwargs['y'])

@@ -15,6 +15,11 @@ static inline hipStream_t idf_stream(void *s) { return reinterpret_cast<hipStrea
 static inline int64_t idf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t idf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
+extern bool g_idf_prof_on;
+void idf_prof_mark_slow(int kind, hipStream_t s);
+static inline void idf_prof_mark(int kind, hipStream_t s) { if (g_idf_prof_on) idf_prof_mark_slow(kind, s); }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

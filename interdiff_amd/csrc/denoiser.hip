@@ -459,9 +459,10 @@ Ws carve(void *ws, int64_t N) {
 }
 
 template <bool LN, int EPI>
-void launch_gemm(hipStream_t s, const float *A, int lda, int K, const float *lnw, const float *lnb, const float *W,
+void launch_gemm(int kind, hipStream_t s, const float *A, int lda, int K, const float *lnw, const float *lnb, const float *W,
                  const float *bias, float *C, int ldc, int M, int N, float *xn, const float *resid, int T) {
     dim3 grid((unsigned)idf_cdiv(M, BM), (unsigned)idf_cdiv(N, BN));
+    idf_prof_mark(kind, s);
     hipLaunchKernelGGL((gemm_tile_kernel<LN, EPI>), grid, dim3(256), 0, s, A, lda, K, lnw, lnb, W, bias, C, ldc, M, N, xn,
                        resid, T);
 }
@@ -486,8 +487,10 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
     hipStream_t s = idf_stream(stream);
     float *kv = reinterpret_cast<float *>(ws);
     float *G = memctx, *VW = memctx + (size_t)L * B * HM * D, *g0 = VW + (size_t)L * B * HM * D;
+    idf_prof_mark(IDF_K_MEM_PREP, s);
     hipLaunchKernelGGL(mem_kv_kernel, dim3(2, MEM * B, L), dim3(256), 0, s, w->arena, *w, cond, MEM * B, kv);
     hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VW);
+    idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -503,6 +506,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
     Ws k = carve(ws, N);
     const float *G = memctx, *VW = memctx + (size_t)L * B * HM * D, *g0 = VW + (size_t)L * B * HM * D;
 
+    idf_prof_mark(IDF_K_EMBED, s);
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)idf_cdiv(T, 16), B), dim3(256), C * 16 * sizeof(float), s, x, ts,
                        ar + w->in_w, ar + w->in_b, ar + w->temb_table, ar + w->pe, C, T, w->n_steps, k.uA);
 
@@ -514,19 +518,22 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         const float *Gl = G + (size_t)l * B * HM * D, *VWl = VW + (size_t)l * B * HM * D, *g0l = g0 + (size_t)l * B * HM;
         float *u2;                                                 // pre-norm2 sum
         if (ly.is_qan) {
+            idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
             hipLaunchKernelGGL((rowblock_kernel<true>), dim3((unsigned)idf_cdiv(T, TC), B), dim3(256), 0, s, u_in, lnp_w,
                                lnp_b, ar + ly.qc, ar + ly.wk, ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWl,
                                ar + ly.ca_out_b, u_tmp, T);
             u2 = u_tmp;
         } else {
             // x = LN_prev(u_in) -> xn ; qkv = x.Win^T + b
-            launch_gemm<true, EPI_BIAS>(s, u_in, D, D, lnp_w, lnp_b, ar + ly.sa_in_w, ar + ly.sa_in_b, k.qkv, 3 * D, N, 3 * D,
+            launch_gemm<true, EPI_BIAS>(IDF_K_GEMM_QKV, s, u_in, D, D, lnp_w, lnp_b, ar + ly.sa_in_w, ar + ly.sa_in_b, k.qkv, 3 * D, N, 3 * D,
                                         k.xn, nullptr, T);
+            idf_prof_mark(IDF_K_SELF_ATTN, s);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             // u1 = x + ctx.Wo^T + bo   (into u_tmp)
-            launch_gemm<false, EPI_RESID>(s, k.ctx, D, D, nullptr, nullptr, ar + ly.sa_out_w, ar + ly.sa_out_b, u_tmp, D, N, D,
+            launch_gemm<false, EPI_RESID>(IDF_K_GEMM_OUTPROJ, s, k.ctx, D, D, nullptr, nullptr, ar + ly.sa_out_w, ar + ly.sa_out_b, u_tmp, D, N, D,
                                           nullptr, k.xn, T);
             // u2 = LN1(u1) + cross(LN1(u1))   (into u_in's buffer: the layer input is dead now)
+            idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
             hipLaunchKernelGGL((rowblock_kernel<false>), dim3((unsigned)idf_cdiv(T, TC), B), dim3(256), 0, s, u_tmp, nullptr,
                                nullptr, nullptr, nullptr, ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWl, ar + ly.ca_out_b,
                                u_in, T);
@@ -534,10 +541,10 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         }
         float *u3 = (u2 == k.uA) ? k.uB : k.uA;
         // x2 = LN2(u2) -> xn ; hid = gelu(x2.W1^T + b1)
-        launch_gemm<true, EPI_GELU>(s, u2, D, D, ar + ly.ln_w[1], ar + ly.ln_b[1], ar + ly.ff1_w, ar + ly.ff1_b, k.hid, FF, N, FF,
+        launch_gemm<true, EPI_GELU>(IDF_K_GEMM_FFN1, s, u2, D, D, ar + ly.ln_w[1], ar + ly.ln_b[1], ar + ly.ff1_w, ar + ly.ff1_b, k.hid, FF, N, FF,
                                     k.xn, nullptr, T);
         // u3 = x2 + hid.W2^T + b2
-        launch_gemm<false, EPI_RESID>(s, k.hid, FF, FF, nullptr, nullptr, ar + ly.ff2_w, ar + ly.ff2_b, u3, D, N, D, nullptr,
+        launch_gemm<false, EPI_RESID>(IDF_K_GEMM_FFN2, s, k.hid, FF, FF, nullptr, nullptr, ar + ly.ff2_w, ar + ly.ff2_b, u3, D, N, D, nullptr,
                                       k.xn, T);
         u_in = u3;
         u_tmp = (u3 == k.uA) ? k.uB : k.uA;
@@ -545,7 +552,8 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         lnp_b = ar + ly.ln_b[2];
     }
     // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
-    launch_gemm<true, EPI_HEADS>(s, u_in, D, D, lnp_w, lnp_b, ar + w->out_w, ar + w->out_b, x0, C, N, C, nullptr, nullptr, T);
+    launch_gemm<true, EPI_HEADS>(IDF_K_GEMM_HEADS, s, u_in, D, D, lnp_w, lnp_b, ar + w->out_w, ar + w->out_b, x0, C, N, C, nullptr, nullptr, T);
+    idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }

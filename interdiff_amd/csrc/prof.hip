@@ -1,0 +1,53 @@
+// Per-kernel-kind timing with HIP events on the launch stream (bench.py's roofline block only).
+#include "common.h"
+#include <vector>
+
+bool g_idf_prof_on = false;
+
+namespace {
+std::vector<hipEvent_t> g_ev;
+std::vector<int> g_kind;
+size_t g_cap = 0;
+}  // namespace
+
+void idf_prof_mark_slow(int kind, hipStream_t s) {
+    if (g_ev.size() >= g_cap) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_ev.push_back(e);
+    g_kind.push_back(kind);
+}
+
+extern "C" int interdiff_profile_begin(int32_t capacity) {
+    if (capacity <= 1) return IDF_E_INVAL;
+    for (hipEvent_t e : g_ev) (void)hipEventDestroy(e);
+    g_ev.clear();
+    g_kind.clear();
+    g_cap = (size_t)capacity;
+    g_ev.reserve(g_cap);
+    g_kind.reserve(g_cap);
+    g_idf_prof_on = true;
+    return IDF_OK;
+}
+
+extern "C" int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kind) {
+    if (!ms_per_kind || !count_per_kind) return IDF_E_INVAL;
+    g_idf_prof_on = false;
+    for (int k = 0; k < IDF_K_COUNT; ++k) { ms_per_kind[k] = 0.0; count_per_kind[k] = 0; }
+    if (g_ev.empty()) return IDF_OK;
+    // closing event on the null-stream-synchronising path: wait for the device, then read pairs
+    if (hipDeviceSynchronize() != hipSuccess) return IDF_E_LAUNCH;
+    for (size_t i = 0; i + 1 < g_ev.size(); ++i) {
+        float ms = 0.f;
+        if (g_kind[i] < 0) continue;                       // -1 = "end of a call" marker: gap not attributed
+        if (hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]) == hipSuccess) {
+            ms_per_kind[g_kind[i]] += ms;
+            count_per_kind[g_kind[i]] += 1;
+        }
+    }
+    for (hipEvent_t e : g_ev) (void)hipEventDestroy(e);
+    g_ev.clear();
+    g_kind.clear();
+    return IDF_OK;
+}

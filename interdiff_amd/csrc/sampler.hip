@@ -88,7 +88,9 @@ inline unsigned grid_for(int64_t work) {
 extern "C" int interdiff_inpaint(float *x0, const float *gt, const uint8_t *mask, int64_t n, void *stream) {
     if (!x0 || !gt || !mask || n < 0) return IDF_E_INVAL;
     if (n == 0) return IDF_OK;
+    idf_prof_mark(IDF_K_INPAINT, idf_stream(stream));
     hipLaunchKernelGGL(inpaint_kernel, dim3(grid_for(n)), dim3(256), 0, idf_stream(stream), x0, gt, mask, n);
+    idf_prof_mark(-1, idf_stream(stream));
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -100,12 +102,14 @@ extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(noise)) & 15)
         return IDF_E_INVAL;
     const unsigned g = grid_for((n + 3) / 4);
+    idf_prof_mark(IDF_K_POSTERIOR, idf_stream(stream));
     if (noise)
         hipLaunchKernelGGL((posterior_kernel<false>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2,
                            sigma, seed, step_index);
     else
         hipLaunchKernelGGL((posterior_kernel<true>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2, sigma,
                            seed, step_index);
+    idf_prof_mark(-1, idf_stream(stream));
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }

@@ -1,0 +1,149 @@
+"""Sampler seam: ``p_sample_loop(model, shape, noise=, clip_denoised=False, model_kwargs=, denoised_fn=)``
+(diffusion/gaussian_diffusion.py:598-736) with the step update on ``interdiff_inpaint`` /
+``interdiff_posterior_step``.
+
+Host-side design (not a translation of the reference loop):
+  * the seven fp64 coefficient tables are built once (numpy) and only the three per-step SCALARS the
+    START_X / FIXED_SMALL path needs -- c1[t], c2[t], sigma[t] = exp(.5 logvar[t]) -- are handed to the
+    kernel as fp32 arguments; the reference re-uploads whole tables 6x per step (:1620);
+  * ``t`` tensors for all steps are materialised once; each carries ``host_value`` so the correction hook
+    never syncs on ``t[0]``;
+  * x0-inpainting, the posterior mean and the noise add are two elementwise launches (one when no hook);
+  * per-step noise: ``step_noise`` = tensor [steps,...] / callable(i, x) for deterministic parity, else the
+    in-kernel Philox generator keyed by (seed, loop index).
+Only the configuration the eval path uses is implemented (ModelMeanType.START_X, ModelVarType.FIXED_SMALL,
+clip_denoised=False, identity timestep map); anything else raises NotImplementedError.
+"""
+import math
+import numpy as np
+import torch
+from . import _lib
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=1.):
+    """gaussian_diffusion.py:20-64."""
+    n = num_diffusion_timesteps
+    if schedule_name == 'linear':
+        scale = scale_betas * 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if schedule_name == 'cosine':
+        abar = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.array([min(1 - abar((i + 1) / n) / abar(i / n), 0.999) for i in range(n)], dtype=np.float64)
+    raise NotImplementedError('unknown beta schedule: %s' % schedule_name)
+
+
+class GaussianDiffusion:
+    """START_X / FIXED_SMALL diffusion (the reference's create_gaussian_diffusion configuration)."""
+
+    def __init__(self, betas):
+        betas = np.array(betas, dtype=np.float64)
+        assert betas.ndim == 1 and (betas > 0).all() and (betas <= 1).all()
+        self.betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        # fp32 per-step scalars exactly as `_extract_into_tensor(...).float()` then fp32 math would give them
+        self._c1 = self.posterior_mean_coef1.astype(np.float32)
+        self._c2 = self.posterior_mean_coef2.astype(np.float32)
+        self._sigma = np.exp(np.float32(0.5) * self.posterior_log_variance_clipped.astype(np.float32)).astype(np.float32)
+        self._t_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _timesteps(self, B, device):
+        key = (B, str(device))
+        if key not in self._t_cache:
+            self._t_cache[key] = torch.arange(self.num_timesteps, device=device, dtype=torch.int64)[:, None].repeat(1, B).contiguous()
+        return self._t_cache[key]
+
+    def _step(self, model, img, x0_buf, i, it, t, model_kwargs, denoised_fn, noise_i, seed):
+        lib = _lib.load()
+        y = model_kwargs.get('y', {})
+        x0 = model(img, t, **model_kwargs)
+        if 'inpainting_mask' in y and 'inpainted_motion' in y:
+            m, g = y['inpainting_mask'], y['inpainted_motion']
+            assert x0.shape == m.shape == g.shape
+            mu8 = m if m.dtype == torch.uint8 else m.view(torch.uint8)
+            _lib.check(lib.interdiff_inpaint(_lib.dptr(x0, torch.float32), _lib.dptr(g.contiguous(), torch.float32),
+                                             _lib.dptr(mu8.contiguous()), x0.numel(), _lib.stream()), 'inpaint')
+        if denoised_fn is not None:
+            x0 = denoised_fn(x0, t, model_kwargs)
+        sigma = 0.0 if i == 0 else float(self._sigma[i])
+        _lib.check(lib.interdiff_posterior_step(_lib.dptr(img, torch.float32), _lib.dptr(x0, torch.float32),
+                                                _lib.dptr(noise_i, torch.float32, allow_none=True), img.numel(),
+                                                float(self._c1[i]), float(self._c2[i]), sigma, seed, it, _lib.stream()),
+                   'posterior_step')
+        return x0
+
+    # ------------------------------------------------------------------ public surface
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                      device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
+                      cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None, seed=0, n_steps=None):
+        """Same keyword surface as the reference (:598-614).  Extra: ``step_noise`` (tensor [n,...] or callable
+        (loop_index, x) -> tensor) for deterministic parity, ``seed`` for the in-kernel generator, ``n_steps`` to
+        run only the first n iterations (t = T-1 .. T-n) -- used by the bench / short-chain parity tests."""
+        if clip_denoised:
+            raise NotImplementedError('clip_denoised=True is not used on the eval path (eval_smpl_short.py:153)')
+        if cond_fn is not None or skip_timesteps or init_image is not None or randomize_class or cond_fn_with_grad or const_noise:
+            raise NotImplementedError('only noise=, denoised_fn=, model_kwargs=, dump_steps= are live (SURVEY.md §8(b))')
+        if model_kwargs is None:
+            model_kwargs = {}
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        if noise is not None:
+            img = noise.clone().contiguous().float()             # NOT inpainted when given (:691-692)
+        else:
+            lib = _lib.load()
+            img = torch.empty(*shape, dtype=torch.float32, device=device)
+            _lib.check(lib.interdiff_randn(_lib.dptr(img), img.numel(), seed, 0xFFFFFFFF, _lib.stream()), 'randn')
+            y = model_kwargs.get('y', {})
+            if 'inpainting_mask' in y and 'inpainted_motion' in y:
+                m = y['inpainting_mask']
+                _lib.check(lib.interdiff_inpaint(_lib.dptr(img), _lib.dptr(y['inpainted_motion'].contiguous()),
+                                                 _lib.dptr((m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous()),
+                                                 img.numel(), _lib.stream()), 'inpaint')
+        ts = self._timesteps(shape[0], device)
+        todo = self.num_timesteps if n_steps is None else int(n_steps)
+        dump = []
+        for it, i in enumerate(range(self.num_timesteps - 1, self.num_timesteps - 1 - todo, -1)):
+            t = ts[i]
+            t.host_value = i
+            if step_noise is None:
+                nz = None
+            elif callable(step_noise):
+                nz = step_noise(it, img).contiguous()
+            else:
+                nz = step_noise[it]
+            self._step(model, img, None, i, it, t, model_kwargs, denoised_fn, nz, seed)
+            if dump_steps is not None and it in dump_steps:
+                dump.append(img.clone())
+        return dump if dump_steps is not None else img
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    """respace.py:64-114.  Betas are re-derived from the kept alphas_cumprod; the timestep map is the
+    identity when every step is kept (the only configuration the eval path builds)."""
+
+    def __init__(self, use_timesteps, betas):
+        base = GaussianDiffusion(betas)
+        use = set(use_timesteps)
+        last, new_betas, self.timestep_map = 1.0, [], []
+        for i, ac in enumerate(base.alphas_cumprod):
+            if i in use:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        if self.timestep_map != list(range(len(betas))):
+            raise NotImplementedError('timestep respacing is not used by the reference eval path')
+        super().__init__(np.array(new_betas))
+
+
+def create_gaussian_diffusion(noise_schedule='cosine', diffusion_steps=1000):
+    """model/diffusion_smpl.py:251-284 with its fixed defaults (predict x_start, sigma_small, no respacing)."""
+    betas = get_named_beta_schedule(noise_schedule, diffusion_steps, 1.)
+    return SpacedDiffusion(range(diffusion_steps), betas)

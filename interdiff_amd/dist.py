@@ -1,0 +1,87 @@
+"""Multi-GPU layer: clips are independent through the whole path, so the batch dimension is
+sharded over ranks (one process per GPU), weights / body model are replicated, and the ONLY collective is one
+all-gather of the six per-clip metric vectors per eval batch (RCCL over xGMI: backend "nccl" on ROCm; payload
+<= 6*B_local*4 bytes, latency-bound).  ``gloo`` exercises the same code on CPU in the tests."""
+import os
+import torch
+import torch.distributed as dist
+
+METRIC_KEYS = ('global_mpjpe', 'local_mpjpe', 'body_translation', 'obj_translation', 'obj_rot_error', 'penetrate')
+
+
+def init_from_env(backend=None):
+    """torchrun-style env (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_slice(n_items, rank, world):
+    """Contiguous, balanced shard of n_items for this rank."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
+
+
+def shard_batch(batch, rank, world, batch_dims):
+    """Slice every tensor of `batch` along its clip dimension (batch_dims: name -> dim)."""
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor) and k in batch_dims:
+            n = v.shape[batch_dims[k]]
+            out[k] = v.narrow(batch_dims[k], shard_slice(n, rank, world).start, shard_slice(n, rank, world).stop - shard_slice(n, rank, world).start).contiguous()
+        else:
+            out[k] = v
+    return out
+
+
+def gather_metrics(local, world):
+    """local: dict name -> [B_local] tensor.  Returns dict name -> [B_total] (rank order) on every rank."""
+    stacked = torch.stack([local[k].float() for k in METRIC_KEYS])                 # [6, B_local]
+    if world == 1 or not dist.is_initialized():
+        return {k: stacked[i] for i, k in enumerate(METRIC_KEYS)}
+    sizes = [torch.zeros(1, dtype=torch.int64, device=stacked.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([stacked.shape[1]], dtype=torch.int64, device=stacked.device))
+    mx = int(max(s.item() for s in sizes))
+    pad = torch.zeros(6, mx, device=stacked.device)
+    pad[:, :stacked.shape[1]] = stacked
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)                                                      # the one data collective
+    full = torch.cat([b[:, :int(s.item())] for b, s in zip(bufs, sizes)], dim=1)
+    return {k: full[i] for i, k in enumerate(METRIC_KEYS)}
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def _selftest_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = init_from_env('gloo')
+    B = 5                                                                           # uneven on purpose
+    full = {k: torch.arange(B, dtype=torch.float32) + 10 * i for i, k in enumerate(METRIC_KEYS)}
+    sl = shard_slice(B, r, w)
+    got = gather_metrics({k: v[sl] for k, v in full.items()}, w)
+    for k in METRIC_KEYS:
+        assert torch.equal(got[k], full[k]), (k, got[k], full[k])
+    batch = shard_batch({'gt': torch.arange(B * 3).reshape(B, 3), 'cond': torch.arange(2 * B).reshape(2, B), 'past_len': 10},
+                        r, w, {'gt': 0, 'cond': 1})
+    assert batch['gt'].shape[0] == sl.stop - sl.start and batch['cond'].shape[1] == sl.stop - sl.start and batch['past_len'] == 10
+    assert max_over_ranks(r + 1.5, 'cpu') == w + 0.5
+    barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,95 @@
+"""Body-model seam: ``SMPL_Layer.forward(pose, th_betas, th_trans) -> (verts, jtr, v_posed, naked)``
+(libsmpl/smplpytorch/pytorch/smpl_layer.py:72-175) on top of ``interdiff_smpl_forward``.
+
+The reference loads a licensed chumpy ``.pkl``; this layer takes the seven buffers it would register
+(smpl_layer.py:47-69) as a dict / ``.npz`` and packs them once on the host (see include/interdiff_hip.h):
+  * blend [3V][KB]: rows [posedirs | shapedirs | v_template | 0] so that template, shape and pose blend
+    shapes are ONE GEMM against the feature row [R_1..R_{J-1} - I | beta | 1];
+  * jt, js: the joint regressor applied to template / shape basis (J = jt + js.beta);
+  * ELL skinning weights with the zeros dropped (ascending joint index, like the dense sum).
+"""
+import ctypes as C
+import numpy as np
+import torch
+from . import _lib
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+def pack_smpl_model(model, device):
+    vt = _np(model['v_template']).astype(np.float64).reshape(-1, 3)
+    sdirs = _np(model['shapedirs']).astype(np.float64)
+    pdirs = _np(model['posedirs']).astype(np.float64)
+    jreg = _np(model['J_regressor']).astype(np.float64)
+    wts = _np(model['weights']).astype(np.float32)
+    parents = _np(model['parents']).astype(np.int64).copy()
+    V, J, nb = vt.shape[0], wts.shape[1], sdirs.shape[2]
+    kp = 9 * (J - 1)
+    if pdirs.shape != (V, 3, kp) or jreg.shape != (J, V):
+        raise ValueError('inconsistent SMPL buffers')
+    KB = (kp + nb + 1 + 15) // 16 * 16
+    blend = np.zeros((3 * V, KB), np.float32)
+    blend[:, :kp] = pdirs.reshape(3 * V, kp)
+    blend[:, kp:kp + nb] = sdirs.reshape(3 * V, nb)
+    blend[:, kp + nb] = vt.reshape(3 * V)
+    jt = (jreg @ vt).astype(np.float32)                                        # [J,3]
+    js = np.einsum('jv,vck->jck', jreg, sdirs).astype(np.float32)              # [J,3,nb]
+    nnz = (wts != 0)
+    S = max(1, int(nnz.sum(1).max()))
+    skin_idx = np.zeros((V, S), np.int32)
+    skin_w = np.zeros((V, S), np.float32)
+    for v in range(V):
+        js_ = np.nonzero(nnz[v])[0]
+        skin_idx[v, :len(js_)] = js_
+        skin_w[v, :len(js_)] = wts[v, js_]
+    parents[0] = 0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    bufs = dict(blend=t(blend), jt=t(jt), js=t(js), parents=t(parents.astype(np.int32)), skin_idx=t(skin_idx), skin_w=t(skin_w))
+    m = _lib.SmplModel()
+    m.V, m.J, m.n_betas, m.KB, m.S = V, J, nb, KB, S
+    for k, v in bufs.items():
+        setattr(m, k, v.data_ptr())
+    return m, bufs
+
+
+class SMPL_Layer:
+    def __init__(self, model, device='cuda'):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.cmodel, self._bufs = pack_smpl_model(model, self.device)
+        self.th_faces = torch.from_numpy(_np(model['faces']).astype(np.int64)).to(self.device)
+        self.num_joints = self.cmodel.J
+        self.kintree_parents = [int(p) for p in _np(model['parents'])]
+        self._ws = None
+
+    def _workspace(self, N):
+        need = self.lib.interdiff_smpl_workspace_bytes(C.byref(self.cmodel), N)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, th_pose_axisang, th_betas=None, th_trans=None, th_offsets=None, scale=1., want_v_posed=True):
+        if th_offsets is not None or scale != 1.:
+            raise NotImplementedError('th_offsets / scale are not used on the eval_smpl_short path')
+        N = th_pose_axisang.shape[0]
+        J, V, nb = self.cmodel.J, self.cmodel.V, self.cmodel.n_betas
+        if th_pose_axisang.shape[1] != 3 * J:
+            raise ValueError('pose must be [N,%d]' % (3 * J))
+        if th_betas is None:
+            th_betas = torch.zeros(N, nb, device=self.device)
+        if th_trans is None:
+            th_trans = torch.zeros(N, 3, device=self.device)
+        pose, betas, trans = (a.contiguous().float() for a in (th_pose_axisang, th_betas, th_trans))
+        verts = torch.empty(N, V, 3, dtype=torch.float32, device=self.device)
+        jtr = torch.empty(N, J, 3, dtype=torch.float32, device=self.device)
+        v_posed = torch.empty(N, V, 3, dtype=torch.float32, device=self.device) if want_v_posed else None
+        ws = self._workspace(N)
+        _lib.check(self.lib.interdiff_smpl_forward(C.byref(self.cmodel), _lib.dptr(pose, torch.float32), _lib.dptr(betas, torch.float32),
+                                                   _lib.dptr(trans, torch.float32), N, _lib.dptr(verts), _lib.dptr(jtr),
+                                                   _lib.dptr(v_posed, allow_none=True), _lib.dptr(ws), ws.numel(), _lib.stream()),
+                   'smpl_forward')
+        return verts, jtr, v_posed, v_posed
+
+    __call__ = forward

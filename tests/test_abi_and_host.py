@@ -1,0 +1,102 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/interdiff_hip.h declares; host-side packing
+logic (no GPU compute calls)."""
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+import torch
+from tests import fixtures as fx
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'interdiff_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(interdiff_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from interdiff_amd import _lib
+    lib = _lib.load()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r' T (interdiff_[a-z0-9_]+)', out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(_lib.exported_symbols()) == set(declared), 'ctypes table out of sync with the header'
+    assert lib.interdiff_abi_version() == _lib.ABI_VERSION
+    assert b'gfx950' in lib.interdiff_build_info()
+
+
+def test_no_cpu_fallback():
+    from interdiff_amd import transforms, _lib
+    with pytest.raises(ValueError):
+        transforms.axis_angle_to_matrix(torch.zeros(2, 3))          # CPU tensor -> loud failure, not a silent fallback
+    assert issubclass(_lib.HipLibraryMissing, RuntimeError)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'interdiff_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+                assert '/root/reference' not in txt, f
+
+
+def test_schedule_scalars_match_oracle():
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    from oracle import diffusion as odf
+    for steps in (1000, 50):
+        d, s = create_gaussian_diffusion('cosine', steps), odf.make_schedule(steps)
+        for k in ('betas', 'posterior_mean_coef1', 'posterior_mean_coef2', 'posterior_log_variance_clipped'):
+            np.testing.assert_allclose(getattr(d, k), s[k], rtol=0, atol=1e-15)
+        z = fx.golden('schedule.npz')
+        np.testing.assert_allclose(d.posterior_mean_coef1, z['posterior_mean_coef1_%d' % steps], rtol=0, atol=1e-15)
+    assert d._sigma.dtype == np.float32 and d._c1.dtype == np.float32
+
+
+def test_vertex_adjacency_order():
+    from interdiff_amd.geometry import build_vertex_adjacency
+    faces = np.array([[0, 1, 2], [2, 1, 3], [1, 0, 3]])
+    ptr, af, ac = build_vertex_adjacency(faces, 4)
+    assert ptr.tolist() == [0, 2, 5, 7, 9]
+    # vertex 1: corner-1 faces first (0, 1), then corner-2 (none), then corner-0 (face 2)
+    assert af[ptr[1]:ptr[2]].tolist() == [0, 1, 2] and ac[ptr[1]:ptr[2]].tolist() == [1, 1, 0]
+    # vertex 3: corner 2 of faces 1 and 2
+    assert af[ptr[3]:ptr[4]].tolist() == [1, 2] and ac[ptr[3]:ptr[4]].tolist() == [2, 2]
+
+
+def test_pack_smpl_model_host_side():
+    from interdiff_amd.smpl import pack_smpl_model
+    model = fx.smpl_model()
+    m, bufs = pack_smpl_model(model, 'cpu')
+    assert (m.V, m.J, m.n_betas, m.KB) == (6890, 52, 10, 480) and 1 <= m.S <= 4
+    betas = torch.randn(10)
+    J_ref = model['J_regressor'] @ (model['v_template'] + torch.einsum('vck,k->vc', model['shapedirs'], betas))
+    J_got = bufs['jt'] + torch.einsum('jck,k->jc', bufs['js'], betas)
+    assert (J_ref - J_got).abs().max() < 1e-5
+    dense = torch.zeros(6890, 52)
+    dense.scatter_add_(1, bufs['skin_idx'].long(), bufs['skin_w'])
+    assert torch.equal(dense, model['weights'])
+
+
+def test_pack_objprojector_folds():
+    from interdiff_amd.objprojector import pack_objprojector, dct_matrices
+    op, arena = pack_objprojector(fx.objproj_weights(), T=35, past_len=10, device='cpu')
+    d, _ = dct_matrices(35)
+    dpad = arena[op.dct_pad:op.dct_pad + 100].reshape(10, 10).double().numpy()
+    pad = list(range(10)) + [9] * 25
+    x = np.random.RandomState(0).randn(35)
+    np.testing.assert_allclose(dpad @ x[:10], d[:10] @ x[pad], atol=1e-5)
+    assert list(op.cin) == [9, 32, 16, 32] * 3 and list(op.cout) == [32, 16, 32, 9] * 3
+
+
+def test_gloo_sharding_world2():
+    """N>1 path on CPU: clips are sharded over ranks, metrics all-gathered (gloo stands in for RCCL)."""
+    import torch.multiprocessing as mp
+    from interdiff_amd import dist as idist
+    mp.spawn(idist._selftest_worker, args=(2, 29517), nprocs=2, join=True)

@@ -1,0 +1,233 @@
+"""GPU parity tests: every HIP entry point (through the C-ABI, via the ctypes host layer) against the CPU
+oracle on the same seeded inputs and against the golden fixtures recorded from the reference's own source.
+Tolerance: north_star's 1e-4 relative fp32 (max|delta| / max|ref|), tighter where the op allows; bit-exact for
+indices and decisions.  Run with:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+from tests import fixtures as fx
+from oracle import diffusion as odf, denoiser as oden, smpl as osmpl, geometry as ogeo
+from oracle import objprojector as oobj, correction as ocor, rotations as R
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def close(a, b, tol, what=''):
+    e = rel(a, b)
+    assert e <= tol, '%s: rel err %.3e > %.1e' % (what, e, tol)
+    return e
+
+
+def dev(x):
+    return {k: dev(v) for k, v in x.items()} if isinstance(x, dict) else (x.to(DEV) if isinstance(x, torch.Tensor) else x)
+
+
+@pytest.fixture(scope='module')
+def mdm(lib):
+    from interdiff_amd.mdm import MDM
+    return MDM(fx.mdm_weights(), device=DEV)
+
+
+@pytest.fixture(scope='module')
+def smpl(lib):
+    from interdiff_amd.smpl import SMPL_Layer
+    return SMPL_Layer(fx.smpl_model(), device=DEV)
+
+
+def make_correction(smpl, T, P):
+    from interdiff_amd.objprojector import ObjProjector
+    from interdiff_amd.correction import HipCorrection
+    op = ObjProjector(fx.objproj_weights(), T=T, past_len=fx.PAST, device=DEV)
+    return HipCorrection(smpl, op, n_points=P, past_len=fx.PAST, device=DEV)
+
+
+# ------------------------------------------------------------------------------------------ rotations (C2)
+def test_rotations(lib):
+    from interdiff_amd import transforms as tr
+    g = torch.Generator().manual_seed(3)
+    aa = torch.randn(4000, 3, generator=g)
+    aa[0] = 0.0
+    aa[1] = torch.tensor([1e-8, 0, 0])
+    aa[2] = torch.tensor([3.1, 0.01, -0.02])                      # near pi
+    d6 = torch.randn(7, 11, 6, generator=g)
+    M = R.axis_angle_to_matrix(aa)
+    close(tr.axis_angle_to_matrix(aa.to(DEV)), M, 1e-6, 'aa->matrix')
+    close(tr.axis_angle_to_quaternion(aa.to(DEV)), R.axis_angle_to_quaternion(aa), 1e-6, 'aa->quat')
+    close(tr.rotation_6d_to_matrix(d6.to(DEV)), R.rotation_6d_to_matrix(d6), 1e-6, '6d->matrix')
+    close(tr.matrix_to_rotation_6d(M.to(DEV)), R.matrix_to_rotation_6d(M), 0, 'matrix->6d')
+    # axis-angle representative can legitimately differ near pi / by quaternion branch: compare the ROTATION
+    got = tr.matrix_to_axis_angle(M.to(DEV)).cpu()
+    close(R.axis_angle_to_matrix(got), M, 2e-6, 'matrix->aa (as rotation)')
+    same_branch = (got - R.matrix_to_axis_angle(M)).abs().max(dim=1)[0] < 1e-3
+    assert same_branch.float().mean() > 0.99
+    got = tr.rotation_6d_to_axis_angle(d6.to(DEV)).cpu()
+    close(R.axis_angle_to_matrix(got), R.rotation_6d_to_matrix(d6), 2e-6, '6d->aa (as rotation)')
+
+
+# ------------------------------------------------------------------------------------------ denoiser (A1-A4)
+@pytest.mark.parametrize('tag,B,T', [('a', 2, 12), ('b', 3, 35)])
+def test_mdm_forward_golden(mdm, tag, B, T):
+    x, ts, cond = fx.mdm_inputs(B, T)
+    got = mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+    close(got, fx.golden('mdm.npz')['out_' + tag], 1e-4, 'vs reference golden')
+    close(got, oden.mdm_forward(fx.mdm_weights(), x, ts, cond), 1e-4, 'vs oracle')
+
+
+def test_mdm_forward_bench_shape(mdm):
+    """BASELINE config #2 shape (B=16, T=100) against the oracle; also ragged T and B=1."""
+    for B, T in ((16, 100), (1, 30), (5, 37)):
+        x, ts, cond = fx.mdm_inputs(B, T)
+        got = mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+        close(got, oden.mdm_forward(fx.mdm_weights(), x, ts, cond), 1e-4, 'B=%d T=%d' % (B, T))
+
+
+def test_mdm_no_rotary_switch(lib):
+    from interdiff_amd.mdm import MDM
+    x, ts, cond = fx.mdm_inputs(2, 12)
+    got = MDM(fx.mdm_weights(), device=DEV, rotary=False)(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+    close(got, oden.mdm_forward(fx.mdm_weights(), x, ts, cond, rotary=False), 1e-4, 'rotary off')
+
+
+# ------------------------------------------------------------------------------------------ sampler update (S4-S5)
+def test_posterior_step_and_inpaint(lib):
+    from interdiff_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 7, 4096, 16 * 144 * 100):
+        x, x0, eps = (torch.randn(n, generator=g) for _ in range(3))
+        c1, c2, s = np.float32(0.3), np.float32(0.69), np.float32(0.05)
+        xd = x.to(DEV)
+        _lib.check(lib.interdiff_posterior_step(_lib.dptr(xd), _lib.dptr(x0.to(DEV)), _lib.dptr(eps.to(DEV)), n, c1, c2, s, 0, 0, _lib.stream()))
+        close(xd, c1 * x0 + c2 * x + s * eps, 1e-6, 'posterior n=%d' % n)
+        gt, mask = torch.randn(n, generator=g), torch.rand(n, generator=g) < 0.3
+        x0d = x0.to(DEV)
+        _lib.check(lib.interdiff_inpaint(_lib.dptr(x0d), _lib.dptr(gt.to(DEV)), _lib.dptr(mask.to(DEV).view(torch.uint8)), n, _lib.stream()))
+        assert torch.equal(x0d.cpu(), torch.where(mask, gt, x0))
+
+
+def test_inkernel_noise_is_standard_normal(lib):
+    from interdiff_amd import _lib
+    n = 1 << 22
+    a, b = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    _lib.check(lib.interdiff_randn(_lib.dptr(a), n, 233, 5, _lib.stream()))
+    _lib.check(lib.interdiff_randn(_lib.dptr(b), n, 233, 6, _lib.stream()))
+    for v in (a, b):
+        assert abs(v.mean().item()) < 3e-3 and abs(v.std().item() - 1) < 3e-3
+        assert abs((v ** 4).mean().item() - 3) < 0.05 and v.abs().max().item() < 7
+    assert abs((a * b).mean().item()) < 3e-3                         # different steps are independent streams
+    c = torch.empty(n, device=DEV)
+    _lib.check(lib.interdiff_randn(_lib.dptr(c), n, 233, 5, _lib.stream()))
+    assert torch.equal(a, c)                                         # counter-based => reproducible
+    # posterior step with generated noise == posterior step with that noise handed in
+    x = torch.randn(n, device=DEV)
+    x1, x2, x0 = x.clone(), x.clone(), torch.randn(n, device=DEV)
+    _lib.check(lib.interdiff_posterior_step(_lib.dptr(x1), _lib.dptr(x0), None, n, 0.25, 0.5, 0.125, 233, 5, _lib.stream()))
+    _lib.check(lib.interdiff_posterior_step(_lib.dptr(x2), _lib.dptr(x0), _lib.dptr(a), n, 0.25, 0.5, 0.125, 233, 5, _lib.stream()))
+    assert torch.equal(x1, x2)
+
+
+# ------------------------------------------------------------------------------------------ SMPL (B1-B3), normals (B4)
+def test_smpl_forward_golden(smpl):
+    z, sub = fx.golden('smpl.npz'), fx.vertex_subset()
+    pose, betas, trans = fx.smpl_inputs(4)
+    verts, jtr, v_posed, _ = smpl(pose.to(DEV), th_betas=betas.to(DEV), th_trans=trans.to(DEV))
+    close(verts[:, sub], z['verts'], 1e-5, 'verts vs reference golden')
+    close(jtr, z['jtr'], 1e-5, 'jtr')
+    close(v_posed[:, sub], z['v_posed'], 1e-5, 'v_posed')
+    from interdiff_amd.geometry import vertex_normals
+    n1 = vertex_normals(verts, smpl.th_faces[None].repeat(4, 1, 1))
+    close(n1[:, sub], z['normals'], 1e-4, 'normals vs reference golden')
+    ref = ogeo.vertex_normals(verts.cpu(), fx.smpl_model()['faces'])
+    close(n1, ref, 1e-5, 'normals vs oracle on the same verts')
+
+
+def test_smpl_forward_ragged_and_identity(smpl):
+    model = fx.smpl_model()
+    for N in (1, 37):
+        pose, betas, trans = fx.smpl_inputs(N)
+        verts, jtr, v_posed, _ = smpl(pose.to(DEV), th_betas=betas.to(DEV), th_trans=trans.to(DEV))
+        rv, rj, rp = osmpl.smpl_forward(model, pose, betas, trans)
+        close(verts, rv, 1e-5, 'verts N=%d' % N)
+        close(jtr, rj, 1e-5, 'jtr N=%d' % N)
+        close(v_posed, rp, 1e-5, 'v_posed N=%d' % N)
+    pose, betas, trans = fx.smpl_inputs(3)
+    verts, _, v_posed, _ = smpl(torch.zeros_like(pose).to(DEV), th_betas=betas.to(DEV), th_trans=trans.to(DEV))
+    close(verts, v_posed + trans.to(DEV)[:, None], 1e-5, 'identity pose => v_shaped + trans')
+
+
+# ------------------------------------------------------------------------------------------ NN / signed distance (B5)
+def test_point2point_signed_golden(lib):
+    from interdiff_amd.geometry import point2point_signed
+    z = fx.golden('p2p.npz')
+    x, y, xn = fx.p2p_inputs()
+    r = point2point_signed(x.to(DEV), y.to(DEV), x_normals=xn.to(DEV), return_vector=True)
+    assert np.array_equal(r[2].cpu().numpy().astype(np.int64), z['yidx']), 'yidx must be bit-exact'
+    assert np.array_equal(r[3].cpu().numpy().astype(np.int64), z['xidx']), 'xidx must be bit-exact'
+    assert r[3][1, 40] == r[3][1, 3] and r[2][0, 5] == 17             # tie -> lowest index; zero distance
+    for got, k in zip((r[0], r[1], r[4], r[5]), ('y2x_signed', 'x2y_signed', 'y2x', 'x2y')):
+        close(got, z[k], 1e-6, k)
+    assert len(point2point_signed(x.to(DEV), y.to(DEV))) == 4
+    with pytest.raises(ValueError):
+        point2point_signed(x.to(DEV), y[:2].to(DEV))
+
+
+def test_nn_argmin_full_size_bit_exact(lib):
+    """6890 x 2048 (the hot-path size) against the oracle: indices identical, both directions."""
+    from interdiff_amd.geometry import nn_argmin
+    g = torch.Generator().manual_seed(9)
+    x, y = 0.5 * torch.randn(2, 6890, 3, generator=g), 0.5 * torch.randn(2, 2048, 3, generator=g)
+    assert torch.equal(nn_argmin(y.to(DEV), x.to(DEV)).cpu().long(), ogeo.nn_argmin(y, x))
+    assert torch.equal(nn_argmin(x.to(DEV), y.to(DEV)).cpu().long(), ogeo.nn_argmin(x, y))
+
+
+# ------------------------------------------------------------------------------------------ ObjProjector (D1-D2)
+@pytest.mark.parametrize('tag,T,B', [('a', 35, 3), ('b', 100, 2)])
+def test_objprojector_golden(lib, tag, T, B):
+    from interdiff_amd.objprojector import ObjProjector
+    oa, ot, hv, contact = fx.objproj_inputs(T, B)
+    op = ObjProjector(fx.objproj_weights(), T=T, past_len=fx.PAST, device=DEV)
+    got = op.sample(oa.to(DEV), ot.to(DEV), hv.to(DEV), contact.to(DEV))
+    close(got, fx.golden('objproj.npz')['out_' + tag], 1e-4, 'vs reference golden (real checkpoint)')
+    close(got, oobj.objprojector_sample(fx.objproj_weights(), oa, ot, hv, contact, fx.PAST), 1e-4, 'vs oracle')
+
+
+# ------------------------------------------------------------------------------------------ denoised_fn (C1)
+def test_denoised_fn_golden(smpl):
+    z = fx.golden('denoised_fn.npz')
+    T, B, P = fx.DFN_SHAPE
+    corr = make_correction(smpl, T, P)
+    corr.debug = {}
+    x, y = fx.denoised_fn_inputs()
+    terms = ocor.correction_terms(x.clone(), dict(y, smpl=fx.smpl_model()), fx.PAST)
+    for tval in fx.DFN_TS:
+        t = torch.full((B,), tval, dtype=torch.int64, device=DEV)
+        got = corr(x.clone().to(DEV), t, {'y': dev(y)})
+        close(got, z['out_t%d' % tval], 1e-4, 'denoised_fn t=%d vs reference golden' % tval)
+    assert torch.equal(corr.debug['condition'].cpu().bool(), terms['condition'])
+    assert torch.equal(corr.debug['contact'].cpu().long(), terms['contact'])
+    close(corr.debug['distance'], terms['distance'], 1e-5, 'distance')
+    close(corr.debug['loss'], terms['loss'][fx.PAST:].mean(dim=2).mean(dim=0), 1e-4, 'loss')
+
+
+# ------------------------------------------------------------------------------------------ whole sampler (S1-S5 + everything)
+def test_full_1000_step_loop_golden(mdm, smpl):
+    """HIP sampler + HIP denoiser + HIP correction over the full 1000 steps (11 corrections) with injected
+    noise, against the reference's own p_sample_loop / MDM / denoised_fn run (tests/golden/loop.npz)."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    z = fx.golden('loop.npz')
+    T, B, P = fx.LOOP_SHAPE
+    noise, y, stream = fx.loop_inputs()
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', 1000)
+    dumps = diff.p_sample_loop(mdm, tuple(noise.shape), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)},
+                               denoised_fn=corr, dump_steps=fx.LOOP_DUMPS, step_noise=lambda i, x: stream.next_like(x).to(DEV))
+    worst = 0.0
+    for s, d in zip(fx.LOOP_DUMPS, dumps):
+        worst = max(worst, close(d, z['dump_%d' % s], 5e-4, 'loop index %d' % s))
+    print('full-loop worst rel err %.2e' % worst)

@@ -23,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T0 = time.perf_counter()
 from interdiff_amd import synthetic as syn, _lib, dist as idist   # noqa: E402
 from interdiff_amd.mdm import MDM                                  # noqa: E402
 from interdiff_amd.smpl import SMPL_Layer                          # noqa: E402
@@ -84,13 +85,30 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
             for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
 
 
+def log(msg):
+    print('[bench %7.1fs] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that
+    reports 100+ cores but is throttled to a few would otherwise thrash) and by 32."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(assets, bt_cpu, y_cpu):
     """The oracle (CPU restatement of the reference path), timed on this box's host cores, bounded sample:
-    2 plain denoiser steps at the full B=16,T=100 batch + 1 correction call on 2 of the 16 clips (x8)."""
+    2 plain denoiser steps at the full B=16,T=100 batch + 1 correction call on 1 of the 16 clips (x16)."""
     from oracle import diffusion as odf, denoiser as oden, correction as ocor
     sd, smpl_np, osd = assets
     sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sched = odf.make_schedule(STEPS)
     x = bt_cpu['noise'].clone()
@@ -105,7 +123,7 @@ def cpu_baseline(assets, bt_cpu, y_cpu):
     for _ in range(2):
         plain()
     t_plain = (time.perf_counter() - t0) / 2
-    nb = 2
+    nb = 1
     ysub = {k: (v[:, :nb] if k in ('cond', 'hand_pose', 'beta') else v[:nb]) if isinstance(v, torch.Tensor) else v
             for k, v in y_cpu.items()}
     ysub.update(smpl={k: torch.from_numpy(v) for k, v in smpl_np.items()}, obj_model={k: torch.from_numpy(v) for k, v in osd.items()})
@@ -114,7 +132,7 @@ def cpu_baseline(assets, bt_cpu, y_cpu):
     t_corr = (time.perf_counter() - t0) * (B_PER_GPU / nb)
     steps_per_s = STEPS / ((STEPS - 11) * t_plain + 11 * (t_plain + t_corr))
     return dict(value=steps_per_s * B_PER_GPU * T, unit='frame-steps/s', cores=cores, kind='port',
-                sample='2 plain steps at B=16,T=100 (%.2f s/step) + 1 correction call on 2 of 16 clips scaled x8 (%.1f s/call); '
+                sample='2 plain steps at B=16,T=100 (%.2f s/step) + 1 correction call on 1 of 16 clips scaled x16 (%.1f s/call); '
                        'blended over 989 plain + 11 corrected steps; torch CPU fp32, %d threads' % (t_plain, t_corr, cores),
                 steps_per_sec=steps_per_s)
 
@@ -133,13 +151,16 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     K = max(1, min(args.steps, STEPS))
+    log('building world (weights, SMPL-H stand-in, clips) on %s' % dev)
     model, corr, bt, y, assets = build_world(dev, rank)
+    log('world ready')
     diff = create_gaussian_diffusion('cosine', STEPS)
 
     # untimed warm-up: W plain steps + one correction call (first-use allocations, code objects)
     run_steps(diff, model, corr, bt, y, max(1, args.warmup), seed=7)
     corr.apply(bt['noise'].clone(), 500, y)
     torch.cuda.synchronize()
+    log('warm-up done')
 
     idist.barrier()
     torch.cuda.synchronize()
@@ -150,14 +171,17 @@ def main():
     idist.barrier()
     wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all()
+    log('timed region: %d steps in %.3f s' % (K, wall))
 
     prof = None
     if rank == 0 and not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
+        log('kernel profile done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(assets, tt({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in bt.items()}),
                            {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in y.items()})
+    log('cpu baseline done' if cpu else 'cpu baseline skipped')
     if rank != 0:
         return
     Btot = B_PER_GPU * world

@@ -67,9 +67,9 @@ class GaussianDiffusion:
         if 'inpainting_mask' in y and 'inpainted_motion' in y:
             m, g = y['inpainting_mask'], y['inpainted_motion']
             assert x0.shape == m.shape == g.shape
-            mu8 = m if m.dtype == torch.uint8 else m.view(torch.uint8)
-            _lib.check(lib.interdiff_inpaint(_lib.dptr(x0, torch.float32), _lib.dptr(g.contiguous(), torch.float32),
-                                             _lib.dptr(mu8.contiguous()), x0.numel(), _lib.stream()), 'inpaint')
+            mu8, gc = (m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous(), g.contiguous()
+            _lib.check(lib.interdiff_inpaint(_lib.dptr(x0, torch.float32), _lib.dptr(gc, torch.float32), _lib.dptr(mu8),
+                                             x0.numel(), _lib.stream()), 'inpaint')
         if denoised_fn is not None:
             x0 = denoised_fn(x0, t, model_kwargs)
         sigma = 0.0 if i == 0 else float(self._sigma[i])
@@ -104,9 +104,8 @@ class GaussianDiffusion:
             y = model_kwargs.get('y', {})
             if 'inpainting_mask' in y and 'inpainted_motion' in y:
                 m = y['inpainting_mask']
-                _lib.check(lib.interdiff_inpaint(_lib.dptr(img), _lib.dptr(y['inpainted_motion'].contiguous()),
-                                                 _lib.dptr((m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous()),
-                                                 img.numel(), _lib.stream()), 'inpaint')
+                mu8, gc = (m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous(), y['inpainted_motion'].contiguous()
+                _lib.check(lib.interdiff_inpaint(_lib.dptr(img), _lib.dptr(gc), _lib.dptr(mu8), img.numel(), _lib.stream()), 'inpaint')
         ts = self._timesteps(shape[0], device)
         todo = self.num_timesteps if n_steps is None else int(n_steps)
         dump = []

@@ -95,6 +95,6 @@ def nn_argmin(q, r):
     lib = _lib.load()
     N, Pq, _ = q.shape
     idx = torch.empty(N, Pq, dtype=torch.int32, device=q.device)
-    _lib.check(lib.interdiff_nn_argmin(_lib.dptr(q.contiguous().float()), Pq, _lib.dptr(r.contiguous().float()), r.shape[1], N,
-                                       _lib.dptr(idx), _lib.stream()), 'nn_argmin')
+    qc, rc = q.contiguous().float(), r.contiguous().float()       # hold references until the launch is enqueued
+    _lib.check(lib.interdiff_nn_argmin(_lib.dptr(qc), Pq, _lib.dptr(rc), r.shape[1], N, _lib.dptr(idx), _lib.stream()), 'nn_argmin')
     return idx

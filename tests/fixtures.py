@@ -56,7 +56,8 @@ def smpl_inputs(N):
     rs = np.random.RandomState(2000 + N)
     pose = 0.4 * _randn(rs, N, 156)
     pose[0] = 0.0                       # exercises the +1e-8 Rodrigues quirk at zero rotation
-    pose[1, :3] = _t(np.array([3.0, 0.6, -0.4], dtype=np.float32))   # root angle near pi (BEHAVE-like)
+    if N > 1:
+        pose[1, :3] = _t(np.array([3.0, 0.6, -0.4], dtype=np.float32))   # root angle near pi (BEHAVE-like)
     return pose, _randn(rs, N, 10), _randn(rs, N, 3)
 
 

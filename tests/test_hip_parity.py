@@ -102,12 +102,12 @@ def test_posterior_step_and_inpaint(lib):
     for n in (1, 7, 4096, 16 * 144 * 100):
         x, x0, eps = (torch.randn(n, generator=g) for _ in range(3))
         c1, c2, s = np.float32(0.3), np.float32(0.69), np.float32(0.05)
-        xd = x.to(DEV)
-        _lib.check(lib.interdiff_posterior_step(_lib.dptr(xd), _lib.dptr(x0.to(DEV)), _lib.dptr(eps.to(DEV)), n, c1, c2, s, 0, 0, _lib.stream()))
+        xd, x0d, epsd = x.to(DEV), x0.to(DEV), eps.to(DEV)          # keep references: temporaries would alias
+        _lib.check(lib.interdiff_posterior_step(_lib.dptr(xd), _lib.dptr(x0d), _lib.dptr(epsd), n, float(c1), float(c2), float(s), 0, 0, _lib.stream()))
         close(xd, c1 * x0 + c2 * x + s * eps, 1e-6, 'posterior n=%d' % n)
         gt, mask = torch.randn(n, generator=g), torch.rand(n, generator=g) < 0.3
-        x0d = x0.to(DEV)
-        _lib.check(lib.interdiff_inpaint(_lib.dptr(x0d), _lib.dptr(gt.to(DEV)), _lib.dptr(mask.to(DEV).view(torch.uint8)), n, _lib.stream()))
+        gtd, md = gt.to(DEV), mask.to(DEV).view(torch.uint8)
+        _lib.check(lib.interdiff_inpaint(_lib.dptr(x0d), _lib.dptr(gtd), _lib.dptr(md), n, _lib.stream()))
         assert torch.equal(x0d.cpu(), torch.where(mask, gt, x0))
 
 

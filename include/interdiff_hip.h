@@ -140,9 +140,9 @@ typedef struct {
 
 /* per-sample constants derived from the memory `cond` (constant over all steps): for every
  * layer and clip the folded cross-attention operands
- *   G  [L][B][40][256]  (scores = x . G^T + g0, 40 = heads*MEM, pre-scaled by 1/sqrt(64))
- *   g0 [L][B][40]
- *   VW [L][B][40][256]  (out = P . VW + out_bias)
+ *   G   [L][B][40][256]  (scores = x . G^T + g0, 40 = heads*MEM, pre-scaled by 1/sqrt(64))
+ *   VWT [L][B][256][48]  (out = P . VW + out_bias, stored output-column-major, 40 padded to 48)
+ *   g0  [L][B][40]
  * cond [MEM,B,256] (reference layout).  `memctx` must hold interdiff_mdm_memctx_floats(B). */
 size_t interdiff_mdm_memctx_floats(int32_t B);
 size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T);
@@ -236,6 +236,14 @@ enum {
 };
 int interdiff_profile_begin(int32_t capacity);
 int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kind);
+
+/* Tile-configuration override for A/B measurements (tools/kbench.py); value 0 = the shipped default.
+ * Not on the product path: nothing in interdiff_amd/ calls it. */
+enum {
+    IDF_TUNE_GEMM_EMBED = 0, IDF_TUNE_GEMM_QKV, IDF_TUNE_GEMM_OUTPROJ, IDF_TUNE_GEMM_FFN1, IDF_TUNE_GEMM_FFN2,
+    IDF_TUNE_GEMM_HEADS, IDF_TUNE_CONTACT, IDF_TUNE_MISC, IDF_TUNE_COUNT
+};
+int interdiff_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -79,6 +79,7 @@ _SIGS = {
                                     vp, vp, sz, vp]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'interdiff_tune': (C.c_int, [i32, i32]),
 }
 
 KERNEL_KINDS = ('embed', 'gemm_qkv', 'self_attn', 'gemm_outproj', 'rowblock_qan', 'rowblock_std', 'gemm_ffn1', 'gemm_ffn2',

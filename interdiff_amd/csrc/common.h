@@ -20,6 +20,8 @@ extern bool g_idf_prof_on;
 void idf_prof_mark_slow(int kind, hipStream_t s);
 static inline void idf_prof_mark(int kind, hipStream_t s) { if (g_idf_prof_on) idf_prof_mark_slow(kind, s); }
 
+extern int g_idf_tune[];          // denoiser.hip: tile-configuration overrides (interdiff_tune)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -36,6 +38,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Branch-free erf-GELU for GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7; the GELU value is
+// within 5e-7 absolute of the exact one over the whole fp32 range, torch's own fp32 gelu is within 1.2e-6).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float er = 1.0f - p * __expf(-(z * z));
+    return 0.5f * x * (1.0f + copysignf(er, x));
+}
 
 // LayerNorm statistics of a 256-wide row held 4 values per lane by one wave.
 __device__ __forceinline__ void ln_row_stats(const float4 v, float &mean, float &rstd) {

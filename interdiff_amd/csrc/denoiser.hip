@@ -4,17 +4,27 @@
 // model/sublayers.py:311-375 (QaN layer), torch.nn.TransformerDecoderLayer (post-norm, gelu).
 // NOT a translation: the reference runs ~40 eager torch kernels per layer over [T,B,D]
 // tensors and re-projects the constant memory every step.  Here
-//   * tokens are clip-major rows (row = b*T + t) of a [N,256] fp32 matrix kept in HBM/L2,
-//   * LayerNorm is applied lazily "on load" by the consumer of a pre-norm sum u = x + f(x),
-//   * all dense contractions run on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32),
-//   * the learned-query local attention collapses to 30 dot products + a 3-tap stencil per
-//     token (constant pre-rotated queries Qc, see interdiff_amd/mdm.py: qan_constants),
-//   * cross-attention to the constant 10-token memory is folded per sample into
-//     scores = x.G^T + g0 and out = P.VW (interdiff_mdm_prepare_memory).
+//   * tokens are clip-major rows (row = b*T + t) of [N,256] fp32 matrices that stay L2-resident,
+//   * EVERY contraction runs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products) --
+//     the six token GEMMs (gemm.h), the temporal self-attention (QK^T and PV), and the whole
+//     "row block" between two FFNs: learned-query local attention, LayerNorms and the cross
+//     attention to the 10-token memory,
+//   * the learned-query local attention collapses to a [16 x 256] x [256 x 30] contraction with
+//     constant pre-rotated queries Qc (interdiff_amd/mdm.py: qan_constants) + a 3-tap stencil,
+//   * cross-attention to the constant memory is folded per sample into
+//     scores = x.G^T + g0 and out = P.VW (interdiff_mdm_prepare_memory),
+//   * LayerNorm never gets its own launch: the row-block kernel owns whole rows (LN_prev on load,
+//     LN1, LN2 in place) and the QKV / heads GEMMs normalise on load.
+// Per step: 1 embed GEMM + 2 x 6 (standard layers) + 6 x 3 (QaN layers) + 1 heads GEMM = 32 launches.
 #include "common.h"
+#include "gemm.h"
 #include <float.h>
 
+int g_idf_tune[IDF_TUNE_COUNT] = {0};
+
 namespace {
+
+using namespace idf_gemm;
 
 constexpr int D = IDF_MDM_D;          // 256
 constexpr int FF = IDF_MDM_FF;        // 1024
@@ -23,376 +33,301 @@ constexpr int HD = D / H;             // 64
 constexpr int NQ = IDF_MDM_NQ;        // 10
 constexpr int MEM = IDF_MDM_MEM;      // 10
 constexpr int HM = H * MEM;           // 40
+constexpr int HMP = 48;               // HM padded to a multiple of 16 (k-groups of the P.VW contraction)
 constexpr int L = IDF_MDM_LAYERS;
 
-// ------------------------------------------------------------------------------------
-// Input embedding: u0[row][col] = sum_c x[b][c][t] WinT[c][col] + b_in[col] + temb[ts[b]][col] + pe[t][col]
-// grid (ceil(T/16), B), 256 threads (thread = output column).
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x, const int64_t *__restrict__ ts,
-                                                    const float *__restrict__ WinT, const float *__restrict__ bin,
-                                                    const float *__restrict__ temb, const float *__restrict__ pe,
-                                                    int C, int T, int n_steps, float *__restrict__ u0) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];        // [C][16]
-    const int b = blockIdx.y, t0 = blockIdx.x * 16, col = threadIdx.x;
-    for (int i = threadIdx.x; i < C * 16; i += 256) {
-        const int c = i >> 4, t = t0 + (i & 15);
-        xs[i] = t < T ? x[((size_t)b * C + c) * T + t] : 0.f;
-    }
-    __syncthreads();
-    float acc[16];
+// four dependent-free rounds of MFMAs over NA accumulators: acc[i] += a[i](k-group) . b[i](k-group)
+template <int NA>
+__device__ __forceinline__ void mma_rounds(f32x4 (&acc)[NA], const float4 (&a)[NA], const float4 (&b)[NA]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float w = WinT[c * D + col];
-        const float4 *xr = reinterpret_cast<const float4 *>(xs + c * 16);
+    for (int i = 0; i < NA; ++i) IDF_MFMA4(acc[i], a[i].x, b[i].x);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = xr[q];
-            acc[q * 4 + 0] += w * v.x;
-            acc[q * 4 + 1] += w * v.y;
-            acc[q * 4 + 2] += w * v.z;
-            acc[q * 4 + 3] += w * v.w;
-        }
-    }
-    int64_t step = ts[b];
-    step = step < 0 ? 0 : (step >= n_steps ? n_steps - 1 : step);
-    const float base = bin[col] + temb[step * D + col];
+    for (int i = 0; i < NA; ++i) IDF_MFMA4(acc[i], a[i].y, b[i].y);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = t0 + r;
-        if (t < T) u0[((size_t)b * T + t) * D + col] = acc[r] + base + pe[(size_t)t * D + col];
-    }
+    for (int i = 0; i < NA; ++i) IDF_MFMA4(acc[i], a[i].z, b[i].z);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) IDF_MFMA4(acc[i], a[i].w, b[i].w);
+}
+
+__device__ __forceinline__ float4 ln_apply(const float4 v, const float4 g, const float4 b) {
+    float mean, rstd;
+    ln_row_stats(v, mean, rstd);
+    return make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y, (v.z - mean) * rstd * g.z + b.z,
+                       (v.w - mean) * rstd * g.w + b.w);
 }
 
 // ------------------------------------------------------------------------------------
-// Tiled fp32-MFMA GEMM:  C[M,N] = epi( pro(A)[M,K] . W[N,K]^T + bias )
-//   pro = LayerNorm over the (K == 256 wide) row when LN, else identity
-//   WG tile 32 x 64, 4 waves as 2(M) x 2(N), wave tile 16 x 32 = two 16x16x4 accumulators.
-//   LDS images are quad-major ([k/4][row][4]) so a lane's MFMA operands for four consecutive
-//   k-steps come from one conflict-free ds_read_b128.
+// Row block shared by QaN layers and standard layers, 16 tokens of one clip per workgroup:
+//   [QAN]  x = LN_prev(u_in rows t-1 .. t+16);  logits[t][n][j] = <Qc[n][j], x[t+j-1]>  (MFMA, K split over waves)
+//          u1 = x_t + sum_j c_j(t) x_{t+j-1},  c_j = sum_n wk[n] softmax_j(logits[t][n][:])
+//   [!QAN] u1 = u_in row
+//   x1 = LN1(u1);  scores = x1.G^T + g0 (MFMA);  P = softmax per head;  u2 = x1 + P.VW + b_out (MFMA)
+//   x2 = LN2(u2)  -> HBM (the FFN input AND its residual)
+// grid (ceil(T/16), B), 256 threads.
 // ------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_HEADS = 3 };
-constexpr int BM = 32, BN = 64, KC = 64;             // k-chunk of 64 = 16 quads
-constexpr int AQ = BM * 4 + 4;                       // padded quad stride of the A image (floats)
-constexpr int BQ = BN * 4 + 4;                       // padded quad stride of the B image
+constexpr int TR = 16;
+constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
+constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
-template <bool LN, int EPI>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(const float *__restrict__ A, int lda, int K,
-                                                        const float *__restrict__ lnw, const float *__restrict__ lnb,
-                                                        const float *__restrict__ W, const float *__restrict__ bias,
-                                                        float *__restrict__ Cout, int ldc, int M, int N,
-                                                        float *__restrict__ xn_out, const float *__restrict__ resid,
-                                                        int T) {
-    constexpr int A_FLOATS = LN ? (D / 4) * AQ : 2 * (KC / 4) * AQ;
-    __shared__ __attribute__((aligned(16))) float As[A_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * (KC / 4) * BQ];
+template <bool QAN>
+__global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
+                                                       const float *__restrict__ lnp_b, const float *__restrict__ Qc,
+                                                       const float *__restrict__ wk, const float *__restrict__ ln1_w,
+                                                       const float *__restrict__ ln1_b, const float *__restrict__ G,
+                                                       const float *__restrict__ g0, const float *__restrict__ VWT,
+                                                       const float *__restrict__ bout, const float *__restrict__ ln2_w,
+                                                       const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T) {
+    constexpr int XS = QAN ? (TR + 2) * RS : 0;
+    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + NQ * TR * 4 + TR * 4 + TR * PS];
+    float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
+    float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
+    float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
+    float *cw = part + 4 * 3 * 256;               // [NQ][TR][4]
+    float *coef = cw + NQ * TR * 4;               // [TR][4]
+    float *Ps = coef + TR * 4;                    // [TR][PS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, kq = lane >> 4;
-    const int nk = K / KC;
+    const int b = blockIdx.y, t0 = blockIdx.x * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4, c4 = lane * 4;
+    const size_t rowbase = (size_t)b * T;
 
-    float4 breg[4], areg[2];
-    auto load_b = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, col = f >> 4, q = f & 15;
-            const int n = n0 + col;
-            breg[i] = n < N ? *reinterpret_cast<const float4 *>(W + (size_t)n * K + kc * KC + q * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, col = f >> 4, q = f & 15;
-            *reinterpret_cast<float4 *>(Bs + buf * (KC / 4) * BQ + q * BQ + col * 4) = breg[i];
-        }
-    };
-    auto load_a = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i, row = f >> 4, q = f & 15;
-            const int m = m0 + row;
-            areg[i] = m < M ? *reinterpret_cast<const float4 *>(A + (size_t)m * lda + kc * KC + q * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i, row = f >> 4, q = f & 15;
-            *reinterpret_cast<float4 *>(As + buf * (KC / 4) * AQ + q * AQ + row * 4) = areg[i];
-        }
-    };
-
-    load_b(0);
-    if constexpr (LN) {
-        // whole rows: wave w owns rows w, w+4, ...; lane holds 4 consecutive features
-        const float4 g = lnw ? *reinterpret_cast<const float4 *>(lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 be = lnb ? *reinterpret_cast<const float4 *>(lnb + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < BM / 4; ++i) {
-            const int row = wave + 4 * i, m = m0 + row;
-            float4 v = m < M ? *reinterpret_cast<const float4 *>(A + (size_t)m * lda + lane * 4)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lnw) {
-                float mean, rstd;
-                ln_row_stats(v, mean, rstd);
-                v.x = (v.x - mean) * rstd * g.x + be.x;
-                v.y = (v.y - mean) * rstd * g.y + be.y;
-                v.z = (v.z - mean) * rstd * g.z + be.z;
-                v.w = (v.w - mean) * rstd * g.w + be.w;
+    if constexpr (QAN) {
+        const float4 gw = lnp_w ? ld4(lnp_w + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 gb = lnp_w ? ld4(lnp_b + c4) : zero4();
+        for (int r = wave; r < TR + 2; r += 4) {
+            const int t = t0 - 1 + r;
+            float4 v = zero4();
+            if (t >= 0 && t < T) {
+                v = ld4(u_in + (rowbase + t) * D + c4);
+                if (lnp_w) v = ln_apply(v, gw, gb);
             }
-            *reinterpret_cast<float4 *>(As + lane * AQ + row * 4) = v;
-            if (xn_out && blockIdx.y == 0 && m < M) *reinterpret_cast<float4 *>(xn_out + (size_t)m * D + lane * 4) = v;
+            *reinterpret_cast<float4 *>(xs + r * RS + c4) = v;
         }
-    } else {
-        load_a(0);
-        store_a(0);
-    }
-    store_b(0);
-    __syncthreads();
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) {
-            load_b(kc + 1);
-            if constexpr (!LN) load_a(kc + 1);
-        }
-        const float *Ab = LN ? As + kc * (KC / 4) * AQ : As + buf * (KC / 4) * AQ;
-        const float *Bb = Bs + buf * (KC / 4) * BQ;
+        __syncthreads();
+        // logits: three 16x16 tiles (j = 0,1,2), each wave contracts a 64-wide slice of K
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 a = *reinterpret_cast<const float4 *>(Ab + (s * 4 + kq) * AQ + (wm * 16 + li) * 4);
-            const float4 b0 = *reinterpret_cast<const float4 *>(Bb + (s * 4 + kq) * BQ + (wn * 32 + li) * 4);
-            const float4 b1 = *reinterpret_cast<const float4 *>(Bb + (s * 4 + kq) * BQ + (wn * 32 + 16 + li) * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+        for (int ss = 0; ss < 4; ++ss) {
+            const int koff = 16 * (wave * 4 + ss) + 4 * kq;
+            float4 a[3], q[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                a[j] = ld4(xs + (li + j) * RS + koff);
+                q[j] = li < NQ ? ld4(Qc + (li * 3 + j) * D + koff) : zero4();
+            }
+            mma_rounds<3>(acc, a, q);
         }
-        if (kc + 1 < nk) {
-            store_b(buf ^ 1);
-            if constexpr (!LN) store_a(buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * 256 + (kq * 4 + r) * 16 + li] = acc[j][r];
+        __syncthreads();
+        {
+            const int t = tid & 15, n = tid >> 4;
+            if (n < NQ) {
+                float l[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    l[j] = (part[(0 * 3 + j) * 256 + t * 16 + n] + part[(1 * 3 + j) * 256 + t * 16 + n]) +
+                           (part[(2 * 3 + j) * 256 + t * 16 + n] + part[(3 * 3 + j) * 256 + t * 16 + n]);
+                const int tg = t0 + t;
+                if (tg <= 0) l[0] = -FLT_MAX;
+                if (tg + 1 >= T) l[2] = -FLT_MAX;
+                const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
+                const float e0 = expf(l[0] - mx), e1 = expf(l[1] - mx), e2 = expf(l[2] - mx);
+                const float w = wk[n] / (e0 + e1 + e2);
+                float *o = cw + (n * TR + t) * 4;
+                o[0] = w * e0;
+                o[1] = w * e1;
+                o[2] = w * e2;
+            }
+        }
+        __syncthreads();
+        if (tid < TR * 4) {
+            const int t = tid >> 2, j = tid & 3;
+            float c = 0.f;
+            if (j < 3)
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) c += cw[(n * TR + t) * 4 + j];
+            coef[tid] = c;
         }
         __syncthreads();
     }
-
-    // epilogue: C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 acc = nt ? acc1 : acc0;
-        const int col = n0 + wn * 32 + nt * 16 + li;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 16 + kq * 4 + r;
-            if (row >= M) continue;
-            float v = acc[r] + bv;
-            if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
-            if constexpr (EPI == EPI_RESID) v += resid[(size_t)row * ldc + col];
-            if constexpr (EPI == EPI_HEADS) {
-                const int b = row / T, t = row - b * T;
-                Cout[((size_t)b * N + col) * T + t] = v;
+    {   // u1 -> x1 = LN1(u1)
+        const float4 gw = ld4(ln1_w + c4), gb = ld4(ln1_b + c4);
+        for (int r = wave; r < TR; r += 4) {
+            float4 u1;
+            if constexpr (QAN) {
+                const float4 xm = ld4(xs + r * RS + c4), xc = ld4(xs + (r + 1) * RS + c4), xp = ld4(xs + (r + 2) * RS + c4);
+                const float c0 = coef[r * 4], c1 = coef[r * 4 + 1], c2 = coef[r * 4 + 2];
+                u1.x = xc.x + (c0 * xm.x + c1 * xc.x + c2 * xp.x);
+                u1.y = xc.y + (c0 * xm.y + c1 * xc.y + c2 * xp.y);
+                u1.z = xc.z + (c0 * xm.z + c1 * xc.z + c2 * xp.z);
+                u1.w = xc.w + (c0 * xm.w + c1 * xc.w + c2 * xp.w);
             } else {
-                Cout[(size_t)row * ldc + col] = v;
+                const int t = t0 + r;
+                u1 = t < T ? ld4(u_in + (rowbase + t) * D + c4) : zero4();
             }
+            *reinterpret_cast<float4 *>(x1s + r * RS + c4) = ln_apply(u1, gw, gb);
+        }
+    }
+    __syncthreads();
+    const float *Gb = G + (size_t)b * HM * D, *g0b = g0 + b * HM, *VWTb = VWT + (size_t)b * D * HMP;
+    {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const int koff = 16 * (wave * 4 + ss) + 4 * kq;
+            const float4 av = ld4(x1s + li * RS + koff);
+            float4 a[3] = {av, av, av}, gv[3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int m = ct * 16 + li;
+                gv[ct] = m < HM ? ld4(Gb + (size_t)m * D + koff) : zero4();
+            }
+            mma_rounds<3>(acc, a, gv);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 3 + ct) * 256 + (kq * 4 + r) * 16 + li] = acc[ct][r];
+    }
+    __syncthreads();
+    {
+        const int t = tid & 15, h = tid >> 4;
+        if (h < H) {
+            float sc[MEM], mx = -FLT_MAX;
+#pragma unroll
+            for (int m = 0; m < MEM; ++m) {
+                const int idx = h * MEM + m, ct = idx >> 4, cl = idx & 15, o = t * 16 + cl;
+                sc[m] = ((part[(0 * 3 + ct) * 256 + o] + part[(1 * 3 + ct) * 256 + o]) +
+                         (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0b[idx];
+                mx = fmaxf(mx, sc[m]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < MEM; ++m) {
+                sc[m] = expf(sc[m] - mx);
+                sum += sc[m];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int m = 0; m < MEM; ++m) Ps[t * PS + h * MEM + m] = sc[m] * inv;
+        } else if (h == H) {
+#pragma unroll
+            for (int c = HM; c < HMP; ++c) Ps[t * PS + c] = 0.f;
+        }
+    }
+    __syncthreads();
+    {   // u2 = x1 + P.VW + b_out : wave w owns output columns [64w, 64w+64)
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < HMP / 16; ++s) {
+            const int koff = 16 * s + 4 * kq;
+            const float4 pv = ld4(Ps + li * PS + koff);
+            float4 a[4] = {pv, pv, pv, pv}, vw[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vw[c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + koff);
+            mma_rounds<4>(acc, a, vw);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = (wave * 4 + c) * 16 + li;
+            const float bo = bout[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] += acc[c][r] + bo;
+        }
+    }
+    __syncthreads();
+    {
+        const float4 gw = ld4(ln2_w + c4), gb = ld4(ln2_b + c4);
+        for (int r = wave; r < TR; r += 4) {
+            const int t = t0 + r;
+            if (t >= T) break;                                       // wave-uniform
+            const float4 v = ln_apply(ld4(x1s + r * RS + c4), gw, gb);
+            *reinterpret_cast<float4 *>(x2_out + (rowbase + t) * D + c4) = v;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------
-// Temporal self-attention of the two standard layers: softmax(Q K^T / 8) V per (clip, head).
-// grid (ceil(T/32), H, B), 256 threads.  LDS: K,V [T][65], Q [32][65], S [32][Tp].
+// Temporal self-attention of the two standard layers: softmax(Q K^T / 8) V per (clip, head), on the MFMA.
+// grid (ceil(T/32), H, B), 256 threads.  LDS: K,V [TP][68], Q [32][68], S [32][TP+4]; TP = T rounded up to 16.
 // ------------------------------------------------------------------------------------
+constexpr int AS = HD + 4;
+constexpr int ATTN_MAX_T = 208;
+
 __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int Tp = T + 1;
-    float *Ks = sm, *Vs = Ks + T * 65, *Qs = Vs + T * 65, *S = Qs + 32 * 65;
+    extern __shared__ __attribute__((aligned(16))) float smx[];
+    const int TP = (T + 15) & ~15, SS = TP + 4;
+    float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + 32 * AS;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
-    for (int i = tid; i < T * 16; i += 256) {
+    for (int i = tid; i < TP * 16; i += 256) {
         const int j = i >> 4, d4 = (i & 15) * 4;
-        const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + d4;
-        const float4 k = *reinterpret_cast<const float4 *>(src + D), v = *reinterpret_cast<const float4 *>(src + 2 * D);
-        float *kd = Ks + j * 65 + d4, *vd = Vs + j * 65 + d4;
-        kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
-        vd[0] = v.x; vd[1] = v.y; vd[2] = v.z; vd[3] = v.w;
+        float4 k = zero4(), v = zero4();
+        if (j < T) {
+            const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + d4;
+            k = ld4(src + D);
+            v = ld4(src + 2 * D);
+        }
+        *reinterpret_cast<float4 *>(Ks + j * AS + d4) = k;
+        *reinterpret_cast<float4 *>(Vs + j * AS + d4) = v;
     }
     for (int i = tid; i < 32 * 16; i += 256) {
         const int r = i >> 4, d4 = (i & 15) * 4, t = q0 + r;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) q = *reinterpret_cast<const float4 *>(qkv + (rowbase + t) * (3 * D) + h * HD + d4);
-        float *qd = Qs + r * 65 + d4;
-        qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
+        *reinterpret_cast<float4 *>(Qs + r * AS + d4) = t < T ? ld4(qkv + (rowbase + t) * (3 * D) + h * HD + d4) : zero4();
     }
     __syncthreads();
-    for (int p = tid; p < 32 * T; p += 256) {
-        const int i = p / T, j = p - i * T;
-        const float *q = Qs + i * 65, *k = Ks + j * 65;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < HD; ++d) s += q[d] * k[d];
-        S[i * Tp + j] = s * 0.125f;
+    // S = Q K^T / 8: wave w owns key tiles w, w+4, ... for both 16-query tiles
+    for (int ct = wave; ct < TP / 16; ct += 4) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            const int koff = 16 * s + 4 * kq;
+            const float4 kv = ld4(Ks + (ct * 16 + li) * AS + koff);
+            float4 a[2] = {ld4(Qs + li * AS + koff), ld4(Qs + (16 + li) * AS + koff)}, bb[2] = {kv, kv};
+            mma_rounds<2>(acc, a, bb);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = acc[rt][r] * 0.125f;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
     for (int i = wave * 8; i < wave * 8 + 8; ++i) {
+        float *row = Ss + i * SS;
         float mx = -FLT_MAX;
-        for (int j = lane; j < T; j += 64) mx = fmaxf(mx, S[i * Tp + j]);
+        for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
         mx = wave_max(mx);
         float sum = 0.f;
         for (int j = lane; j < T; j += 64) {
-            const float e = expf(S[i * Tp + j] - mx);
-            S[i * Tp + j] = e;
+            const float e = expf(row[j] - mx);
+            row[j] = e;
             sum += e;
         }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
-        for (int j = lane; j < T; j += 64) S[i * Tp + j] *= inv;
+        for (int j = lane; j < TP; j += 64) row[j] = j < T ? row[j] * inv : 0.f;
     }
     __syncthreads();
-    for (int p = tid; p < 32 * HD; p += 256) {
-        const int i = p >> 6, d = p & 63, t = q0 + i;
-        if (t >= T) continue;
-        float o = 0.f;
-        for (int j = 0; j < T; ++j) o += S[i * Tp + j] * Vs[j * 65 + d];
-        ctx[(rowbase + t) * D + h * HD + d] = o;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Row-wise block shared by QaN layers and standard layers:
-//   [QAN]  x = LN_prev(u_in rows t-1,t,t+1);  u1 = x_t + sum_j c_j x_{t+j-1}   (learned-query local attention)
-//   [!QAN] u1 = u_in row
-//   x1 = LN1(u1);  scores = x1.G^T + g0;  P = softmax per head;  u2 = x1 + P.VW + b_out
-// One wave per token, 4 tokens per pass, TC tokens per workgroup.  grid (ceil(T/TC), B).
-// ------------------------------------------------------------------------------------
-constexpr int TC = 8;
-
-template <bool QAN>
-__global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in,
-                                                       const float *__restrict__ lnp_w, const float *__restrict__ lnp_b,
-                                                       const float *__restrict__ Qc, const float *__restrict__ wk,
-                                                       const float *__restrict__ ln1_w, const float *__restrict__ ln1_b,
-                                                       const float *__restrict__ G, const float *__restrict__ g0,
-                                                       const float *__restrict__ VW, const float *__restrict__ bout,
-                                                       float *__restrict__ u_out, int T) {
-    __shared__ __attribute__((aligned(16))) float rows[(TC + 2) * D];
-    const int b = blockIdx.y, t0 = blockIdx.x * TC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t rowbase = (size_t)b * T;
-    const int c4 = lane * 4;
-    if constexpr (QAN) {
-        const float4 g = lnp_w ? *reinterpret_cast<const float4 *>(lnp_w + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 be = lnp_b ? *reinterpret_cast<const float4 *>(lnp_b + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = wave; r < TC + 2; r += 4) {
-            const int t = t0 - 1 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T) {
-                v = *reinterpret_cast<const float4 *>(u_in + (rowbase + t) * D + c4);
-                if (lnp_w) {
-                    float mean, rstd;
-                    ln_row_stats(v, mean, rstd);
-                    v.x = (v.x - mean) * rstd * g.x + be.x;
-                    v.y = (v.y - mean) * rstd * g.y + be.y;
-                    v.z = (v.z - mean) * rstd * g.z + be.z;
-                    v.w = (v.w - mean) * rstd * g.w + be.w;
-                }
+    {   // ctx = P V: wave w owns the 16 head-dim columns [16w, 16w+16) for both query tiles
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const int dcol = wave * 16 + li;
+        for (int s = 0; s < TP / 16; ++s) {
+            const int koff = 16 * s + 4 * kq;
+            const float *vp = Vs + koff * AS + dcol;
+            const float4 vv = make_float4(vp[0], vp[AS], vp[2 * AS], vp[3 * AS]);
+            float4 a[2] = {ld4(Ss + li * SS + koff), ld4(Ss + (16 + li) * SS + koff)}, bb[2] = {vv, vv};
+            mma_rounds<2>(acc, a, bb);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = q0 + rt * 16 + kq * 4 + r;
+                if (t < T) ctx[(rowbase + t) * D + h * HD + dcol] = acc[rt][r];
             }
-            *reinterpret_cast<float4 *>(rows + r * D + c4) = v;
-        }
-        __syncthreads();
-    }
-    const float *Gb = G + (size_t)b * HM * D, *g0b = g0 + b * HM, *VWb = VW + (size_t)b * HM * D;
-    for (int k = wave; k < TC; k += 4) {
-        const int t = t0 + k;
-        if (t >= T) break;                                       // wave-uniform
-        float4 u1;
-        if constexpr (QAN) {
-            const float4 xm = *reinterpret_cast<const float4 *>(rows + k * D + c4);
-            const float4 xc = *reinterpret_cast<const float4 *>(rows + (k + 1) * D + c4);
-            const float4 xp = *reinterpret_cast<const float4 *>(rows + (k + 2) * D + c4);
-            float lg[NQ][3];
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const float4 q0 = *reinterpret_cast<const float4 *>(Qc + (n * 3 + 0) * D + c4);
-                const float4 q1 = *reinterpret_cast<const float4 *>(Qc + (n * 3 + 1) * D + c4);
-                const float4 q2 = *reinterpret_cast<const float4 *>(Qc + (n * 3 + 2) * D + c4);
-                lg[n][0] = xm.x * q0.x + xm.y * q0.y + xm.z * q0.z + xm.w * q0.w;
-                lg[n][1] = xc.x * q1.x + xc.y * q1.y + xc.z * q1.z + xc.w * q1.w;
-                lg[n][2] = xp.x * q2.x + xp.y * q2.y + xp.z * q2.z + xp.w * q2.w;
-            }
-#pragma unroll
-            for (int n = 0; n < NQ; ++n)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) lg[n][j] = wave_sum(lg[n][j]);
-            const bool vm = t > 0, vp = t + 1 < T;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const float l0 = vm ? lg[n][0] : -FLT_MAX, l1 = lg[n][1], l2 = vp ? lg[n][2] : -FLT_MAX;
-                const float mx = fmaxf(l0, fmaxf(l1, l2));
-                const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
-                const float w = wk[n] / (e0 + e1 + e2);
-                c0 += w * e0; c1 += w * e1; c2 += w * e2;
-            }
-            u1.x = xc.x + (c0 * xm.x + c1 * xc.x + c2 * xp.x);
-            u1.y = xc.y + (c0 * xm.y + c1 * xc.y + c2 * xp.y);
-            u1.z = xc.z + (c0 * xm.z + c1 * xc.z + c2 * xp.z);
-            u1.w = xc.w + (c0 * xm.w + c1 * xc.w + c2 * xp.w);
-        } else {
-            u1 = *reinterpret_cast<const float4 *>(u_in + (rowbase + t) * D + c4);
-        }
-        // x1 = LN1(u1)
-        float mean, rstd;
-        ln_row_stats(u1, mean, rstd);
-        const float4 g1 = *reinterpret_cast<const float4 *>(ln1_w + c4), b1 = *reinterpret_cast<const float4 *>(ln1_b + c4);
-        float4 x1;
-        x1.x = (u1.x - mean) * rstd * g1.x + b1.x;
-        x1.y = (u1.y - mean) * rstd * g1.y + b1.y;
-        x1.z = (u1.z - mean) * rstd * g1.z + b1.z;
-        x1.w = (u1.w - mean) * rstd * g1.w + b1.w;
-        // folded cross-attention
-        float sc[HM];
-#pragma unroll
-        for (int m = 0; m < HM; ++m) {
-            const float4 gv = *reinterpret_cast<const float4 *>(Gb + m * D + c4);
-            sc[m] = x1.x * gv.x + x1.y * gv.y + x1.z * gv.z + x1.w * gv.w;
-        }
-#pragma unroll
-        for (int m = 0; m < HM; ++m) sc[m] = wave_sum(sc[m]) + g0b[m];
-#pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-            float mx = sc[hh * MEM];
-#pragma unroll
-            for (int m = 1; m < MEM; ++m) mx = fmaxf(mx, sc[hh * MEM + m]);
-            float sum = 0.f;
-#pragma unroll
-            for (int m = 0; m < MEM; ++m) {
-                sc[hh * MEM + m] = expf(sc[hh * MEM + m] - mx);
-                sum += sc[hh * MEM + m];
-            }
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int m = 0; m < MEM; ++m) sc[hh * MEM + m] *= inv;
-        }
-        float4 o = *reinterpret_cast<const float4 *>(bout + c4);
-#pragma unroll
-        for (int m = 0; m < HM; ++m) {
-            const float4 vw = *reinterpret_cast<const float4 *>(VWb + m * D + c4);
-            o.x += sc[m] * vw.x; o.y += sc[m] * vw.y; o.z += sc[m] * vw.z; o.w += sc[m] * vw.w;
-        }
-        float4 u2 = make_float4(x1.x + o.x, x1.y + o.y, x1.z + o.z, x1.w + o.w);
-        *reinterpret_cast<float4 *>(u_out + (rowbase + t) * D + c4) = u2;
     }
 }
 
@@ -416,11 +351,11 @@ __global__ __launch_bounds__(256) void mem_kv_kernel(const float *__restrict__ a
 }
 
 // G[l][b][h*MEM+m][i] = 1/8 sum_d Wq[h*64+d][i] K[m,b][h*64+d];  g0 = 1/8 sum_d bq[h*64+d] K[..]
-// VW[l][b][h*MEM+m][o] = sum_d V[m,b][h*64+d] Wo[o][h*64+d]
+// VWT[l][b][o][h*MEM+m] = sum_d V[m,b][h*64+d] Wo[o][h*64+d]   (columns 40..47 zero)
 // grid (HM, B, L), 256 threads (thread = i / o)
 __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__ arena, const idf_mdm_weights w,
                                                        const float *__restrict__ kv, int B, float *__restrict__ G,
-                                                       float *__restrict__ g0, float *__restrict__ VW) {
+                                                       float *__restrict__ g0, float *__restrict__ VWT) {
     const int hm = blockIdx.x, b = blockIdx.y, l = blockIdx.z, h = hm / MEM, m = hm - h * MEM, i = threadIdx.x;
     __shared__ float kd[HD], vd[HD];
     const float *row = kv + ((size_t)l * (MEM * B) + (size_t)m * B + b) * 512;
@@ -433,9 +368,10 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
         sg += Wq[(size_t)(h * HD + d) * D + i] * kd[d];
         sv += vd[d] * Wo[(size_t)i * D + h * HD + d];
     }
-    const size_t o = (((size_t)l * B + b) * HM + hm) * D + i;
-    G[o] = sg * 0.125f;
-    VW[o] = sv;
+    G[(((size_t)l * B + b) * HM + hm) * D + i] = sg * 0.125f;
+    float *vrow = VWT + (((size_t)l * B + b) * D + i) * HMP;
+    vrow[hm] = sv;
+    if (hm < HMP - HM) vrow[HM + hm] = 0.f;
     if (i == 0) {
         float s = 0.f;
         for (int d = 0; d < HD; ++d) s += bq[h * HD + d] * kd[d];
@@ -444,7 +380,7 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
 }
 
 struct Ws {
-    float *uA, *uB, *xn, *ctx, *qkv, *hid;
+    float *uA, *uB, *xn, *x2, *ctx, *qkv, *hid;
 };
 Ws carve(void *ws, int64_t N) {
     float *p = reinterpret_cast<float *>(ws);
@@ -452,30 +388,49 @@ Ws carve(void *ws, int64_t N) {
     r.uA = p; p += N * D;
     r.uB = p; p += N * D;
     r.xn = p; p += N * D;
+    r.x2 = p; p += N * D;
     r.ctx = p; p += N * D;
     r.qkv = p; p += N * 3 * D;
     r.hid = p;
     return r;
 }
 
-template <bool LN, int EPI>
-void launch_gemm(int kind, hipStream_t s, const float *A, int lda, int K, const float *lnw, const float *lnb, const float *W,
-                 const float *bias, float *C, int ldc, int M, int N, float *xn, const float *resid, int T) {
-    dim3 grid((unsigned)idf_cdiv(M, BM), (unsigned)idf_cdiv(N, BN));
-    idf_prof_mark(kind, s);
-    hipLaunchKernelGGL((gemm_tile_kernel<LN, EPI>), grid, dim3(256), 0, s, A, lda, K, lnw, lnb, W, bias, C, ldc, M, N, xn,
-                       resid, T);
+// tile configurations of the token GEMMs (A_PLAIN / A_LN call sites: the LDS-DMA pipeline of gemm.h).  The default
+// per call site was picked on MI355X with tools/gemm_probe.hip + tools/kbench.py (profiles/); interdiff_tune()
+// overrides it for A/B runs.  Config ids: BM x BN, waves, k-slices per workgroup (ks), chunk depth (kc).
+template <int APRO, int EPI>
+void run_gemm(int cfg, hipStream_t s, const Args &g) {
+    switch (cfg) {
+    case 1: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
+    case 2: launch_glds<32, 64, 2, 2, 1, 64, APRO, EPI>(s, g); break;
+    case 3: launch_glds<32, 64, 2, 2, 2, 64, APRO, EPI>(s, g); break;
+    case 4: launch_glds<64, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
+    case 5: launch_glds<32, 32, 2, 2, 1, 64, APRO, EPI>(s, g); break;
+    case 6: launch_glds<32, 32, 2, 2, 2, 64, APRO, EPI>(s, g); break;
+    case 7: launch_glds<64, 32, 2, 2, 1, 32, APRO, EPI>(s, g); break;
+    case 8: launch_glds<64, 32, 2, 2, 2, 64, APRO, EPI>(s, g); break;
+    case 9: launch<32, 64, 2, 2, 32, APRO, EPI>(s, g); break;               // register-staged double buffer
+    default: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
+    }
 }
+constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 9;
+inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 
 }  // namespace
 
+extern "C" int interdiff_tune(int32_t key, int32_t value) {
+    if (key < 0 || key >= IDF_TUNE_COUNT) return IDF_E_INVAL;
+    g_idf_tune[key] = value;
+    return IDF_OK;
+}
+
 extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) {
-    return (size_t)L * B * HM * D * 2 + (size_t)L * B * HM;
+    return (size_t)L * B * HM * D + (size_t)L * B * D * HMP + (size_t)L * B * HM;
 }
 
 extern "C" size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T) {
     const size_t N = (size_t)B * T;
-    const size_t fwd = N * (4 * D + 3 * D + FF) * sizeof(float);
+    const size_t fwd = N * (5 * D + 3 * D + FF) * sizeof(float);
     const size_t prep = (size_t)L * MEM * B * 512 * sizeof(float);
     return idf_align(fwd > prep ? fwd : prep);
 }
@@ -486,10 +441,10 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
     if (ws_bytes < (size_t)L * MEM * B * 512 * sizeof(float)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     float *kv = reinterpret_cast<float *>(ws);
-    float *G = memctx, *VW = memctx + (size_t)L * B * HM * D, *g0 = VW + (size_t)L * B * HM * D;
+    float *G = memctx, *VWT = memctx + (size_t)L * B * HM * D, *g0 = VWT + (size_t)L * B * D * HMP;
     idf_prof_mark(IDF_K_MEM_PREP, s);
     hipLaunchKernelGGL(mem_kv_kernel, dim3(2, MEM * B, L), dim3(256), 0, s, w->arena, *w, cond, MEM * B, kv);
-    hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VW);
+    hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VWT);
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
@@ -498,61 +453,84 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
 extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts,
                                      int32_t B, int32_t T, float *x0, void *ws, size_t ws_bytes, void *stream) {
     if (!w || !memctx || !x || !ts || !x0 || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
-    if (T > w->max_T || T > 512 || w->C > 256) return IDF_E_INVAL;
+    if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || (w->C & 3)) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_workspace_bytes(B, T)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const float *ar = w->arena;
     const int N = B * T, C = w->C;
     Ws k = carve(ws, N);
-    const float *G = memctx, *VW = memctx + (size_t)L * B * HM * D, *g0 = VW + (size_t)L * B * HM * D;
+    const float *G = memctx, *VWT = memctx + (size_t)L * B * HM * D, *g0 = VWT + (size_t)L * B * D * HMP;
+    const int *tune = g_idf_tune;
 
-    idf_prof_mark(IDF_K_EMBED, s);
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)idf_cdiv(T, 16), B), dim3(256), C * 16 * sizeof(float), s, x, ts,
-                       ar + w->in_w, ar + w->in_b, ar + w->temb_table, ar + w->pe, C, T, w->n_steps, k.uA);
-
+    {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
+        Args g{};
+        g.A = x; g.K = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
+        g.ts = ts; g.temb = ar + w->temb_table; g.pe = ar + w->pe; g.n_steps = w->n_steps;
+        idf_prof_mark(IDF_K_EMBED, s);
+        if (tune[IDF_TUNE_GEMM_EMBED] == 1) launch<64, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
+        else launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
+    }
     float *u_in = k.uA, *u_tmp = k.uB;         // layer input (pre-norm sum of the previous layer) / scratch
     const float *lnp_w = nullptr, *lnp_b = nullptr;   // LayerNorm still to be applied to u_in (none for layer 0)
-    const size_t attn_lds = ((size_t)2 * T * 65 + 32 * 65 + 32 * (T + 1)) * sizeof(float);
+    const int TP = (T + 15) & ~15;
+    const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(self_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float))) != hipSuccess)
+            return IDF_E_LAUNCH;
+        attr_set = true;
+    }
+    const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];
-        const float *Gl = G + (size_t)l * B * HM * D, *VWl = VW + (size_t)l * B * HM * D, *g0l = g0 + (size_t)l * B * HM;
-        float *u2;                                                 // pre-norm2 sum
+        const float *Gl = G + (size_t)l * B * HM * D, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
-            hipLaunchKernelGGL((rowblock_kernel<true>), dim3((unsigned)idf_cdiv(T, TC), B), dim3(256), 0, s, u_in, lnp_w,
-                               lnp_b, ar + ly.qc, ar + ly.wk, ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWl,
-                               ar + ly.ca_out_b, u_tmp, T);
-            u2 = u_tmp;
+            hipLaunchKernelGGL((rowblock_kernel<true>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                               ar + ly.ln_b[1], k.x2, T);
         } else {
-            // x = LN_prev(u_in) -> xn ; qkv = x.Win^T + b
-            launch_gemm<true, EPI_BIAS>(IDF_K_GEMM_QKV, s, u_in, D, D, lnp_w, lnp_b, ar + ly.sa_in_w, ar + ly.sa_in_b, k.qkv, 3 * D, N, 3 * D,
-                                        k.xn, nullptr, T);
+            // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
+            Args g{};
+            g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T;
+            idf_prof_mark(IDF_K_GEMM_QKV, s);
+            run_gemm<A_LN, E_BIAS>(pick(tune[IDF_TUNE_GEMM_QKV], CFG_QKV), s, g);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
-            // u1 = x + ctx.Wo^T + bo   (into u_tmp)
-            launch_gemm<false, EPI_RESID>(IDF_K_GEMM_OUTPROJ, s, k.ctx, D, D, nullptr, nullptr, ar + ly.sa_out_w, ar + ly.sa_out_b, u_tmp, D, N, D,
-                                          nullptr, k.xn, T);
-            // u2 = LN1(u1) + cross(LN1(u1))   (into u_in's buffer: the layer input is dead now)
+            // u1 = xn + ctx.Wo^T + bo
+            Args o{};
+            o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
+            o.N = D; o.resid = k.xn; o.T = T;
+            idf_prof_mark(IDF_K_GEMM_OUTPROJ, s);
+            run_gemm<A_PLAIN, E_RESID>(pick(tune[IDF_TUNE_GEMM_OUTPROJ], CFG_OUTPROJ), s, o);
             idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
-            hipLaunchKernelGGL((rowblock_kernel<false>), dim3((unsigned)idf_cdiv(T, TC), B), dim3(256), 0, s, u_tmp, nullptr,
-                               nullptr, nullptr, nullptr, ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWl, ar + ly.ca_out_b,
-                               u_in, T);
-            u2 = u_in;
+            hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                               ar + ly.ln_b[1], k.x2, T);
         }
-        float *u3 = (u2 == k.uA) ? k.uB : k.uA;
-        // x2 = LN2(u2) -> xn ; hid = gelu(x2.W1^T + b1)
-        launch_gemm<true, EPI_GELU>(IDF_K_GEMM_FFN1, s, u2, D, D, ar + ly.ln_w[1], ar + ly.ln_b[1], ar + ly.ff1_w, ar + ly.ff1_b, k.hid, FF, N, FF,
-                                    k.xn, nullptr, T);
-        // u3 = x2 + hid.W2^T + b2
-        launch_gemm<false, EPI_RESID>(IDF_K_GEMM_FFN2, s, k.hid, FF, FF, nullptr, nullptr, ar + ly.ff2_w, ar + ly.ff2_b, u3, D, N, D, nullptr,
-                                      k.xn, T);
-        u_in = u3;
-        u_tmp = (u3 == k.uA) ? k.uB : k.uA;
+        // hid = gelu(x2.W1^T + b1) ; u3 = x2 + hid.W2^T + b2  (into the dead layer-input buffer)
+        Args f1{};
+        f1.A = k.x2; f1.lda = D; f1.K = D; f1.W = ar + ly.ff1_w; f1.bias = ar + ly.ff1_b; f1.C = k.hid; f1.ldc = FF; f1.M = N;
+        f1.N = FF; f1.T = T;
+        idf_prof_mark(IDF_K_GEMM_FFN1, s);
+        run_gemm<A_PLAIN, E_GELU>(pick(tune[IDF_TUNE_GEMM_FFN1], CFG_FFN1), s, f1);
+        Args f2{};
+        f2.A = k.hid; f2.lda = FF; f2.K = FF; f2.W = ar + ly.ff2_w; f2.bias = ar + ly.ff2_b; f2.C = u_in; f2.ldc = D; f2.M = N;
+        f2.N = D; f2.resid = k.x2; f2.T = T;
+        idf_prof_mark(IDF_K_GEMM_FFN2, s);
+        run_gemm<A_PLAIN, E_RESID>(pick(tune[IDF_TUNE_GEMM_FFN2], CFG_FFN2), s, f2);
         lnp_w = ar + ly.ln_w[2];
         lnp_b = ar + ly.ln_b[2];
     }
-    // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
-    launch_gemm<true, EPI_HEADS>(IDF_K_GEMM_HEADS, s, u_in, D, D, lnp_w, lnp_b, ar + w->out_w, ar + w->out_b, x0, C, N, C, nullptr, nullptr, T);
+    {   // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
+        Args g{};
+        g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + w->out_w; g.bias = ar + w->out_b; g.C = x0;
+        g.ldc = C; g.M = N; g.N = C; g.T = T;
+        idf_prof_mark(IDF_K_GEMM_HEADS, s);
+        run_gemm<A_LN, E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g);
+    }
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;

@@ -1,0 +1,482 @@
+// Generic tiled fp32-MFMA GEMM for the token-matrix contractions of the denoiser (gfx950).
+//
+//   C[M,N] = epi( pro(A)[M,K] . W[N,K]^T + bias )
+//
+// * arithmetic: v_mfma_f32_16x16x4_f32 -- exact fp32 products, fp32 accumulate (no reduced precision);
+// * workgroup tile BM x BN, WM x WN waves, each wave owns a (BM/WM) x (BN/WN) tile = TM x TN accumulators
+//   of 16x16 (>= 2 independent accumulators per wave keep the 40-cycle dependent latency hidden);
+// * LDS images are quad-major ([k/4][row][4], padded by one quad per plane): the four k-steps of a 16-wide
+//   k-group come from ONE ds_read_b128 per operand tile, and the register->LDS write of a 128-B row segment
+//   is conflict-free;
+// * global->register prefetch of chunk k+1 is issued before the MFMAs of chunk k (double-buffered LDS,
+//   one barrier per chunk).
+// A producers:  A_PLAIN row-major; A_LN LayerNorm over the 256-wide row on load (whole normalised rows are
+// parked in LDS once); A_TOKT gathers token rows from the sampler layout x[b][c][t] (row = b*T+t, k = c).
+// Epilogues: bias | gelu | +residual | heads (transposed store back to [b][c][t]) | embed (+temb[ts[b]]+pe[t]).
+#pragma once
+#include "common.h"
+
+namespace idf_gemm {
+
+enum { A_PLAIN = 0, A_LN = 1, A_TOKT = 2 };
+enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4 };
+
+struct Args {
+    const float *A;
+    int lda, K;
+    const float *lnw, *lnb;         // A_LN (null lnw: rows copied unnormalised)
+    const float *W;                 // [N][K]
+    const float *bias;              // [N] or null
+    float *C;
+    int ldc, M, N;
+    float *xn_out;                  // A_LN: normalised rows [M][256] written by the blockIdx.y == 0 column (nullable)
+    const float *resid;             // E_RESID, leading dimension ldc
+    int T;                          // tokens per clip (A_TOKT, E_HEADS, E_EMBED)
+    const int64_t *ts;              // E_EMBED: timestep per clip
+    const float *temb, *pe;         // E_EMBED: [n_steps][N], [max_T][N]
+    int n_steps;
+    long long *probe;               // tools/gemm_probe.hip only: per-workgroup s_memtime stamps (null on the product path)
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+#define IDF_MFMA4(acc, a, b)                                            \
+    do {                                                                \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); \
+    } while (0)
+
+
+// ---- epilogue shared by both kernels.  C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg.
+// rbase0 / col0: first row / column of this lane in accumulator tile (0,0); tiles step by 16.
+template <int TN>
+__device__ __forceinline__ void load_bias(const Args &g, float (&bv)[TN], int col0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = g.bias ? g.bias[min(col0 + j * 16, g.N - 1)] : 0.f;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void load_resid(const Args &g, float (&rres)[TM][TN][4], int rbase0, int col0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = min(col0 + j * 16, g.N - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rres[i][j][r] = g.resid[(size_t)min(rbase0 + i * 16 + r, g.M - 1) * g.ldc + col];
+        }
+}
+
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epilogue(const Args &g, const f32x4 (&acc)[TM][TN], const float (&rres)[TM][TN][4],
+                                         const float (&bvs)[TN], int rbase0, int col0) {
+    const int M = g.M, N = g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = rbase0 + i * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + j * 16;
+            const bool colok = col < N;
+            const float bv = bvs[j];
+            if constexpr (EPI == E_HEADS) {
+                // rows rbase..rbase+3 are 4 consecutive frames of one clip when T % 4 == 0: one 16-B store
+                if (!colok) continue;
+                const int b = rbase / g.T, t = rbase - b * g.T;
+                if ((g.T & 3) == 0 && rbase + 3 < M) {
+                    *reinterpret_cast<float4 *>(g.C + ((size_t)b * N + col) * g.T + t) =
+                        make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rbase + r;
+                        if (row >= M) continue;
+                        const int bb = row / g.T, tt = row - bb * g.T;
+                        g.C[((size_t)bb * N + col) * g.T + tt] = acc[i][j][r] + bv;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + r;
+                    float v = acc[i][j][r] + bv;
+                    if constexpr (EPI == E_GELU) v = gelu_fast(v);
+                    if constexpr (EPI == E_RESID) v += rres[i][j][r];
+                    if constexpr (EPI == E_EMBED) {
+                        const int rc = min(row, M - 1), b = rc / g.T, t = rc - b * g.T, cc = min(col, N - 1);
+                        int64_t step = g.ts[b];
+                        step = step < 0 ? 0 : (step >= g.n_steps ? g.n_steps - 1 : step);
+                        v += g.temb[(size_t)step * N + cc] + g.pe[(size_t)t * N + cc];
+                    }
+                    if (row < M && colok) g.C[(size_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int QC = KC / 4;                            // quads per k-chunk
+    constexpr int AQ = BM * 4 + 4, BQ = BN * 4 + 4;       // padded plane strides (floats)
+    constexpr int KLN = 256;                              // A_LN row width
+    constexpr int A_FLOATS = APRO == A_LN ? (KLN / 4) * AQ : 2 * QC * AQ;
+    constexpr int LA = (BM * QC + NT - 1) / NT, LB = (BN * QC + NT - 1) / NT;
+    static_assert(TM >= 1 && TN >= 1 && QC % 4 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + 2 * QC * BQ];
+    float *As = smem, *Bs = smem + A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const int K = g.K, M = g.M, N = g.N;
+    const int nk = (K + KC - 1) / KC;
+
+    float4 areg[LA], breg[LB];
+    auto load_b = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int f = tid + NT * i;
+            if ((BN * QC) % NT == 0 || f < BN * QC) {
+                const int col = f / QC, q = f % QC, n = n0 + col, k = kc * KC + q * 4;
+                breg[i] = (n < N && k < K) ? ld4(g.W + (size_t)n * K + k) : zero4();
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int f = tid + NT * i;
+            if ((BN * QC) % NT == 0 || f < BN * QC) {
+                const int col = f / QC, q = f % QC;
+                *reinterpret_cast<float4 *>(Bs + (buf * QC + q) * BQ + col * 4) = breg[i];
+            }
+        }
+    };
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int f = tid + NT * i;
+            if ((BM * QC) % NT == 0 || f < BM * QC) {
+                if constexpr (APRO == A_TOKT) {
+                    const int row = f % BM, q = f / BM, m = m0 + row, k = kc * KC + q * 4;
+                    float4 v = zero4();
+                    if (m < M && k < K) {
+                        const int b = m / g.T, t = m - b * g.T;
+                        const float *p = g.A + ((size_t)b * K + k) * g.T + t;
+                        v.x = p[0];
+                        v.y = p[(size_t)g.T];
+                        v.z = p[(size_t)2 * g.T];
+                        v.w = p[(size_t)3 * g.T];
+                    }
+                    areg[i] = v;
+                } else {
+                    const int row = f / QC, q = f % QC, m = m0 + row, k = kc * KC + q * 4;
+                    areg[i] = (m < M && k < K) ? ld4(g.A + (size_t)m * g.lda + k) : zero4();
+                }
+            }
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int f = tid + NT * i;
+            if ((BM * QC) % NT == 0 || f < BM * QC) {
+                const int row = APRO == A_TOKT ? f % BM : f / QC, q = APRO == A_TOKT ? f / BM : f % QC;
+                *reinterpret_cast<float4 *>(As + (buf * QC + q) * AQ + row * 4) = areg[i];
+            }
+        }
+    };
+
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
+    load_b(0);
+    if constexpr (APRO == A_LN) {
+        // whole rows: wave w owns rows w, w+NW, ...; a lane holds 4 consecutive features of the 256-wide row
+        constexpr int NW = WM * WN;
+        const float4 gw = g.lnw ? ld4(g.lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 gb = g.lnw ? ld4(g.lnb + lane * 4) : zero4();
+#pragma unroll
+        for (int i = 0; i < BM / NW; ++i) {
+            const int row = wave + NW * i, m = m0 + row;
+            float4 v = m < M ? ld4(g.A + (size_t)m * g.lda + lane * 4) : zero4();
+            if (g.lnw) {
+                float mean, rstd;
+                ln_row_stats(v, mean, rstd);
+                v.x = (v.x - mean) * rstd * gw.x + gb.x;
+                v.y = (v.y - mean) * rstd * gw.y + gb.y;
+                v.z = (v.z - mean) * rstd * gw.z + gb.z;
+                v.w = (v.w - mean) * rstd * gw.w + gb.w;
+            }
+            *reinterpret_cast<float4 *>(As + lane * AQ + row * 4) = v;
+            if (g.xn_out && blockIdx.y == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * KLN + lane * 4) = v;
+        }
+    } else {
+        load_a(0);
+        store_a(0);
+    }
+    store_b(0);
+    __syncthreads();
+    if (g.probe && tid == 0) g.probe[wg * 4 + 1] = clock64();
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) {
+            load_b(kc + 1);
+            if constexpr (APRO != A_LN) load_a(kc + 1);
+        }
+        const float *Ab = APRO == A_LN ? As + kc * QC * AQ : As + buf * QC * AQ;
+        const float *Bb = Bs + buf * QC * BQ;
+#pragma unroll
+        for (int s = 0; s < QC / 4; ++s) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ld4(Ab + (s * 4 + kq) * AQ + ((wm * TM + i) * 16 + li) * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = ld4(Bb + (s * 4 + kq) * BQ + ((wn * TN + j) * 16 + li) * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].x, b[j].x);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].y, b[j].y);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].z, b[j].z);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].w, b[j].w);
+        }
+        if (kc + 1 < nk) {
+            store_b(buf ^ 1);
+            if constexpr (APRO != A_LN) store_a(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    if (g.probe && tid == 0) g.probe[wg * 4 + 2] = clock64();
+    float rres[TM][TN][4], bvs[TN];
+    load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_RESID) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
+}
+
+template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
+inline void launch(hipStream_t s, const Args &g) {
+    dim3 grid((unsigned)idf_cdiv(g.M, BM), (unsigned)idf_cdiv(g.N, BN));
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KC, APRO, EPI>), grid, dim3(WM * WN * 64), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant (A_PLAIN / A_LN, K % KC == 0).
+//  * both operands go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass).  The LDS
+//    image of a wave instruction is lane-linear (1 KiB), so tiles are stored ROW-MAJOR and unpadded: KC/4 consecutive
+//    lanes fetch one contiguous KC*4-byte row segment (coalesced), and bank conflicts are removed by an XOR swizzle
+//    of the 16-B chunk index with the row number, applied to the SOURCE address on the way in and to the ds_read
+//    address on the way out (the same involution on both sides);
+//  * an MFMA operand fragment for a 16-wide k-group is still ONE ds_read_b128 (lane (i, kq) reads chunk 4s+kq of
+//    row i: k = 16s + 4kq + {0..3});
+//  * three LDS stages: chunk k+2 is in flight while chunk k is on the MFMAs; the only wait in the loop is a COUNTED
+//    s_waitcnt vmcnt(LPC) (chunk k+1 landed, chunk k+2 still flying) followed by ONE raw s_barrier per chunk;
+//  * KS = 2 splits the 16-wide k-groups of every chunk over two wave sets (2 waves per SIMD at one workgroup per
+//    CU), reduced through LDS at the end -- for the N = 256 GEMMs whose grid cannot fill the chip twice.
+// ------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 8, "vmcnt literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI>
+__global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g) {
+    constexpr int NWT = WM * WN, NW = NWT * KS;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int CH = KC / 4, NS = 3;                          // 16-B chunks per tile row; LDS stages
+    constexpr int RSL = 256 + 4;                                // A_LN: padded row stride of the normalised rows
+    constexpr int A_STAGE = APRO == A_LN ? 0 : BM * KC, STAGE = A_STAGE + BN * KC;
+    constexpr int A_LN_FLOATS = APRO == A_LN ? BM * RSL : 0;
+    constexpr int IA = A_STAGE / 256, IB = BN * KC / 256, IPC = IA + IB, LPC = IPC / NW;
+    constexpr int RED = KS > 1 ? NWT * 64 * TM * TN * 4 : 0;
+    static_assert(IPC % NW == 0 && LPC >= 1 && LPC <= 8, "chunk loads must split evenly over the waves");
+    static_assert((CH / 4) % KS == 0 && TM >= 1 && TN >= 1 && (CH == 8 || CH == 16), "tile shape");
+    static_assert(APRO != A_TOKT, "token gather uses the register-staged kernel");
+    constexpr int SMEM = A_LN_FLOATS + NS * STAGE;
+    __shared__ __attribute__((aligned(1024))) float smem[SMEM > RED ? SMEM : RED];
+    float *Aln = smem, *stages = smem + A_LN_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ks = wave / NWT, wt = wave % NWT, wm = wt / WN, wn = wt % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const int K = g.K, M = g.M, N = g.N;
+    const int nk = K / KC;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
+
+    // per-wave DMA descriptors: instruction i = wave + NW*j of the IPC that make up one chunk; lane l of it fills
+    // the 16-B LDS cell p = 64 i + l, i.e. (row p / CH, position p % CH), from source chunk (p % CH) ^ (row % CH)
+    const float *src[LPC];
+    int dst[LPC];
+#pragma unroll
+    for (int j = 0; j < LPC; ++j) {
+        const int i = wave + NW * j;
+        if (i < IA) {
+            const int p = i * 64 + lane, row = p / CH, c = (p % CH) ^ (row % CH);
+            src[j] = g.A + (size_t)min(m0 + row, M - 1) * g.lda + c * 4;
+            dst[j] = i * 256;
+        } else {
+            const int ib = i - IA, p = ib * 64 + lane, row = p / CH, c = (p % CH) ^ (row % CH);
+            src[j] = g.W + (size_t)min(n0 + row, N - 1) * K + c * 4;
+            dst[j] = A_STAGE + ib * 256;
+        }
+    }
+    auto issue = [&](int kc, int st) {
+#pragma unroll
+        for (int j = 0; j < LPC; ++j)
+            __builtin_amdgcn_global_load_lds((const void *)(src[j] + kc * KC), (lds_ptr_t)(stages + st * STAGE + dst[j]), 16, 0, 0);
+    };
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    float rres[TM][TN][4], bvs[TN];
+    load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_RESID) {
+        if (ks == 0) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    }
+    if constexpr (APRO == A_LN) {
+        const float4 gw = g.lnw ? ld4(g.lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 gb = g.lnw ? ld4(g.lnb + lane * 4) : zero4();
+#pragma unroll
+        for (int i = 0; i < BM / NW; ++i) {
+            const int row = wave + NW * i, m = m0 + row;
+            float4 v = m < M ? ld4(g.A + (size_t)m * g.lda + lane * 4) : zero4();
+            if (g.lnw) {
+                float mean, rstd;
+                ln_row_stats(v, mean, rstd);
+                v.x = (v.x - mean) * rstd * gw.x + gb.x;
+                v.y = (v.y - mean) * rstd * gw.y + gb.y;
+                v.z = (v.z - mean) * rstd * gw.z + gb.z;
+                v.w = (v.w - mean) * rstd * gw.w + gb.w;
+            }
+            *reinterpret_cast<float4 *>(Aln + row * RSL + lane * 4) = v;
+            if (g.xn_out && blockIdx.y == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * 256 + lane * 4) = v;
+        }
+    }
+    // chunk 0 landed (chunk 1 may still fly); the compiler's own waits for the ordinary loads above can only be stricter
+    if (nk > 1) wait_vmcnt<LPC>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g.probe && tid == 0) g.probe[wg * 4 + 1] = clock64();
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment bases: row offsets and the swizzle key of each operand tile row
+    int aoff[TM], akey[TM], boff[TN], bkey[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + li;
+        aoff[i] = APRO == A_LN ? row * RSL : row * KC;
+        akey[i] = row % CH;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 16 + li;
+        boff[j] = row * KC;
+        bkey[j] = row % CH;
+    }
+
+    int st = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 2 < nk) issue(kc + 2, st >= 1 ? st - 1 : 2);          // stage (kc+2) % 3, last read in iteration kc-1
+        const float *Ab = APRO == A_LN ? Aln + kc * KC : stages + st * STAGE;
+        const float *Bb = stages + st * STAGE + A_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < CH / 4 / KS; ++s2) {
+            const int c = (s2 * KS + ks) * 4 + kq;                     // chunk index within the tile row
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ld4(Ab + aoff[i] + (APRO == A_LN ? c : (c ^ akey[i])) * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = ld4(Bb + boff[j] + (c ^ bkey[j]) * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].x, b[j].x);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].y, b[j].y);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].z, b[j].z);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].w, b[j].w);
+        }
+        // chunk kc+1 must have landed before anyone reads it; chunk kc+2 (just issued) may keep flying
+        if (kc + 2 < nk) wait_vmcnt<LPC>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st = st == 2 ? 0 : st + 1;
+    }
+    if (g.probe && tid == 0) g.probe[wg * 4 + 2] = clock64();
+
+    if constexpr (KS > 1) {
+        // all LDS reads of the k-loop are behind the last barrier: reuse the buffer for the partial tiles
+        float *red = smem + (size_t)(wt * 64 + lane) * (TM * TN * 4);
+        if (ks == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4 *>(red + (i * TN + j) * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4 *>(red + (i * TN + j) * 4);
+        }
+    }
+    if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI>
+inline void launch_glds(hipStream_t s, const Args &g) {
+    dim3 grid((unsigned)idf_cdiv(g.M, BM), (unsigned)idf_cdiv(g.N, BN));
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI>), grid, dim3(WM * WN * KS * 64), 0, s, g);
+}
+
+}  // namespace idf_gemm

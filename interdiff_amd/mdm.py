@@ -12,7 +12,7 @@ Weights-only constants folded at pack time (host, once):
                    logit[t,n,j] = <Qc[n,j], x[t+j-1]>   (SURVEY.md appendix B.2);
   * temb[t][:]   : time_embed(pe[t]) for every diffusion step (layers.py:42-43) -- depends on
                    the weights and t only;
-  * W_in = [bodyEmbedding | objEmbedding] (transposed), W_out = [bodyFinalLinear ; objFinalLinear].
+  * W_in = [bodyEmbedding | objEmbedding] ([256][C]), W_out = [bodyFinalLinear ; objFinalLinear].
 """
 import ctypes as C
 import math
@@ -85,7 +85,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
     w = _lib.MdmWeights()
     win = np.concatenate([g('bodyEmbedding.weight'), g('objEmbedding.weight')], axis=1)      # [256, C]
     w.C = win.shape[1]
-    w.in_w = ar.add(win.T)
+    w.in_w = ar.add(win)                       # [256][C]: the embed GEMM's W[N][K]
     w.in_b = ar.add(g('bodyEmbedding.bias') + g('objEmbedding.bias'))
     w.out_w = ar.add(np.concatenate([g('bodyFinalLinear.weight'), g('objFinalLinear.weight')], axis=0))
     w.out_b = ar.add(np.concatenate([g('bodyFinalLinear.bias'), g('objFinalLinear.bias')]))

@@ -1,0 +1,97 @@
+"""Kernel-level A/B bench on one MI355X (not part of the product path).
+
+    python tools/kbench.py [--B 16] [--T 100] [--reps 20] [--sweep]
+
+Times every kernel kind of one denoiser forward (HIP events on the launch stream, via the library's profile
+hooks) and, with --sweep, re-times the forward under every tile configuration of each GEMM call site
+(interdiff_tune).  Output: one table per sweep + a JSON line, so the numbers can be pasted into profiles/.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from interdiff_amd import synthetic as syn, _lib          # noqa: E402
+from interdiff_amd.mdm import MDM                          # noqa: E402
+
+TUNE = dict(embed=0, qkv=1, outproj=2, ffn1=3, ffn2=4, heads=5, contact=6, misc=7)
+KIND_OF = dict(embed='embed', qkv='gemm_qkv', outproj='gemm_outproj', ffn1='gemm_ffn1', ffn2='gemm_ffn2', heads='gemm_heads')
+CFGS = {0: 'default', 1: '32x64 ks1 kc32', 2: '32x64 ks1 kc64', 3: '32x64 ks2 kc64', 4: '64x64 ks1 kc32', 5: '32x32 ks1 kc64',
+        6: '32x32 ks2 kc64', 7: '64x32 ks1 kc32', 8: '64x32 ks2 kc64', 9: 'reg-staged 32x64 kc32'}
+
+
+def profile_forward(lib, model, x, ts, y, reps):
+    for _ in range(3):
+        model(x, ts, y=y)
+    torch.cuda.synchronize()
+    _lib.check(lib.interdiff_profile_begin(100000))
+    for _ in range(reps):
+        model(x, ts, y=y)
+    ms = (C.c_double * len(_lib.KERNEL_KINDS))()
+    cnt = (C.c_int64 * len(_lib.KERNEL_KINDS))()
+    _lib.check(lib.interdiff_profile_end(ms, cnt))
+    out = {k: 1e3 * ms[i] / cnt[i] for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
+    out['_launches_per_forward'] = sum(cnt[i] for i in range(len(_lib.KERNEL_KINDS))) / reps
+    out['_sum_us_per_forward'] = 1e3 * sum(ms[i] for i in range(len(_lib.KERNEL_KINDS))) / reps
+    return out
+
+
+def wall_forward(model, x, ts, y, reps):
+    for _ in range(3):
+        model(x, ts, y=y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model(x, ts, y=y)
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--B', type=int, default=16)
+    ap.add_argument('--T', type=int, default=100)
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--sweep', action='store_true')
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    lib = _lib.load()
+    dev = 'cuda'
+    model = MDM(syn.mdm_state_dict(233), device=dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(args.B, 1, 144, args.T, generator=g).to(dev)
+    cond = torch.randn(10, args.B, 256, generator=g).to(dev)
+    ts = torch.full((args.B,), 500, dtype=torch.int64, device=dev)
+    y = {'cond': cond}
+    base = profile_forward(lib, model, x, ts, y, args.reps)
+    wall = wall_forward(model, x, ts, y, 200)
+    print('== default configuration, B=%d T=%d: forward wall %.1f us, sum of kernels %.1f us, %d launches'
+          % (args.B, args.T, wall, base['_sum_us_per_forward'], base['_launches_per_forward']))
+    for k, v in base.items():
+        if not k.startswith('_'):
+            print('   %-14s %8.2f us' % (k, v))
+    result = dict(B=args.B, T=args.T, default=base, wall_us=wall, sweeps={})
+    if args.sweep:
+        for site in ('ffn1', 'ffn2', 'outproj', 'qkv', 'heads', 'embed'):
+            cfgs = range(2) if site == 'embed' else range(10)
+            row = {}
+            for c in cfgs:
+                _lib.check(lib.interdiff_tune(TUNE[site], c))
+                p = profile_forward(lib, model, x, ts, y, args.reps)
+                row[c] = p[KIND_OF[site]]
+            _lib.check(lib.interdiff_tune(TUNE[site], 0))
+            result['sweeps'][site] = row
+            print('== %s' % site)
+            for c, v in row.items():
+                print('   cfg %d %-18s %8.2f us' % (c, CFGS[c], v))
+    print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

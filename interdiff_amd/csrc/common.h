@@ -2,13 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/interdiff_hip.h"
 
 #define IDF_WAVE 64
 
-#define IDF_CHECK_LAUNCH()                                      \
-    do {                                                        \
-        if (hipGetLastError() != hipSuccess) return IDF_E_LAUNCH; \
+#define IDF_CHECK_LAUNCH()                                                                        \
+    do {                                                                                          \
+        const hipError_t idf_e_ = hipGetLastError();                                              \
+        if (idf_e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "interdiff_hip: %s (%s:%d)\n", hipGetErrorString(idf_e_), __FILE__, __LINE__); \
+            return IDF_E_LAUNCH;                                                                  \
+        }                                                                                         \
     } while (0)
 
 static inline hipStream_t idf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

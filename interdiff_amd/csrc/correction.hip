@@ -77,27 +77,35 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 }
 
 // ---- K4: per-frame contact analysis -------------------------------------------------------------------
-constexpr int QP = 8;                  // object points per thread (P <= 2048)
+// One workgroup (CT threads = 8 waves, two per SIMD) per frame; every thread owns QP object points as QP/2 PACKED
+// pairs: the exact-arithmetic distance (dx*dx + dy*dy) + dz*dz of a pair against the LDS-broadcast vertex is
+// 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add (no FMA contraction, so the argmin is bit-identical to geometry.hip
+// and to the oracle), then compare + 2 selects per point.
+constexpr int CT = 512;                // threads per workgroup
+constexpr int QP = 4;                  // object points per thread (P <= CT*QP = 2048)
 constexpr int MAXM = 128;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void corr_contact_kernel(const float *__restrict__ verts, int V,
-                                                           const float *__restrict__ obj_points, int P,
-                                                           const float *__restrict__ objR, const float *__restrict__ objT,
-                                                           const int32_t *__restrict__ faces, const int32_t *__restrict__ adj_ptr,
-                                                           const int32_t *__restrict__ adj_face,
-                                                           const int32_t *__restrict__ adj_corner,
-                                                           const int32_t *__restrict__ markers_idx, int M, int B,
-                                                           float *__restrict__ markers_out, float *__restrict__ loss_sum,
-                                                           float *__restrict__ min_dist, int32_t *__restrict__ label,
-                                                           float *__restrict__ o2h_out /* nullable [N][P] */) {
-    extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V] then markers [MAXM]
-    float4 *ms = vs + V;
+__global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restrict__ verts, int V,
+                                                          const float *__restrict__ obj_points, int P,
+                                                          const float *__restrict__ objR, const float *__restrict__ objT,
+                                                          const int32_t *__restrict__ faces, const int32_t *__restrict__ adj_ptr,
+                                                          const int32_t *__restrict__ adj_face,
+                                                          const int32_t *__restrict__ adj_corner,
+                                                          const int32_t *__restrict__ markers_idx, int M, int B,
+                                                          float *__restrict__ markers_out, float *__restrict__ loss_sum,
+                                                          float *__restrict__ min_dist, int32_t *__restrict__ label,
+                                                          float *__restrict__ o2h_out /* nullable [N][P] */) {
+    extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V rounded up to 4] then markers [MAXM]
+    const int V4 = (V + 3) & ~3;
+    float4 *ms = vs + V4;
     __shared__ int flags[MAXM];
-    __shared__ float red[256];
+    __shared__ float red[CT];
     const int64_t n = blockIdx.x;
     const int b = (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
-    for (int v = tid; v < V; v += 256) vs[v] = make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], 0.f);
+    for (int v = tid; v < V4; v += CT)
+        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], 0.f) : make_float4(3e18f, 3e18f, 3e18f, 0.f);
     if (tid < MAXM) flags[tid] = 0;
     __syncthreads();
     if (tid < M) {
@@ -111,34 +119,50 @@ __global__ __launch_bounds__(256) void corr_contact_kernel(const float *__restri
     for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
-    float qx[QP], qy[QP], qz[QP], best[QP];
-    int bi[QP];
+    float qx[QP], qy[QP], qz[QP];
     const float *op = obj_points + (size_t)b * P * 3;
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + CT * k;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (i < P) { px = op[3 * i]; py = op[3 * i + 1]; pz = op[3 * i + 2]; }
         // matmul(points, R^T) + t  (eval_smpl_short.py:107)
         qx[k] = (px * R[0] + py * R[1] + pz * R[2]) + tr[0];
         qy[k] = (px * R[3] + py * R[4] + pz * R[5]) + tr[1];
         qz[k] = (px * R[6] + py * R[7] + pz * R[8]) + tr[2];
-        best[k] = FLT_MAX;
-        bi[k] = 0;
+    }
+    v2f QX[QP / 2], QY[QP / 2], QZ[QP / 2], best[QP / 2];
+    int bi[QP];
+#pragma unroll
+    for (int k = 0; k < QP / 2; ++k) {
+        QX[k] = v2f{qx[2 * k], qx[2 * k + 1]};
+        QY[k] = v2f{qy[2 * k], qy[2 * k + 1]};
+        QZ[k] = v2f{qz[2 * k], qz[2 * k + 1]};
+        best[k] = v2f{FLT_MAX, FLT_MAX};
+        bi[2 * k] = bi[2 * k + 1] = 0;
     }
     __syncthreads();
-    for (int v = 0; v < V; ++v) {
-        const float4 p = vs[v];
+    {
+#pragma clang fp contract(off)
+        for (int v0 = 0; v0 < V4; v0 += 4) {
 #pragma unroll
-        for (int k = 0; k < QP; ++k) {
-            const float d2 = dist2_exact(qx[k], qy[k], qz[k], p.x, p.y, p.z);
-            if (d2 < best[k]) { best[k] = d2; bi[k] = v; }
+            for (int u = 0; u < 4; ++u) {
+                const float4 p = vs[v0 + u];
+                const v2f PX = v2f{p.x, p.x}, PY = v2f{p.y, p.y}, PZ = v2f{p.z, p.z};
+#pragma unroll
+                for (int k = 0; k < QP / 2; ++k) {
+                    const v2f dx = QX[k] - PX, dy = QY[k] - PY, dz = QZ[k] - PZ;
+                    const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2.x < best[k].x) { best[k].x = d2.x; bi[2 * k] = v0 + u; }
+                    if (d2.y < best[k].y) { best[k].y = d2.y; bi[2 * k + 1] = v0 + u; }
+                }
+            }
         }
     }
     float loss = 0.f, mind = FLT_MAX;
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + CT * k;
         if (i >= P) continue;
         // normal of the nearest vertex (data/tools.py:4-40 restricted to one vertex), from LDS
         const int v = bi[k];
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256) void corr_contact_kernel(const float *__restri
     // deterministic block reductions
     red[tid] = loss;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = CT / 2; s > 0; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(256) void corr_contact_kernel(const float *__restri
     __syncthreads();
     red[tid] = mind;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = CT / 2; s > 0; s >>= 1) {
         if (tid < s) red[tid] = fminf(red[tid], red[tid + s]);
         __syncthreads();
     }
@@ -270,7 +294,7 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
                                     size_t ws_bytes, void *stream) {
     if (!c || !c->smpl || !c->objproj || !x0 || !gt || !hand_pose || !beta || !obj_points || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
     const int V = c->smpl->V, M = c->n_markers, P = c->n_points;
-    if (c->smpl->J != 52 || c->smpl->n_betas != 10 || M > MAXM || M != c->objproj->P || P > 256 * QP || T != c->objproj->T ||
+    if (c->smpl->J != 52 || c->smpl->n_betas != 10 || M > MAXM || M != c->objproj->P || P > CT * QP || T != c->objproj->T ||
         c->past_len != c->objproj->past_len || c->past_len >= T)
         return IDF_E_INVAL;
     CorrWs w = carve(c, B, T, ws);
@@ -282,16 +306,16 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
                        w.trans, w.objR, w.objT, w.gt_angles, w.gt_trans);
     int rc = interdiff_smpl_forward(c->smpl, w.pose, beta, w.trans, N, w.verts, w.jtr, nullptr, w.smpl_ws, w.smpl_ws_bytes, stream);
     if (rc) return rc;
-    const size_t lds = ((size_t)V + MAXM) * sizeof(float4);
+    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
             return IDF_E_LAUNCH;
         attr_set = true;
     }
-    if (lds > 160 * 1024 - 2048) return IDF_E_INVAL;
+    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
     idf_prof_mark(IDF_K_CORR_CONTACT, s);
-    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(256), lds, s, w.verts, V, obj_points, P, w.objR, w.objT, c->faces,
+    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, w.verts, V, obj_points, P, w.objR, w.objT, c->faces,
                        c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label,
                        (float *)nullptr);
     uint8_t *cond = condition ? condition : w.condition;

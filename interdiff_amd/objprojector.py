@@ -6,7 +6,8 @@ the ``model.`` prefix stripped) and folds, on the host in float64:
   * eval-mode BatchNorm into the preceding 1x1 convolution (tcn.0/tcn.1 and residual.0/residual.1);
   * the idx_pad frame repetition into ``dct_pad`` [n_pre, past_len];
   * DCT / IDCT matrices exactly as get_dct_matrix builds them (fp64, inverse by numpy) -> fp32.
-Arena layer block (see csrc/objproj.hip): [Tm | (Am)] Wt bt Wr br prelu.
+Arena layer block (see csrc/objproj.hip): Tm | (A^T padded to 80x80 per coefficient) | Wt bt Wr br (zero-padded to
+multiples of 16 channels: MFMA operands) | prelu.
 """
 import ctypes as C
 import numpy as np
@@ -15,6 +16,7 @@ from . import _lib
 
 HAND_MARKERS = [10, 11, 14, 31, 13, 17, 23, 28, 27] + [60, 43, 44, 47, 62, 46, 51, 57]   # data/utils.py:249-260
 STACKS = ('st_gcnns_relative', 'st_gcnns', 'st_gcnns_all')
+VP = 80                                  # nodes padded to 5 MFMA tiles (csrc/objproj.hip)
 
 
 def dct_matrices(N):
@@ -65,12 +67,29 @@ def pack_objprojector(sd, T, past_len, device, n_pre=10, P=67):
             p = '%s.%d' % (name, l)
             Wt, bt = _fold(sd, p + '.tcn.0', p + '.tcn.1')
             Wr, br = _fold(sd, p + '.residual.0', p + '.residual.1')
-            blk = [_np(sd[p + '.gcn.T']).ravel()]
+            cout, cin = Wt.shape
+            cinp, coutp = -(-cin // 16) * 16, -(-cout // 16) * 16
+
+            def padw(W):
+                out = np.zeros((coutp, cinp))
+                out[:cout, :cin] = W
+                return out.ravel()
+
+            def padb(b):
+                out = np.zeros(coutp)
+                out[:cout] = b
+                return out
+            Tm = _np(sd[p + '.gcn.T']).ravel()
             if s == 2:
-                blk.append(_np(sd[p + '.gcn.A']).ravel())
-            blk += [Wt.ravel(), bt, Wr.ravel(), br, _np(sd[p + '.prelu.weight']).ravel()]
+                A = _np(sd[p + '.gcn.A'])                                  # [n_pre, nodes, nodes] : y[w] = sum_v x[v] A[t][v][w]
+                AT = np.zeros((n_pre, VP, VP))
+                AT[:, :A.shape[2], :A.shape[1]] = A.transpose(0, 2, 1)     # [t][w][v], zero padded to 80 x 80
+                blk = [Tm, AT.ravel()]
+            else:
+                blk = [Tm, np.zeros(12)]                                   # keep the weights 16-byte aligned
+            blk += [padw(Wt), padb(bt), padw(Wr), padb(br), _np(sd[p + '.prelu.weight']).ravel()]
             op.layer[s * 4 + l] = add(np.concatenate(blk))
-            op.cout[s * 4 + l], op.cin[s * 4 + l] = Wt.shape
+            op.cout[s * 4 + l], op.cin[s * 4 + l] = cout, cin
     arena = torch.from_numpy(np.concatenate(parts)).to(device)
     op.arena = arena.data_ptr()
     return op, arena

@@ -213,7 +213,11 @@ int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt
                          uint8_t *condition, int32_t *contact, float *distance, float *loss,
                          void *ws, size_t ws_bytes, void *stream);
 
-/* Evaluation metrics (eval_smpl_short.py:24-81) on future frames; each output [B]. */
+/* Evaluation metrics (eval_smpl_short.py:24-81) over the T frames handed in (the caller slices the future frames,
+ * :279); frame-major inputs: obj_pred/obj_gt [T,B,6] (axis-angle | translation), jtr/jtr_gt [T,B,J,3],
+ * body_trans(_gt) [T,B,3], verts [T,B,V,3], obj_points [B,P,3] (canonical).  out6 [6][B] rows: global_mpjpe,
+ * local_mpjpe, body_translation, obj_translation, obj_rot_error, penetrate. */
+size_t interdiff_metrics_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);
 int interdiff_metrics(const idf_correction_ctx *c, const float *obj_pred, const float *jtr,
                       const float *body_trans, const float *obj_gt, const float *jtr_gt,
                       const float *body_trans_gt, const float *verts, const float *obj_points,

@@ -75,6 +75,7 @@ _SIGS = {
     'interdiff_correction_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_correction': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, i32, i32, f32,
                                        vp, vp, vp, vp, vp, sz, vp]),
+    'interdiff_metrics_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_metrics': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                     vp, vp, sz, vp]),
     'interdiff_profile_begin': (C.c_int, [i32]),

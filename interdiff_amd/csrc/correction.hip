@@ -333,11 +333,139 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
     return IDF_OK;
 }
 
+// ---- evaluation metrics (row E1, eval_smpl_short.py:24-81) --------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void metrics_prepare_kernel(const float *__restrict__ obj_pred, int64_t N,
+                                                              float *__restrict__ objR, float *__restrict__ objT) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float q[4], m[9];
+    rot::axis_angle_to_quaternion(obj_pred + n * 6, q);
+    rot::quaternion_to_matrix(q, m);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) objR[n * 9 + k] = m[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) objT[n * 3 + k] = obj_pred[n * 6 + 3 + k];
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {      // 256 threads, deterministic tree
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// one workgroup per clip; out6 rows: global_mpjpe, local_mpjpe, body_translation, obj_translation, obj_rot_error, penetrate
+__global__ __launch_bounds__(256) void metrics_reduce_kernel(const float *__restrict__ obj_pred, const float *__restrict__ jtr,
+                                                             const float *__restrict__ body_trans, const float *__restrict__ obj_gt,
+                                                             const float *__restrict__ jtr_gt, const float *__restrict__ body_trans_gt,
+                                                             const float *__restrict__ o2h, int B, int T, int J, int P,
+                                                             float *__restrict__ out6) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float g = 0.f, l = 0.f;
+    for (int i = tid; i < T * J; i += 256) {
+        const int t = i / J, j = i - t * J;
+        const float *a = jtr + (((size_t)t * B + b) * J + j) * 3, *c = jtr_gt + (((size_t)t * B + b) * J + j) * 3;
+        const float *a0 = jtr + ((size_t)t * B + b) * J * 3, *c0 = jtr_gt + ((size_t)t * B + b) * J * 3;
+        const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
+        g += sqrtf(dx * dx + dy * dy + dz * dz);
+        const float ex = (a[0] - a0[0]) - (c[0] - c0[0]), ey = (a[1] - a0[1]) - (c[1] - c0[1]), ez = (a[2] - a0[2]) - (c[2] - c0[2]);
+        l += sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    float bt = 0.f, ot = 0.f, rq = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const size_t n = (size_t)t * B + b;
+        const float *x = body_trans + n * 3, *y = body_trans_gt + n * 3;
+        bt += sqrtf((x[0] - y[0]) * (x[0] - y[0]) + (x[1] - y[1]) * (x[1] - y[1]) + (x[2] - y[2]) * (x[2] - y[2]));
+        const float *p = obj_pred + n * 6, *q = obj_gt + n * 6;
+        ot += sqrtf((p[3] - q[3]) * (p[3] - q[3]) + (p[4] - q[4]) * (p[4] - q[4]) + (p[5] - q[5]) * (p[5] - q[5]));
+        float qa[4], qb[4];
+        rot::axis_angle_to_quaternion(p, qa);
+        rot::axis_angle_to_quaternion(q, qb);
+        float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e1 += fabsf(qa[k] - qb[k]); e2 += fabsf(qa[k] + qb[k]); }
+        rq += fminf(e1, e2);
+    }
+    const float gs = block_sum(g, red), ls = block_sum(l, red), bs = block_sum(bt, red), os = block_sum(ot, red), rs = block_sum(rq, red);
+    float pen = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float *row = o2h + ((size_t)t * B + b) * P;
+        float c = 0.f;
+        for (int i = tid; i < P; i += 256) c += row[i] < 0.f ? 1.f : 0.f;
+        const float cs = block_sum(c, red);
+        pen += cs / (float)P;
+    }
+    if (tid == 0) {
+        out6[0 * B + b] = gs / (float)J / (float)T;
+        out6[1 * B + b] = ls / (float)J / (float)T;
+        out6[2 * B + b] = bs / (float)T;
+        out6[3 * B + b] = os / (float)T;
+        out6[4 * B + b] = rs / (float)T;
+        out6[5 * B + b] = pen / (float)T;
+    }
+}
+
+struct MetWs {
+    float *objR, *objT, *o2h, *markers, *loss_sum, *min_dist;
+    int32_t *label;
+    size_t total;
+};
+MetWs carve_metrics(const idf_correction_ctx *c, int B, int T, void *ws) {
+    const int64_t N = (int64_t)B * T;
+    char *p = reinterpret_cast<char *>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += idf_align(bytes); return r; };
+    MetWs w;
+    w.objR = (float *)take(N * 9 * 4);
+    w.objT = (float *)take(N * 3 * 4);
+    w.o2h = (float *)take((size_t)N * c->n_points * 4);
+    w.markers = (float *)take((size_t)N * c->n_markers * 3 * 4);
+    w.loss_sum = (float *)take(N * 4);
+    w.min_dist = (float *)take(N * 4);
+    w.label = (int32_t *)take((size_t)N * c->n_markers * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t interdiff_metrics_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T) {
+    if (!c || B <= 0 || T <= 0) return 0;
+    return carve_metrics(c, B, T, nullptr).total;
+}
+
 extern "C" int interdiff_metrics(const idf_correction_ctx *c, const float *obj_pred, const float *jtr, const float *body_trans,
                                  const float *obj_gt, const float *jtr_gt, const float *body_trans_gt, const float *verts,
                                  const float *obj_points, int32_t B, int32_t T, int32_t J, float *out6, void *ws, size_t ws_bytes,
                                  void *stream) {
-    (void)c; (void)obj_pred; (void)jtr; (void)body_trans; (void)obj_gt; (void)jtr_gt; (void)body_trans_gt; (void)verts;
-    (void)obj_points; (void)B; (void)T; (void)J; (void)out6; (void)ws; (void)ws_bytes; (void)stream;
-    return IDF_E_INVAL;   // TODO(round 1): implemented in metrics.hip once the sampler path is parity-green
+    if (!c || !c->smpl || !obj_pred || !jtr || !body_trans || !obj_gt || !jtr_gt || !body_trans_gt || !verts || !obj_points || !out6 ||
+        !ws || B <= 0 || T <= 0 || J <= 0)
+        return IDF_E_INVAL;
+    const int V = c->smpl->V, M = c->n_markers, P = c->n_points;
+    if (M > MAXM || P > CT * QP) return IDF_E_INVAL;
+    MetWs w = carve_metrics(c, B, T, ws);
+    if (ws_bytes < w.total) return IDF_E_NOMEM;
+    hipStream_t s = idf_stream(stream);
+    const int64_t N = (int64_t)B * T;
+    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
+    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+        return IDF_E_LAUNCH;
+    idf_prof_mark(IDF_K_OTHER, s);
+    hipLaunchKernelGGL(metrics_prepare_kernel, dim3((unsigned)idf_cdiv(N, 256)), dim3(256), 0, s, obj_pred, N, w.objR, w.objT);
+    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, w.objR, w.objT, c->faces,
+                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h);
+    hipLaunchKernelGGL(metrics_reduce_kernel, dim3(B), dim3(256), 0, s, obj_pred, jtr, body_trans, obj_gt, jtr_gt, body_trans_gt, w.o2h, B,
+                       T, J, P, out6);
+    idf_prof_mark(-1, s);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
 }

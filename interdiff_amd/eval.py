@@ -1,0 +1,141 @@
+"""Evaluation glue of eval_smpl_short.py (rows E1/E2 of SURVEY.md §8) on the HIP path.
+
+Mirrors ``sample_once_proj`` (:133-177), ``sample_once`` (:179-215), ``get_gt`` (:225-250), ``metrics`` (:24-81) and
+``smooth`` (:217-223).  The reference feeds a dataset batch (dict of per-frame lists) through the encoder
+(``_get_embeddings``: a "next" row); here the clip batch is the tensor schema of SURVEY.md §8(d):
+
+    gt [B,1,144,T]   cond [10,B,256]   hand_pose [T,B,90] (GT hands, NOT padded)   beta [T,B,10]   obj_points [B,P,3]
+
+torch is used for views / concatenation only; every arithmetic step (rot6d -> axis-angle, SMPL, nearest
+neighbours, the metric reductions) runs in libinterdiff_hip.so.
+"""
+import ctypes as C
+import torch
+from . import _lib, transforms as tr
+from .dist import METRIC_KEYS
+
+SMPL_DIM = 132          # 22 joints x rot6d (eval_smpl_short.py:416)
+
+
+def idx_pad(past_len, T):
+    """eval_smpl_short.py:407."""
+    return list(range(past_len)) + [past_len - 1] * (T - past_len)
+
+
+def split_tokens(x):
+    """[B,1,144,T] -> body [T,B,135], obj [T,B,9]  (:154-155)."""
+    xt = x.squeeze(1).permute(2, 0, 1).contiguous()
+    return xt[..., :SMPL_DIM + 3], xt[..., SMPL_DIM + 3:]
+
+
+def model_kwargs_for(batch, past_len):
+    """model_kwargs['y'] as sample_once_proj builds it (:136-150), minus 'smpl'/'obj_model' which the HipCorrection
+    object owns on this path."""
+    gt = batch['gt']
+    T = gt.shape[-1]
+    mask = torch.ones_like(gt, dtype=torch.bool)
+    mask[..., past_len:] = False
+    return dict(cond=batch['cond'], inpainted_motion=gt, inpainting_mask=mask,
+                hand_pose=batch['hand_pose'][idx_pad(past_len, T)].contiguous(), beta=batch['beta'], obj_points=batch['obj_points'])
+
+
+def _to_pose(tokens_body, tokens_obj, hands, smpl, beta):
+    """rot6d tokens -> (obj [T,B,6] axis-angle|trans, body [T,B,159], verts, jtr) (:156-173)."""
+    T, B, _ = tokens_body.shape
+    body_rot = tr.rotation_6d_to_axis_angle(tokens_body[..., :SMPL_DIM].reshape(T, B, -1, 6)).reshape(T, B, -1)
+    obj_rot = tr.rotation_6d_to_axis_angle(tokens_obj[..., :6])
+    body = torch.cat([body_rot, hands, tokens_body[..., -3:]], dim=2)
+    flat = body.reshape(T * B, -1)
+    verts, jtr, _, _ = smpl(flat[:, :-3], th_betas=beta.reshape(T * B, -1), th_trans=flat[:, -3:], want_v_posed=False)
+    obj = torch.cat([obj_rot, tokens_obj[..., -3:]], dim=2)
+    return obj, body, verts.reshape(T, B, -1, 3), jtr.reshape(T, B, -1, 3)
+
+
+def finalize(sample, batch, smpl, past_len):
+    body, obj = split_tokens(sample)
+    T = body.shape[0]
+    obj_pred, body_pred, verts, jtr = _to_pose(body, obj, batch['hand_pose'][idx_pad(past_len, T)], smpl, batch['beta'])
+    return obj_pred, body_pred, verts, jtr, jtr[:, :, 0, :]
+
+
+def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=None, **loop_kw):
+    """Full InterDiff: diffusion + correction hook.  Returns (obj_pred [T,B,6], body_pred [T,B,159], verts [T,B,V,3],
+    jtr [T,B,J,3], pelvis [T,B,3]) like the reference (:177).  ``noise`` / ``step_noise`` / ``seed`` make it deterministic."""
+    gt = batch['gt']
+    if noise is None:
+        noise = torch.randn(*gt.shape, device=gt.device)
+    sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise,
+                                     model_kwargs={'y': model_kwargs_for(batch, past_len)}, denoised_fn=correction, **loop_kw)
+    return finalize(sample, batch, correction.smpl if correction is not None else loop_kw['smpl'], past_len)
+
+
+def sample_once(model, diffusion, smpl, batch, past_len=10, noise=None, **loop_kw):
+    """Diffusion only (mode no_correction, :179-215)."""
+    gt = batch['gt']
+    if noise is None:
+        noise = torch.randn(*gt.shape, device=gt.device)
+    y = model_kwargs_for(batch, past_len)
+    sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise, model_kwargs={'y': y}, **loop_kw)
+    return finalize(sample, batch, smpl, past_len)
+
+
+def get_gt(batch, smpl):
+    """:225-250 -- GT hands are used as they are (no padding).  Returns (obj_gt, jtr_gt, body_gt, faces)."""
+    body, obj = split_tokens(batch['gt'])
+    obj_gt, body_gt, _, jtr = _to_pose(body, obj, batch['hand_pose'], smpl, batch['beta'])
+    return obj_gt, jtr, body_gt, smpl.th_faces
+
+
+def smooth(obj, body, verts, jtrs, pelvis, future_len):
+    """:217-223 (rendering only; applied after the metrics)."""
+    f = future_len
+    out = []
+    for a in (obj, body, verts, jtrs, pelvis):
+        a[-f:] = a[-f:] + (2 * a[-f - 1] - a[-f - 2] - a[-f])
+        out.append(a)
+    return tuple(out)
+
+
+class Metrics:
+    """``metrics(obj_pred, body_jtr, body, obj_gt, body_jtr_gt, body_gt, verts, faces, obj_points)`` (:24-81) on
+    ``interdiff_metrics``; owns its workspace.  ``correction`` supplies the mesh topology / packed SMPL handle."""
+
+    def __init__(self, correction):
+        self.lib = _lib.load()
+        self.c = correction
+        self._ws = None
+
+    def __call__(self, obj_pred, body_jtr, body, obj_gt, body_jtr_gt, body_gt, verts, faces, obj_points):
+        T, B, J, _ = body_jtr_gt.shape
+        if obj_points.shape[1] != self.c.ctx.n_points:
+            raise ValueError('obj_points must have %d points' % self.c.ctx.n_points)
+        f32 = lambda a: a.contiguous().float()
+        op, og, jt, jg = f32(obj_pred), f32(obj_gt), f32(body_jtr), f32(body_jtr_gt)
+        bt, bg, vv, pts = f32(body[..., -3:]), f32(body_gt[..., -3:]), f32(verts), f32(obj_points)
+        need = self.lib.interdiff_metrics_workspace_bytes(C.byref(self.c.ctx), B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=op.device)
+        out = torch.empty(6, B, dtype=torch.float32, device=op.device)
+        _lib.check(self.lib.interdiff_metrics(C.byref(self.c.ctx), _lib.dptr(op), _lib.dptr(jt), _lib.dptr(bt), _lib.dptr(og),
+                                              _lib.dptr(jg), _lib.dptr(bg), _lib.dptr(vv), _lib.dptr(pts), B, T, J, _lib.dptr(out),
+                                              _lib.dptr(self._ws), self._ws.numel(), _lib.stream()), 'metrics')
+        return {k: out[i] for i, k in enumerate(METRIC_KEYS)}
+
+
+def evaluate_batch(model, diffusion, correction, batch, past_len=10, mode='correction', diverse_samples=1, noise=None, **loop_kw):
+    """One iteration of the reference's outer eval loop (:252-296) for a clip batch: sample ``diverse_samples`` times,
+    score each against the ground truth on the future frames, keep the per-clip minimum (:291-296).  Returns the six
+    [B] metric vectors (ready for dist.gather_metrics)."""
+    smpl = correction.smpl
+    obj_gt, jtr_gt, body_gt, faces = get_gt(batch, smpl)
+    met = Metrics(correction)
+    best = None
+    for _ in range(diverse_samples):
+        if mode == 'correction':
+            obj, body, verts, jtr, _ = sample_once_proj(model, diffusion, correction, batch, past_len, noise=noise, **loop_kw)
+        else:
+            obj, body, verts, jtr, _ = sample_once(model, diffusion, smpl, batch, past_len, noise=noise, **loop_kw)
+        m = met(obj[past_len:], jtr[past_len:], body[past_len:], obj_gt[past_len:], jtr_gt[past_len:], body_gt[past_len:],
+                verts[past_len:], faces, batch['obj_points'])
+        best = m if best is None else {k: torch.minimum(best[k], m[k]) for k in m}
+    return best

@@ -125,3 +125,15 @@ def loop_inputs():
     T, B, P = LOOP_SHAPE
     bt = _clip(11, B, T, P)
     return bt['noise'], model_kwargs_y(bt, T), NoiseStream(6000)
+
+
+EVAL_SHAPE = (14, 2, 128)              # T, B, P : eval glue (sample_once_proj / get_gt / metrics), 50-step schedule
+EVAL_STEPS = 50
+
+
+def eval_inputs():
+    """Clip batch in the tensor schema of interdiff_amd/eval.py + the injected noise."""
+    T, B, P = EVAL_SHAPE
+    bt = _clip(21, B, T, P)
+    batch = dict(gt=bt['gt'], cond=bt['cond'], hand_pose=bt['hand_pose'], beta=bt['beta'], obj_points=bt['obj_points'])
+    return batch, bt['noise'], NoiseStream(7000)

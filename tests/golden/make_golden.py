@@ -17,6 +17,8 @@ What each fixture pins (reference file:line in brackets):
   denoised_fn.npz  eval_smpl_short.denoised_fn            [eval_smpl_short.py:84-130]
   loop.npz         GaussianDiffusion.p_sample_loop, full 1000 steps, with the reference MDM and
                    the reference denoised_fn, injected per-step noise [gaussian_diffusion.py:598-736]
+  eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
+                   through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
 import os
 import sys
@@ -168,6 +170,36 @@ def main():
     finally:
         gd.th.randn_like = real_randn_like
     save('loop.npz', **{'dump_%d' % s: np_(v) for s, v in zip(fx.LOOP_DUMPS, dumps)})
+
+    # ---- eval glue: the reference's sample_once_proj / get_gt / metrics on a tiny clip, 50-step schedule.
+    # The dataset batch and the encoder (_get_embeddings: a "next" row) are stand-ins that hand back our tensors.
+    T, B, P = fx.EVAL_SHAPE
+    batch, noise, stream = fx.eval_inputs()
+    past = fx.PAST
+    ev.args = Namespace(smpl_dim=132, past_len=past, future_len=T - past)
+    ev.idx_pad = list(range(past)) + [past - 1] * (T - past)
+    ev.device = torch.device('cpu')
+    om.model = ref_objproj(T)
+    ev.obj_model = om
+    net._get_embeddings = lambda b, device: (batch['cond'], batch['gt'].squeeze(1).permute(2, 0, 1).contiguous())
+    lit = Holder()
+    lit.model, lit.diffusion, lit.body_model = net, ref_diffusion(fx.EVAL_STEPS), {'male': L}
+    ev.model = lit
+    pose_full = torch.cat([torch.zeros(T, B, 66), batch['hand_pose']], dim=2)     # only [:, 66:] is read (:146)
+    rb = {'frames': [{'smplfit_params': {'pose': pose_full[t], 'betas': batch['beta'][t]}} for t in range(T)],
+          'obj_points': torch.cat([batch['obj_points'], torch.zeros(B, P, 3)], dim=2)}
+    real_randn, gd.th.randn_like = torch.randn, (lambda x: stream.next_like(x))
+    torch.randn = lambda *shape, **kw: noise.clone()
+    try:
+        obj, body, verts, jtrs, pelvis = ev.sample_once_proj(rb)
+    finally:
+        torch.randn, gd.th.randn_like = real_randn, real_randn_like
+    obj_gt, jtr_gt, body_gt, faces = ev.get_gt(rb)
+    met = ev.metrics(obj[past:], jtrs[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces,
+                     batch['obj_points'])
+    sub = fx.vertex_subset()
+    save('eval.npz', obj=np_(obj), body=np_(body), verts=np_(verts[:, :, sub]), jtr=np_(jtrs), pelvis=np_(pelvis),
+         obj_gt=np_(obj_gt), jtr_gt=np_(jtr_gt), body_gt=np_(body_gt), **{'m_' + k: np_(v) for k, v in met.items()})
 
 
 if __name__ == '__main__':

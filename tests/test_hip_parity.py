@@ -231,3 +231,50 @@ def test_full_1000_step_loop_golden(mdm, smpl):
     for s, d in zip(fx.LOOP_DUMPS, dumps):
         worst = max(worst, close(d, z['dump_%d' % s], 5e-4, 'loop index %d' % s))
     print('full-loop worst rel err %.2e' % worst)
+
+
+# ------------------------------------------------------------------------------------------ eval glue + metrics (E1, E2)
+def test_eval_glue_and_metrics_golden(mdm, smpl):
+    """HIP sample_once_proj / get_gt / metrics against the reference's own functions (tests/golden/eval.npz):
+    50-step schedule, injected noise, correction hook at t = 0."""
+    from interdiff_amd import eval as ev
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    z = fx.golden('eval.npz')
+    T, B, P = fx.EVAL_SHAPE
+    past = fx.PAST
+    batch, noise, stream = fx.eval_inputs()
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=fx.EVAL_STEPS)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', fx.EVAL_STEPS)
+    bd = dev(batch)
+    obj, body, verts, jtr, pelvis = ev.sample_once_proj(model, diff, corr, bd, past, noise=noise.to(DEV),
+                                                        step_noise=lambda i, x: stream.next_like(x).to(DEV))
+    sub = fx.vertex_subset()
+    close(obj[..., 3:], z['obj'][..., 3:], 1e-4, 'obj translation')
+    close(R.axis_angle_to_matrix(obj[..., :3].cpu()), R.axis_angle_to_matrix(torch.from_numpy(z['obj'][..., :3])), 1e-4, 'obj rotation')
+    close(body[..., 66:], z['body'][..., 66:], 1e-4, 'hands + translation')
+    close(R.axis_angle_to_matrix(body[..., :66].reshape(T, B, 22, 3).cpu()),
+          R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3)), 1e-4, 'body rotations')
+    close(verts[:, :, sub], z['verts'], 1e-4, 'verts')
+    close(jtr, z['jtr'], 1e-4, 'jtr')
+    close(pelvis, z['pelvis'], 1e-4, 'pelvis')
+    obj_gt, jtr_gt, body_gt, faces = ev.get_gt(bd, smpl)
+    close(jtr_gt, z['jtr_gt'], 1e-5, 'jtr_gt')
+    close(obj_gt[..., 3:], z['obj_gt'][..., 3:], 1e-6, 'obj_gt')
+    assert torch.equal(faces.cpu(), fx.smpl_model()['faces'].long())
+    met = ev.Metrics(corr)
+    m = met(obj[past:], jtr[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces, bd['obj_points'])
+    for k in m:
+        close(m[k], z['m_' + k], 2e-4 if k != 'penetrate' else 2e-2, 'metric %s vs reference golden' % k)
+    # the metric kernel alone, on the reference's own sample: tight
+    full = lambda k: torch.from_numpy(z[k]).to(DEV)
+    m2 = met(full('obj')[past:], full('jtr')[past:], full('body')[past:], full('obj_gt')[past:], full('jtr_gt')[past:],
+             full('body_gt')[past:], verts[past:], faces, bd['obj_points'])
+    for k in m2:
+        close(m2[k], z['m_' + k], 1e-5 if k != 'penetrate' else 2e-2, 'metric kernel %s' % k)
+    # min over diverse samples + smooth (host logic)
+    o2 = ev.smooth(obj.clone(), body.clone(), verts.clone(), jtr.clone(), pelvis.clone(), T - past)[0]
+    ref = obj.clone()
+    ref[-(T - past):] = ref[-(T - past):] + (2 * obj[-(T - past) - 1] - obj[-(T - past) - 2] - obj[-(T - past)])
+    assert torch.equal(o2, ref)

@@ -142,3 +142,33 @@ def test_full_1000_step_loop():
                               dump_steps=fx.LOOP_DUMPS)
     for s, d in zip(fx.LOOP_DUMPS, dumps):
         close(d, z['dump_%d' % s], 2e-4, 'loop index %d' % s)
+
+
+def test_eval_glue_and_metrics():
+    """Oracle sample_once_proj / get_gt / metrics vs the reference's own functions (eval_smpl_short.py:24-81,133-250)
+    on a tiny clip with a 50-step schedule (the hook fires once, at t = 0)."""
+    z = fx.golden('eval.npz')
+    batch, noise, stream = fx.eval_inputs()
+    T, B, P = fx.EVAL_SHAPE
+    past, sd, smpl = fx.PAST, fx.mdm_weights(), fx.smpl_model()
+    y = _y(fx.model_kwargs_y(dict(batch, noise=noise), T))
+    sample = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond']), tuple(noise.shape),
+                               odf.make_schedule(fx.EVAL_STEPS), noise.clone(), lambda i, x: stream.next_like(x), {'y': y},
+                               denoised_fn=lambda x, t, kw: ocor.denoised_fn(x, t, kw, past_len=past))
+    obj, body, verts, jtr = ocor.finalize(sample, batch['gt'], batch['hand_pose'], batch['beta'], smpl, past)
+    sub = fx.vertex_subset()
+    close(obj[..., 3:], z['obj'][..., 3:], 1e-4, 'obj translation')
+    close(R.axis_angle_to_matrix(obj[..., :3]), R.axis_angle_to_matrix(torch.from_numpy(z['obj'][..., :3])), 1e-4, 'obj rotation')
+    close(body[..., 66:], z['body'][..., 66:], 1e-4, 'hands + translation')
+    close(verts[:, :, sub], z['verts'], 1e-4, 'verts')
+    close(jtr, z['jtr'], 1e-4, 'jtr')
+    obj_gt, jtr_gt, body_gt = ocor.ground_truth(batch['gt'], batch['hand_pose'], batch['beta'], smpl)
+    close(jtr_gt, z['jtr_gt'], 1e-5, 'jtr_gt')
+    close(body_gt[..., 66:], z['body_gt'][..., 66:], 1e-5, 'body_gt')
+    # metrics on the REFERENCE's own sample (isolates the metric arithmetic from sampling noise)
+    full = lambda k: torch.from_numpy(z[k])
+    verts_ref = ocor.finalize(sample, batch['gt'], batch['hand_pose'], batch['beta'], smpl, past)[2]
+    m = ocor.metrics(full('obj')[past:], full('jtr')[past:], full('body')[past:], full('obj_gt')[past:], full('jtr_gt')[past:],
+                     full('body_gt')[past:], verts_ref[past:], smpl['faces'], batch['obj_points'])
+    for k, v in m.items():
+        close(v, z['m_' + k], 1e-4 if k != 'penetrate' else 2e-2, 'metric ' + k)

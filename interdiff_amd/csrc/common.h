@@ -30,16 +30,32 @@ extern int g_idf_tune[];          // denoiser.hip: tile-configuration overrides 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// ---- wave-wide reductions (all 64 lanes participate, result in every lane) -------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions on the DPP path (no LDS-crossbar permutes) --------------------------------------
+// row16_*: all-reduce inside each 16-lane DPP row by rotations (row_ror:8,4,2,1); every lane of the row gets the result.
+#define IDF_DPP_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += IDF_DPP_ROR(v, 8);
+    v += IDF_DPP_ROR(v, 4);
+    v += IDF_DPP_ROR(v, 2);
+    v += IDF_DPP_ROR(v, 1);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, IDF_DPP_ROR(v, 8));
+    v = fmaxf(v, IDF_DPP_ROR(v, 4));
+    v = fmaxf(v, IDF_DPP_ROR(v, 2));
+    v = fmaxf(v, IDF_DPP_ROR(v, 1));
     return v;
+}
+#define IDF_LANE(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l))
+// wave-wide (all 64 lanes participate, result in every lane): four row results combined through scalar registers
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (IDF_LANE(v, 0) + IDF_LANE(v, 16)) + (IDF_LANE(v, 32) + IDF_LANE(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(IDF_LANE(v, 0), IDF_LANE(v, 16)), fmaxf(IDF_LANE(v, 32), IDF_LANE(v, 48)));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -60,4 +76,43 @@ __device__ __forceinline__ void ln_row_stats(const float4 v, float &mean, float 
     const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
     const float var = wave_sum(a * a + b * b + c * c + d * d) * (1.0f / 256.0f);
     rstd = 1.0f / sqrtf(var + 1e-5f);
+}
+
+// LayerNorm of 256-wide rows held by 16-lane groups: lane l16 of the group owns the four float4 chunks
+// {l16, 16+l16, 32+l16, 48+l16} of its row (so that each load/store instruction of a group covers 256 contiguous bytes).
+struct Row16 {
+    float4 c[4];
+};
+__device__ __forceinline__ void ln_row16(Row16 &r, const float *__restrict__ w, const float *__restrict__ b, int l16) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
+    const float mean = row16_sum(s) * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 g = *reinterpret_cast<const float4 *>(w + (i * 16 + l16) * 4), be = *reinterpret_cast<const float4 *>(b + (i * 16 + l16) * 4);
+        r.c[i].x = (r.c[i].x - mean) * rstd * g.x + be.x;
+        r.c[i].y = (r.c[i].y - mean) * rstd * g.y + be.y;
+        r.c[i].z = (r.c[i].z - mean) * rstd * g.z + be.z;
+        r.c[i].w = (r.c[i].w - mean) * rstd * g.w + be.w;
+    }
+}
+__device__ __forceinline__ void row16_load(Row16 &r, const float *__restrict__ row, int l16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * 16 + l16) * 4);
+}
+__device__ __forceinline__ void row16_store(const Row16 &r, float *__restrict__ row, int l16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(row + (i * 16 + l16) * 4) = r.c[i];
+}
+__device__ __forceinline__ void row16_zero(Row16 &r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }

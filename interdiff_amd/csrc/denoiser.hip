@@ -87,35 +87,55 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     float *Ps = coef + TR * 4;                    // [TR][PS]
 
     const int b = blockIdx.y, t0 = blockIdx.x * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4, c4 = lane * 4;
+    const int li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
+    // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
+    const int rown = wave * 4 + kq;
+    const float *Gb = G + (size_t)b * HM * D, *g0b = g0 + b * HM, *VWTb = VWT + (size_t)b * D * HMP;
+
+    float4 gv[4][3];                              // folded-score operand fragments, prefetched one phase ahead
+    auto prefetch_g = [&]() {
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int m = ct * 16 + li;
+                gv[ss][ct] = m < HM ? ld4(Gb + (size_t)m * D + 16 * (wave * 4 + ss) + 4 * kq) : zero4();
+            }
+    };
 
     if constexpr (QAN) {
-        const float4 gw = lnp_w ? ld4(lnp_w + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 gb = lnp_w ? ld4(lnp_b + c4) : zero4();
-        for (int r = wave; r < TR + 2; r += 4) {
-            const int t = t0 - 1 + r;
-            float4 v = zero4();
-            if (t >= 0 && t < T) {
-                v = ld4(u_in + (rowbase + t) * D + c4);
-                if (lnp_w) v = ln_apply(v, gw, gb);
-            }
-            *reinterpret_cast<float4 *>(xs + r * RS + c4) = v;
+        // rows t0-1 .. t0+14 by all groups, halo rows t0+15, t0+16 by the first two groups of wave 0
+        const int ta = t0 - 1 + rown, tb = t0 + 15 + kq;
+        const bool va = ta >= 0 && ta < T, vb = wave == 0 && kq < 2 && tb < T;
+        Row16 ra, rb;
+        row16_zero(ra);
+        row16_zero(rb);
+        if (va) row16_load(ra, u_in + (rowbase + ta) * D, li);
+        if (vb) row16_load(rb, u_in + (rowbase + tb) * D, li);
+        float4 q[4][3];
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q[ss][j] = li < NQ ? ld4(Qc + (li * 3 + j) * D + 16 * (wave * 4 + ss) + 4 * kq) : zero4();
+        if (lnp_w) {
+            if (va) ln_row16(ra, lnp_w, lnp_b, li);
+            if (vb) ln_row16(rb, lnp_w, lnp_b, li);
         }
+        row16_store(ra, xs + rown * RS, li);
+        if (wave == 0 && kq < 2) row16_store(rb, xs + (16 + kq) * RS, li);
         __syncthreads();
         // logits: three 16x16 tiles (j = 0,1,2), each wave contracts a 64-wide slice of K
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
             const int koff = 16 * (wave * 4 + ss) + 4 * kq;
-            float4 a[3], q[3];
+            float4 a[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                a[j] = ld4(xs + (li + j) * RS + koff);
-                q[j] = li < NQ ? ld4(Qc + (li * 3 + j) * D + koff) : zero4();
-            }
-            mma_rounds<3>(acc, a, q);
+            for (int j = 0; j < 3; ++j) a[j] = ld4(xs + (li + j) * RS + koff);
+            mma_rounds<3>(acc, a, q[ss]);
         }
+        prefetch_g();
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 if (tg <= 0) l[0] = -FLT_MAX;
                 if (tg + 1 >= T) l[2] = -FLT_MAX;
                 const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
-                const float e0 = expf(l[0] - mx), e1 = expf(l[1] - mx), e2 = expf(l[2] - mx);
+                const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
                 const float w = wk[n] / (e0 + e1 + e2);
                 float *o = cw + (n * TR + t) * 4;
                 o[0] = w * e0;
@@ -151,41 +171,46 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             coef[tid] = c;
         }
         __syncthreads();
-    }
-    {   // u1 -> x1 = LN1(u1)
-        const float4 gw = ld4(ln1_w + c4), gb = ld4(ln1_b + c4);
-        for (int r = wave; r < TR; r += 4) {
-            float4 u1;
-            if constexpr (QAN) {
-                const float4 xm = ld4(xs + r * RS + c4), xc = ld4(xs + (r + 1) * RS + c4), xp = ld4(xs + (r + 2) * RS + c4);
-                const float c0 = coef[r * 4], c1 = coef[r * 4 + 1], c2 = coef[r * 4 + 2];
-                u1.x = xc.x + (c0 * xm.x + c1 * xc.x + c2 * xp.x);
-                u1.y = xc.y + (c0 * xm.y + c1 * xc.y + c2 * xp.y);
-                u1.z = xc.z + (c0 * xm.z + c1 * xc.z + c2 * xp.z);
-                u1.w = xc.w + (c0 * xm.w + c1 * xc.w + c2 * xp.w);
-            } else {
-                const int t = t0 + r;
-                u1 = t < T ? ld4(u_in + (rowbase + t) * D + c4) : zero4();
+        {   // u1 = x_t + sum_j c_j x_{t+j-1} ;  x1 = LN1(u1)
+            Row16 xm, xc, xp;
+            row16_load(xm, xs + rown * RS, li);
+            row16_load(xc, xs + (rown + 1) * RS, li);
+            row16_load(xp, xs + (rown + 2) * RS, li);
+            const float c0 = coef[rown * 4], c1 = coef[rown * 4 + 1], c2 = coef[rown * 4 + 2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xc.c[i].x = xc.c[i].x + (c0 * xm.c[i].x + c1 * xc.c[i].x + c2 * xp.c[i].x);
+                xc.c[i].y = xc.c[i].y + (c0 * xm.c[i].y + c1 * xc.c[i].y + c2 * xp.c[i].y);
+                xc.c[i].z = xc.c[i].z + (c0 * xm.c[i].z + c1 * xc.c[i].z + c2 * xp.c[i].z);
+                xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
             }
-            *reinterpret_cast<float4 *>(x1s + r * RS + c4) = ln_apply(u1, gw, gb);
+            ln_row16(xc, ln1_w, ln1_b, li);
+            row16_store(xc, x1s + rown * RS, li);
         }
+    } else {
+        const int t = t0 + rown;
+        Row16 ra;
+        row16_zero(ra);
+        if (t < T) row16_load(ra, u_in + (rowbase + t) * D, li);
+        prefetch_g();
+        ln_row16(ra, ln1_w, ln1_b, li);
+        row16_store(ra, x1s + rown * RS, li);
     }
     __syncthreads();
-    const float *Gb = G + (size_t)b * HM * D, *g0b = g0 + b * HM, *VWTb = VWT + (size_t)b * D * HMP;
+    float4 vw[HMP / 16][4];
     {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
-            const int koff = 16 * (wave * 4 + ss) + 4 * kq;
-            const float4 av = ld4(x1s + li * RS + koff);
-            float4 a[3] = {av, av, av}, gv[3];
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const int m = ct * 16 + li;
-                gv[ct] = m < HM ? ld4(Gb + (size_t)m * D + koff) : zero4();
-            }
-            mma_rounds<3>(acc, a, gv);
+            const float4 av = ld4(x1s + li * RS + 16 * (wave * 4 + ss) + 4 * kq);
+            float4 a[3] = {av, av, av};
+            mma_rounds<3>(acc, a, gv[ss]);
         }
+        // operand fragments of the next contraction (P.VW) fly while the softmax runs
+#pragma unroll
+        for (int s = 0; s < HMP / 16; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vw[s][c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + 16 * s + 4 * kq);
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             float sum = 0.f;
 #pragma unroll
             for (int m = 0; m < MEM; ++m) {
-                sc[m] = expf(sc[m] - mx);
+                sc[m] = __expf(sc[m] - mx);
                 sum += sc[m];
             }
             const float inv = 1.0f / sum;
@@ -222,12 +247,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < HMP / 16; ++s) {
-            const int koff = 16 * s + 4 * kq;
-            const float4 pv = ld4(Ps + li * PS + koff);
-            float4 a[4] = {pv, pv, pv, pv}, vw[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) vw[c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + koff);
-            mma_rounds<4>(acc, a, vw);
+            const float4 pv = ld4(Ps + li * PS + 16 * s + 4 * kq);
+            float4 a[4] = {pv, pv, pv, pv};
+            mma_rounds<4>(acc, a, vw[s]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -239,13 +261,11 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     }
     __syncthreads();
     {
-        const float4 gw = ld4(ln2_w + c4), gb = ld4(ln2_b + c4);
-        for (int r = wave; r < TR; r += 4) {
-            const int t = t0 + r;
-            if (t >= T) break;                                       // wave-uniform
-            const float4 v = ln_apply(ld4(x1s + r * RS + c4), gw, gb);
-            *reinterpret_cast<float4 *>(x2_out + (rowbase + t) * D + c4) = v;
-        }
+        const int t = t0 + rown;
+        Row16 r;
+        row16_load(r, x1s + rown * RS, li);
+        ln_row16(r, ln2_w, ln2_b, li);
+        if (t < T) row16_store(r, x2_out + (rowbase + t) * D, li);
     }
 }
 

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                                                           const int32_t *__restrict__ markers_idx, int M, int B,
                                                           float *__restrict__ markers_out, float *__restrict__ loss_sum,
                                                           float *__restrict__ min_dist, int32_t *__restrict__ label,
-                                                          float *__restrict__ o2h_out /* nullable [N][P] */) {
+                                                          float *__restrict__ o2h_out /* nullable [N][P] */,
+                                                          int64_t nn_from /* frames below it skip the NN scan */) {
     extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V rounded up to 4] then markers [MAXM]
     const int V4 = (V + 3) & ~3;
     float4 *ms = vs + V4;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     const int b = (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
     for (int v = tid; v < V4; v += CT)
-        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], 0.f) : make_float4(3e18f, 3e18f, 3e18f, 0.f);
+        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], __int_as_float(v)) : make_float4(3e18f, 3e18f, 3e18f, 0.f);
     if (tid < MAXM) flags[tid] = 0;
     __syncthreads();
     if (tid < M) {
@@ -142,7 +143,10 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         bi[2 * k] = bi[2 * k + 1] = 0;
     }
     __syncthreads();
-    {
+    // the signed object->human distance is only consumed on future frames (eval_smpl_short.py:121 slices
+    // loss_dist_o[past_len:]); past frames only need the marker distances below
+    const bool do_nn = n >= nn_from;
+    if (do_nn) {
 #pragma clang fp contract(off)
         for (int v0 = 0; v0 < V4; v0 += 4) {
 #pragma unroll
@@ -153,8 +157,9 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                 for (int k = 0; k < QP / 2; ++k) {
                     const v2f dx = QX[k] - PX, dy = QY[k] - PY, dz = QZ[k] - PZ;
                     const v2f d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2.x < best[k].x) { best[k].x = d2.x; bi[2 * k] = v0 + u; }
-                    if (d2.y < best[k].y) { best[k].y = d2.y; bi[2 * k + 1] = v0 + u; }
+                    // the vertex id rides in .w of the LDS record (one 16-B broadcast read per vertex)
+                    if (d2.x < best[k].x) { best[k].x = d2.x; bi[2 * k] = __float_as_int(p.w); }
+                    if (d2.y < best[k].y) { best[k].y = d2.y; bi[2 * k + 1] = __float_as_int(p.w); }
                 }
             }
         }
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     for (int k = 0; k < QP; ++k) {
         const int i = tid + CT * k;
         if (i >= P) continue;
+        if (do_nn) {
         // normal of the nearest vertex (data/tools.py:4-40 restricted to one vertex), from LDS
         const int v = bi[k];
         float3 acc = make_float3(0.f, 0.f, 0.f);
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         const float o2h = d * (dt > 0.f ? 1.f : (dt < 0.f ? -1.f : 0.f));
         if (o2h_out) o2h_out[(size_t)n * P + i] = o2h;
         if (o2h < 0.f) loss += fabsf(o2h) * 20.0f;                      // eval_smpl_short.py:113-119
+        }
         for (int m = 0; m < M; ++m) {
             const float4 mk = ms[m];
             const float dx = mk.x - qx[k], dy = mk.y - qy[k], dz = mk.z - qz[k];
@@ -317,7 +324,7 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
     idf_prof_mark(IDF_K_CORR_CONTACT, s);
     hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, w.verts, V, obj_points, P, w.objR, w.objT, c->faces,
                        c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label,
-                       (float *)nullptr);
+                       (float *)nullptr, (int64_t)c->past_len * B);
     uint8_t *cond = condition ? condition : w.condition;
     int32_t *cont = contact ? contact : w.contact;
     idf_prof_mark(IDF_K_CORR_REDUCE, s);
@@ -462,7 +469,7 @@ extern "C" int interdiff_metrics(const idf_correction_ctx *c, const float *obj_p
     idf_prof_mark(IDF_K_OTHER, s);
     hipLaunchKernelGGL(metrics_prepare_kernel, dim3((unsigned)idf_cdiv(N, 256)), dim3(256), 0, s, obj_pred, N, w.objR, w.objT);
     hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, w.objR, w.objT, c->faces,
-                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h);
+                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h, (int64_t)0);
     hipLaunchKernelGGL(metrics_reduce_kernel, dim3(B), dim3(256), 0, s, obj_pred, jtr, body_trans, obj_gt, jtr_gt, body_trans_gt, w.o2h, B,
                        T, J, P, out6);
     idf_prof_mark(-1, s);

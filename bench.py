@@ -66,16 +66,16 @@ def build_world(dev, rank):
     return model, corr, bt, y, (sd, smpl_np, osd)
 
 
-def run_steps(diff, model, corr, bt, y, n_steps, seed):
+def run_steps(diff, model, corr, bt, y, n_steps, seed, use_graph=True):
     return diff.p_sample_loop(model, tuple(bt['noise'].shape), noise=bt['noise'], clip_denoised=False,
-                              model_kwargs={'y': y}, denoised_fn=corr, seed=seed, n_steps=n_steps)
+                              model_kwargs={'y': y}, denoised_fn=corr, seed=seed, n_steps=n_steps, use_graph=use_graph)
 
 
 def kernel_profile(diff, model, corr, bt, y, n_steps=30):
     """Second, instrumented pass: HIP events around every launch (on the launch stream) -> ms per kernel kind."""
     lib = _lib.load()
     _lib.check(lib.interdiff_profile_begin(200000))
-    run_steps(diff, model, corr, bt, y, n_steps, seed=1)
+    run_steps(diff, model, corr, bt, y, n_steps, seed=1, use_graph=False)       # eager route: events between launches
     x = bt['noise'].clone()
     corr.apply(x, 500, y)                                   # one correction call so its kernels are sampled too
     ms = (C.c_double * len(_lib.KERNEL_KINDS))()
@@ -165,7 +165,7 @@ def main():
     idist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    model._mem_key = None                                   # the once-per-sample memory folding is inside the clock
+    # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
     out = run_steps(diff, model, corr, bt, y, K, seed=233)
     torch.cuda.synchronize()
     idist.barrier()

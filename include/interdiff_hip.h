@@ -167,6 +167,14 @@ int interdiff_posterior_step(float *x, const float *x0, const float *noise, int6
                              float c1, float c2, float sigma, uint64_t seed, uint64_t step_index,
                              void *stream);
 int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream);
+/* Graph-replayable form of the same update: all per-step scalars live in HBM, so one captured hipGraph of
+ * [interdiff_mdm_forward -> interdiff_posterior_step_dev -> interdiff_sampler_advance] serves every plain step.
+ *   state int64[3] = {t (current timestep), loop index (noise counter), seed};
+ *   table  f32[steps][4] = {c1[t], c2[t], sigma[t] (0 at t == 0), t/1000};
+ *   mask/gt may be NULL (x0 already inpainted).  advance: t -= 1, loop index += 1, ts[b] = max(t, 0). */
+int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
+                                 const float *table, const int64_t *state, void *stream);
+int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,

@@ -68,6 +68,10 @@ class HipCorrection:
             self.debug.update(condition=dbg[0], contact=dbg[1], distance=dbg[2], loss=dbg[3])
         return x
 
+    def is_active(self, t0):
+        """Host-side gate (eval_smpl_short.py:85) -- lets the sampler replay its captured plain-step graph otherwise."""
+        return correction_gate(int(t0))
+
     def __call__(self, x, t, model_kwargs):
         t0 = getattr(t, 'host_value', None)
         if t0 is None:

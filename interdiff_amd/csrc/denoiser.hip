@@ -315,20 +315,21 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
             for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = acc[rt][r] * 0.125f;
     }
     __syncthreads();
-    for (int i = wave * 8; i < wave * 8 + 8; ++i) {
-        float *row = Ss + i * SS;
-        float mx = -FLT_MAX;
-        for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < T; j += 64) {
-            const float e = expf(row[j] - mx);
-            row[j] = e;
-            sum += e;
+    {   // row softmax: one 16-lane group per row, 16 rows per sweep; lane l16 owns columns l16, 16+l16, ...
+        for (int i = wave * 4 + kq; i < 32; i += 16) {
+            float *row = Ss + i * SS;
+            float mx = -FLT_MAX;
+            for (int j = li; j < T; j += 16) mx = fmaxf(mx, row[j]);
+            mx = row16_max(mx);
+            float sum = 0.f;
+            for (int j = li; j < T; j += 16) {
+                const float e = __expf(row[j] - mx);
+                row[j] = e;
+                sum += e;
+            }
+            const float inv = 1.0f / row16_sum(sum);
+            for (int j = li; j < TP; j += 16) row[j] = j < T ? row[j] * inv : 0.f;
         }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int j = lane; j < TP; j += 64) row[j] = j < T ? row[j] * inv : 0.f;
     }
     __syncthreads();
     {   // ctx = P V: wave w owns the 16 head-dim columns [16w, 16w+16) for both query tiles
@@ -433,7 +434,7 @@ void run_gemm(int cfg, hipStream_t s, const Args &g) {
     default: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
     }
 }
-constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 9;
+constexpr int CFG_FFN1 = 6, CFG_FFN2 = 6, CFG_OUTPROJ = 6, CFG_QKV = 9, CFG_HEADS = 9;
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 
 }  // namespace

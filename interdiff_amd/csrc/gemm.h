@@ -38,6 +38,16 @@ struct Args {
     long long *probe;               // tools/gemm_probe.hip only: per-workgroup s_memtime stamps (null on the product path)
 };
 
+// XCD-aware tile order (workgroup b is dispatched to XCD b % 8, each XCD has its own L2): remap the linear
+// workgroup id so that one XCD works through CONSECUTIVE logical tiles, with the N tiles of an M tile adjacent --
+// the A rows of an M tile are then fetched into ONE L2 instead of up to eight (speed only; any order is correct).
+__device__ __forceinline__ void xcd_tile(int ntn, int &mt, int &nt, int &wg) {
+    const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    mt = wg / ntn;
+    nt = wg - mt * ntn;
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -129,7 +139,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     float *As = smem, *Bs = smem + A_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt_, nt_, wg;
+    xcd_tile((g.N + BN - 1) / BN, mt_, nt_, wg);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, kq = lane >> 4;
     const int K = g.K, M = g.M, N = g.N;
@@ -191,7 +203,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
         }
     };
 
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
     load_b(0);
     if constexpr (APRO == A_LN) {
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
                 v.w = (v.w - mean) * rstd * gw.w + gb.w;
             }
             *reinterpret_cast<float4 *>(As + lane * AQ + row * 4) = v;
-            if (g.xn_out && blockIdx.y == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * KLN + lane * 4) = v;
+            if (g.xn_out && nt_ == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * KLN + lane * 4) = v;
         }
     } else {
         load_a(0);
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
 
 template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
 inline void launch(hipStream_t s, const Args &g) {
-    dim3 grid((unsigned)idf_cdiv(g.M, BM), (unsigned)idf_cdiv(g.N, BN));
+    dim3 grid((unsigned)(idf_cdiv(g.M, BM) * idf_cdiv(g.N, BN)));
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KC, APRO, EPI>), grid, dim3(WM * WN * 64), 0, s, g);
 }
 
@@ -330,12 +341,13 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mt_, nt_, wg;
+    xcd_tile((g.N + BN - 1) / BN, mt_, nt_, wg);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
     const int ks = wave / NWT, wt = wave % NWT, wm = wt / WN, wn = wt % WN;
     const int li = lane & 15, kq = lane >> 4;
     const int K = g.K, M = g.M, N = g.N;
     const int nk = K / KC;
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
 
     // per-wave DMA descriptors: instruction i = wave + NW*j of the IPC that make up one chunk; lane l of it fills
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
                 v.w = (v.w - mean) * rstd * gw.w + gb.w;
             }
             *reinterpret_cast<float4 *>(Aln + row * RSL + lane * 4) = v;
-            if (g.xn_out && blockIdx.y == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * 256 + lane * 4) = v;
+            if (g.xn_out && nt_ == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * 256 + lane * 4) = v;
         }
     }
     // chunk 0 landed (chunk 1 may still fly); the compiler's own waits for the ordinary loads above can only be stricter
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 
 template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI>
 inline void launch_glds(hipStream_t s, const Args &g) {
-    dim3 grid((unsigned)idf_cdiv(g.M, BM), (unsigned)idf_cdiv(g.N, BN));
+    dim3 grid((unsigned)(idf_cdiv(g.M, BM) * idf_cdiv(g.N, BN)));
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI>), grid, dim3(WM * WN * KS * 64), 0, s, g);
 }
 

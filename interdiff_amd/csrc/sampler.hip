@@ -78,6 +78,50 @@ __global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int
     }
 }
 
+// Device-parameterised step update: every per-step scalar comes from HBM (coefficient table row of the current
+// timestep, loop index and seed from the sampler state), so ONE captured hipGraph of [denoiser forward -> this ->
+// advance] replays for every plain step of the loop.  state = {t, loop_index, seed}; table[t] = {c1, c2, sigma, t/1000}.
+__global__ __launch_bounds__(256) void posterior_dev_kernel(float *__restrict__ x, const float *__restrict__ x0,
+                                                            const float *__restrict__ gt, const uint8_t *__restrict__ mask,
+                                                            int64_t n, const float *__restrict__ table,
+                                                            const int64_t *__restrict__ state) {
+    const int64_t t = state[0];
+    const uint64_t it = (uint64_t)state[1], seed = (uint64_t)state[2];
+    const float c1 = table[t * 4], c2 = table[t * 4 + 1], sigma = table[t * 4 + 2];
+    const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+        const int64_t i = g * 4;
+        const float4 e = randn4(seed, it, (uint64_t)g);
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+        if (i + 3 < n) {
+            float4 xv = *reinterpret_cast<float4 *>(x + i);
+            float4 pv = *reinterpret_cast<const float4 *>(x0 + i);
+            if (mask) {
+                const uchar4 m = *reinterpret_cast<const uchar4 *>(mask + i);
+                const float4 gv = *reinterpret_cast<const float4 *>(gt + i);
+                pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
+            }
+            xv.x = c1 * pv.x + c2 * xv.x + sigma * ev[0];
+            xv.y = c1 * pv.y + c2 * xv.y + sigma * ev[1];
+            xv.z = c1 * pv.z + c2 * xv.z + sigma * ev[2];
+            xv.w = c1 * pv.w + c2 * xv.w + sigma * ev[3];
+            *reinterpret_cast<float4 *>(x + i) = xv;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; ++k) {
+                const float p = (mask && mask[i + k]) ? gt[i + k] : x0[i + k];
+                x[i + k] = c1 * p + c2 * x[i + k] + sigma * ev[k];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void advance_kernel(int64_t *__restrict__ state, int64_t *__restrict__ ts, int B) {
+    const int64_t t = state[0] - 1;
+    __syncthreads();                                        // every thread has read the old value (single workgroup)
+    for (int b = threadIdx.x; b < B; b += 256) ts[b] = t < 0 ? 0 : t;
+    if (threadIdx.x == 0) { state[0] = t; state[1] += 1; }
+}
+
 inline unsigned grid_for(int64_t work) {
     int64_t b = idf_cdiv(work, 256);
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -114,6 +158,27 @@ extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *
     return IDF_OK;
 }
 
+extern "C" int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
+                                            const float *table, const int64_t *state, void *stream) {
+    if (!x || !x0 || !table || !state || n < 0 || (mask && !gt)) return IDF_E_INVAL;
+    if (n == 0) return IDF_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(gt)) & 15) return IDF_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(mask) & 3) return IDF_E_INVAL;
+    idf_prof_mark(IDF_K_POSTERIOR, idf_stream(stream));
+    hipLaunchKernelGGL(posterior_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, idf_stream(stream), x, x0, gt, mask, n, table,
+                       state);
+    idf_prof_mark(-1, idf_stream(stream));
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
+extern "C" int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stream) {
+    if (!state || !ts || B <= 0) return IDF_E_INVAL;
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, idf_stream(stream), state, ts, B);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
 extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream) {
     if (!out || n < 0) return IDF_E_INVAL;
     if (n == 0) return IDF_OK;
@@ -122,5 +187,5 @@ extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t st
     return IDF_OK;
 }
 
-extern "C" int interdiff_abi_version(void) { return 2; }
-extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 2"; }
+extern "C" int interdiff_abi_version(void) { return 3; }
+extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 3"; }

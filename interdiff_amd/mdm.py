@@ -129,6 +129,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
 
 class MDM:
     """Drop-in for the reference denoiser at the sampler seam: ``MDM(state_dict)(x, ts, y={'cond': ...})``."""
+    graph_safe = True        # forward() enqueues kernels only (no allocation / sync once warmed up): hipGraph-capturable
 
     def __init__(self, state_dict, device='cuda', n_steps=1000, rotary=ROTARY_DEFAULT):
         self.lib = _lib.load()
@@ -158,7 +159,10 @@ class MDM:
             raise ValueError('cond must be [%d,B,%d]' % (MEM, D))
         B = cond.shape[1]
         cond = cond.contiguous()
-        memctx = torch.empty(self.lib.interdiff_mdm_memctx_floats(B), dtype=torch.float32, device=self.device)
+        need = self.lib.interdiff_mdm_memctx_floats(B)
+        # the buffer is reused when the size matches: its address may be baked into a captured hipGraph
+        memctx = self._memctx if (self._memctx is not None and self._memctx.numel() == need) else \
+            torch.empty(need, dtype=torch.float32, device=self.device)
         ws = self._workspace(B, 16)
         _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                          _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),

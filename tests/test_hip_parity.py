@@ -278,3 +278,28 @@ def test_eval_glue_and_metrics_golden(mdm, smpl):
     ref = obj.clone()
     ref[-(T - past):] = ref[-(T - past):] + (2 * obj[-(T - past) - 1] - obj[-(T - past) - 2] - obj[-(T - past)])
     assert torch.equal(o2, ref)
+
+
+# ------------------------------------------------------------------------------------------ hipGraph route of the sampler
+def test_graph_replay_equals_eager(smpl):
+    """The captured plain-step graph (device-side scalars) and the eager loop produce bit-identical samples, with and
+    without the correction hook (50-step schedule: the hook fires at t = 0), twice in a row (graph reuse)."""
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P = fx.EVAL_SHAPE
+    batch, noise, _ = fx.eval_inputs()
+    y = dev(fx.model_kwargs_y(dict(batch, noise=noise), T))
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=fx.EVAL_STEPS)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', fx.EVAL_STEPS)
+    nz = noise.to(DEV)
+    for hook in (None, corr):
+        eager = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook,
+                                   seed=77, use_graph=False)
+        for rep in range(2):
+            graph = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook,
+                                       seed=77)
+            assert torch.equal(eager, graph), 'graph route differs (hook=%s, rep %d): %g' % (hook is not None, rep, (eager - graph).abs().max())
+        other = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook, seed=78)
+        assert not torch.equal(other, eager)
+    assert len(diff._graphs) == 1

@@ -148,10 +148,17 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     const bool do_nn = n >= nn_from;
     if (do_nn) {
 #pragma clang fp contract(off)
+        // software pipeline: the LDS records of the NEXT four vertices are in flight while the current four are scored
+        float4 cur[4], nxt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = vs[u];
         for (int v0 = 0; v0 < V4; v0 += 4) {
+            const int vn = v0 + 4 < V4 ? v0 + 4 : v0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = vs[vn + u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 p = vs[v0 + u];
+                const float4 p = cur[u];
                 const v2f PX = v2f{p.x, p.x}, PY = v2f{p.y, p.y}, PZ = v2f{p.z, p.z};
 #pragma unroll
                 for (int k = 0; k < QP / 2; ++k) {
@@ -162,6 +169,8 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                     if (d2.y < best[k].y) { best[k].y = d2.y; bi[2 * k + 1] = __float_as_int(p.w); }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
         }
     }
     float loss = 0.f, mind = FLT_MAX;
@@ -216,6 +225,28 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     }
     if (tid == 0) { loss_sum[n] = loss_total; min_dist[n] = red[0]; }
     if (tid < M) label[(size_t)n * M + tid] = flags[tid];
+}
+
+// (An fp32-MFMA "filter" variant of this scan -- g~ = |p|^2 - 2 q.p on v_mfma_f32_16x16x4, exact re-evaluation of
+// the vertices inside the error band -- was built, verified bit-identical and measured on MI355X: its two sweeps run
+// at 40% of the matrix pipe next to the VALU work that reads every product, 6.1 ms vs 5.0 ms per call for this kernel.
+// The fp32 MFMA issues at the fp32 VALU rate on gfx950, so the filter cannot win)
+int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const float *obj_points, int P, const float *objR,
+                   const float *objT, const idf_correction_ctx *c, int B, float *markers, float *loss_sum, float *min_dist,
+                   int32_t *label, float *o2h, int64_t nn_from) {
+    const int M = c->n_markers;
+    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
+    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 4096) != hipSuccess)
+            return IDF_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
+                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
+    return IDF_OK;
 }
 
 // ---- K5: per-clip decisions (eval_smpl_short.py:119-125) ---------------------------------------------
@@ -313,18 +344,10 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
                        w.trans, w.objR, w.objT, w.gt_angles, w.gt_trans);
     int rc = interdiff_smpl_forward(c->smpl, w.pose, beta, w.trans, N, w.verts, w.jtr, nullptr, w.smpl_ws, w.smpl_ws_bytes, stream);
     if (rc) return rc;
-    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
-    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
     idf_prof_mark(IDF_K_CORR_CONTACT, s);
-    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, w.verts, V, obj_points, P, w.objR, w.objT, c->faces,
-                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label,
-                       (float *)nullptr, (int64_t)c->past_len * B);
+    rc = launch_contact(s, N, w.verts, V, obj_points, P, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, nullptr,
+                        (int64_t)c->past_len * B);
+    if (rc) return rc;
     uint8_t *cond = condition ? condition : w.condition;
     int32_t *cont = contact ? contact : w.contact;
     idf_prof_mark(IDF_K_CORR_REDUCE, s);
@@ -462,14 +485,10 @@ extern "C" int interdiff_metrics(const idf_correction_ctx *c, const float *obj_p
     if (ws_bytes < w.total) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const int64_t N = (int64_t)B * T;
-    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
-    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
-        return IDF_E_LAUNCH;
     idf_prof_mark(IDF_K_OTHER, s);
     hipLaunchKernelGGL(metrics_prepare_kernel, dim3((unsigned)idf_cdiv(N, 256)), dim3(256), 0, s, obj_pred, N, w.objR, w.objT);
-    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, w.objR, w.objT, c->faces,
-                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h, (int64_t)0);
+    const int rc = launch_contact(s, N, verts, V, obj_points, P, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h, 0);
+    if (rc) return rc;
     hipLaunchKernelGGL(metrics_reduce_kernel, dim3(B), dim3(256), 0, s, obj_pred, jtr, body_trans, obj_gt, jtr_gt, body_trans_gt, w.o2h, B,
                        T, J, P, out6);
     idf_prof_mark(-1, s);

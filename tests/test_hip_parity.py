@@ -303,3 +303,4 @@ def test_graph_replay_equals_eager(smpl):
         other = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook, seed=78)
         assert not torch.equal(other, eager)
     assert len(diff._graphs) == 1
+

@@ -169,11 +169,12 @@ int interdiff_posterior_step(float *x, const float *x0, const float *noise, int6
 int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream);
 /* Graph-replayable form of the same update: all per-step scalars live in HBM, so one captured hipGraph of
  * [interdiff_mdm_forward -> interdiff_posterior_step_dev -> interdiff_sampler_advance] serves every plain step.
- *   state int64[3] = {t (current timestep), loop index (noise counter), seed};
+ *   state int64[4] = {t (current timestep), loop index (noise counter), seed, arrival counter (zero it once)};
  *   table  f32[steps][4] = {c1[t], c2[t], sigma[t] (0 at t == 0), t/1000};
- *   mask/gt may be NULL (x0 already inpainted).  advance: t -= 1, loop index += 1, ts[b] = max(t, 0). */
+ *   mask/gt may be NULL (x0 already inpainted).  With ts != NULL the launch also advances the state when its last
+ *   workgroup retires: t -= 1, loop index += 1, ts[b] = max(t, 0) for b < B (interdiff_sampler_advance does only that). */
 int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
-                                 const float *table, const int64_t *state, void *stream);
+                                 const float *table, int64_t *state, int64_t *ts, int32_t B, void *stream);
 int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stream);
 
 /* ------------------------------------------------------------------------------------

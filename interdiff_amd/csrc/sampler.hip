@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int
 __global__ __launch_bounds__(256) void posterior_dev_kernel(float *__restrict__ x, const float *__restrict__ x0,
                                                             const float *__restrict__ gt, const uint8_t *__restrict__ mask,
                                                             int64_t n, const float *__restrict__ table,
-                                                            const int64_t *__restrict__ state) {
+                                                            int64_t *__restrict__ state, int64_t *__restrict__ ts, int B) {
     const int64_t t = state[0];
     const uint64_t it = (uint64_t)state[1], seed = (uint64_t)state[2];
     const float c1 = table[t * 4], c2 = table[t * 4 + 1], sigma = table[t * 4 + 2];
@@ -110,6 +110,21 @@ __global__ __launch_bounds__(256) void posterior_dev_kernel(float *__restrict__ 
             for (int k = 0; k < 4 && i + k < n; ++k) {
                 const float p = (mask && mask[i + k]) ? gt[i + k] : x0[i + k];
                 x[i + k] = c1 * p + c2 * x[i + k] + sigma * ev[k];
+            }
+        }
+    }
+    // advance (t -= 1, loop index += 1, ts[b] = max(t, 0)) by the LAST workgroup to arrive: every workgroup has read
+    // the state before it adds itself to the arrival counter, so the update cannot race with a reader of this launch
+    if (ts) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned *arrived = reinterpret_cast<unsigned *>(state + 3);
+            if (atomicAdd(arrived, 1u) == gridDim.x - 1) {
+                *arrived = 0u;
+                const int64_t tn = t - 1;
+                state[0] = tn;
+                state[1] = (int64_t)it + 1;
+                for (int b = 0; b < B; ++b) ts[b] = tn < 0 ? 0 : tn;
             }
         }
     }
@@ -159,14 +174,14 @@ extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *
 }
 
 extern "C" int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
-                                            const float *table, const int64_t *state, void *stream) {
-    if (!x || !x0 || !table || !state || n < 0 || (mask && !gt)) return IDF_E_INVAL;
+                                            const float *table, int64_t *state, int64_t *ts, int32_t B, void *stream) {
+    if (!x || !x0 || !table || !state || n < 0 || (mask && !gt) || (ts && B <= 0)) return IDF_E_INVAL;
     if (n == 0) return IDF_OK;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(gt)) & 15) return IDF_E_INVAL;
     if (reinterpret_cast<uintptr_t>(mask) & 3) return IDF_E_INVAL;
     idf_prof_mark(IDF_K_POSTERIOR, idf_stream(stream));
     hipLaunchKernelGGL(posterior_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, idf_stream(stream), x, x0, gt, mask, n, table,
-                       state);
+                       state, ts, B);
     idf_prof_mark(-1, idf_stream(stream));
     IDF_CHECK_LAUNCH();
     return IDF_OK;
@@ -187,5 +202,5 @@ extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t st
     return IDF_OK;
 }
 
-extern "C" int interdiff_abi_version(void) { return 3; }
-extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 3"; }
+extern "C" int interdiff_abi_version(void) { return 4; }
+extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 4"; }

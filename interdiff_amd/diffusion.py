@@ -95,12 +95,11 @@ class GaussianDiffusion:
         def posterior(x, x0, g, mk, st):
             _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(x), _lib.dptr(x0), _lib.dptr(g, allow_none=True),
                                                         _lib.dptr(mk, allow_none=True), x.numel(), _lib.dptr(table), _lib.dptr(st.state),
-                                                        _lib.stream()), 'posterior_step_dev')
-            _lib.check(lib.interdiff_sampler_advance(_lib.dptr(st.state), _lib.dptr(st.ts), B, _lib.stream()), 'sampler_advance')
+                                                        _lib.dptr(st.ts), B, _lib.stream()), 'posterior_step_dev')
         st = self._graphs.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),
-                                 state=torch.zeros(3, dtype=torch.int64, device=dev), keep=(mu8, gc, cond, model_kwargs))
+                                 state=torch.zeros(4, dtype=torch.int64, device=dev), keep=(mu8, gc, cond, model_kwargs))
             model(st.x, st.ts, out=st.x0, **model_kwargs)            # warm-up: workspaces, kernel attributes
             torch.cuda.synchronize(dev)
             st.graph = torch.cuda.CUDAGraph()
@@ -112,7 +111,7 @@ class GaussianDiffusion:
             self._graphs[key] = st
         t_start = self.num_timesteps - 1
         st.x.copy_(img)
-        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64))
+        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         gate = getattr(denoised_fn, 'is_active', None)

@@ -25,14 +25,15 @@ def main(path):
     kn = 'kernel_name' if 'kernel_name' in cols else 'name'
     cn = 'counter_name' if 'counter_name' in cols else 'counter'
     vn = 'value' if 'value' in cols else 'counter_value'
-    rows = con.execute('select %s, %s, %s, dispatch_id from %s' % (kn, cn, vn, view)).fetchall()
+    rows = con.execute('select %s, %s, %s, dispatch_id, grid_size from %s' % (kn, cn, vn, view)).fetchall()
     per = {}
-    for k, c, v, d in rows:
-        per.setdefault((short(k), c), {}).setdefault(d, 0.0)
-        per[(short(k), c)][d] += float(v)                 # sum over XCD/SE instances of one dispatch
-    print('%-70s %-22s %10s %16s' % ('kernel', 'counter', 'dispatches', 'mean per dispatch'))
+    for k, c, v, d, gsz in rows:
+        key = ('%s grid=%s' % (short(k), gsz), c)          # same kernel at different call sites differs by grid
+        per.setdefault(key, {}).setdefault(d, 0.0)
+        per[key][d] += float(v)                           # sum over XCD/SE instances of one dispatch
+    print('%-84s %-14s %10s %16s' % ('kernel', 'counter', 'dispatches', 'mean per dispatch'))
     for (k, c), dd in sorted(per.items()):
-        print('%-70s %-22s %10d %16.1f' % (k, c, len(dd), sum(dd.values()) / len(dd)))
+        print('%-84s %-14s %10d %16.1f' % (k, c, len(dd), sum(dd.values()) / len(dd)))
 
 
 if __name__ == '__main__':

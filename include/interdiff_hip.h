@@ -138,6 +138,12 @@ typedef struct {
     idf_mdm_layer layer[IDF_MDM_LAYERS];
 } idf_mdm_weights;
 
+/* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
+ * (torch.nn.functional.linear semantics; model/diffusion_smpl.py:73-120 linear1/linear2/out_proj).  epi: 0 bias,
+ * 1 bias + erf-GELU, 2 bias + resid (leading dimension ldc).  cfg 0 = shipped tile configuration.  K % 64 == 0, N % 16 == 0. */
+int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float *bias, const float *resid, float *C,
+                       int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t cfg, void *stream);
+
 /* per-sample constants derived from the memory `cond` (constant over all steps): for every
  * layer and clip the folded cross-attention operands
  *   G   [L][B][40][256]  (scores = x . G^T + g0, 40 = heads*MEM, pre-scaled by 1/sqrt(64))

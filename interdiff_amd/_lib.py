@@ -64,6 +64,7 @@ _SIGS = {
     'interdiff_vertex_normals': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     'interdiff_nn_argmin': (C.c_int, [vp, i32, vp, i32, i64, vp, vp]),
     'interdiff_point2point_signed': (C.c_int, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'interdiff_gemm_f32': (C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'interdiff_mdm_memctx_floats': (sz, [i32]),
     'interdiff_mdm_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),

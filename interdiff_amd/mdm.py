@@ -191,3 +191,19 @@ class MDM:
         return out
 
     __call__ = forward
+
+
+def linear(x, weight, bias=None, residual=None, gelu=False, out=None, cfg=0):
+    """``epi(x @ weight.T + bias)`` on the denoiser's fp32-MFMA GEMM (x [M,K], weight [N,K]); gelu = erf form."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = weight.shape[0]
+    x, weight = x.contiguous(), weight.contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    epi = 1 if gelu else (2 if residual is not None else 0)
+    if gelu and residual is not None:
+        raise ValueError('gelu and residual are separate epilogues')
+    _lib.check(lib.interdiff_gemm_f32(_lib.dptr(x, torch.float32), K, _lib.dptr(weight, torch.float32), _lib.dptr(bias, allow_none=True),
+                                      _lib.dptr(residual, allow_none=True), _lib.dptr(out), N, M, N, K, epi, cfg, _lib.stream()), 'gemm_f32')
+    return out

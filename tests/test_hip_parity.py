@@ -304,3 +304,22 @@ def test_graph_replay_equals_eager(smpl):
         assert not torch.equal(other, eager)
     assert len(diff._graphs) == 1
 
+
+
+# ------------------------------------------------------------------------------------------ the token GEMM as an op
+def test_gemm_f32_epilogues_vs_torch_fp32(lib):
+    """interdiff_gemm_f32 (LDS-DMA pipelined fp32-MFMA GEMM) against torch CPU in float64, every epilogue and every tile
+    configuration, bench shape + ragged M; asymmetric operands catch transposes."""
+    from interdiff_amd.mdm import linear
+    g = torch.Generator().manual_seed(12)
+    for M, N, K in ((1600, 256, 1024), (1600, 1024, 256), (37, 144, 256), (1, 16, 64)):
+        x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ref = x.double() @ w.double().T + b.double()
+        xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+        for cfg in range(0, 10):
+            close(linear(xd, wd, bd, cfg=cfg), ref, 2e-6, 'bias M=%d N=%d K=%d cfg=%d' % (M, N, K, cfg))
+        close(linear(xd, wd, bd, gelu=True), torch.nn.functional.gelu(ref), 2e-6, 'gelu')
+        close(linear(xd, wd, bd, residual=rd), ref + r.double(), 2e-6, 'residual')
+        close(linear(xd, wd), x.double() @ w.double().T, 2e-6, 'no bias')
+    with pytest.raises(RuntimeError):
+        linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0

@@ -301,38 +301,35 @@ inline void launch(hipStream_t s, const Args &g) {
 //    address on the way out (the same involution on both sides);
 //  * an MFMA operand fragment for a 16-wide k-group is still ONE ds_read_b128 (lane (i, kq) reads chunk 4s+kq of
 //    row i: k = 16s + 4kq + {0..3});
-//  * three LDS stages: chunk k+2 is in flight while chunk k is on the MFMAs; the only wait in the loop is a COUNTED
-//    s_waitcnt vmcnt(LPC) (chunk k+1 landed, chunk k+2 still flying) followed by ONE raw s_barrier per chunk;
-//  * KS = 2 splits the 16-wide k-groups of every chunk over two wave sets (2 waves per SIMD at one workgroup per
-//    CU), reduced through LDS at the end -- for the N = 256 GEMMs whose grid cannot fill the chip twice.
+//  * NS (3..6) LDS stages: chunks k+1 .. k+NS-1 are in flight while chunk k is on the MFMAs; the only wait in the loop
+//    is a COUNTED s_waitcnt vmcnt((NS-2)*LPC) (chunk k+1 landed, the later ones still flying) followed by ONE raw
+//    s_barrier per chunk -- the lookahead has to cover ~1 us of loaded global->LDS latency;
+//  * KS = 2 / 4 splits the 16-wide k-groups of every chunk over that many wave sets (2 / 4 waves per SIMD at one
+//    workgroup per CU), reduced through LDS at the end -- for the GEMMs whose grid cannot fill the chip twice.
 // ------------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 8, "vmcnt literal");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 0 && N <= 16, "vmcnt literal");
+#define IDF_VMCNT_CASE(n) if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    IDF_VMCNT_CASE(0) IDF_VMCNT_CASE(1) IDF_VMCNT_CASE(2) IDF_VMCNT_CASE(3) IDF_VMCNT_CASE(4) IDF_VMCNT_CASE(5) IDF_VMCNT_CASE(6)
+    IDF_VMCNT_CASE(7) IDF_VMCNT_CASE(8) IDF_VMCNT_CASE(9) IDF_VMCNT_CASE(10) IDF_VMCNT_CASE(11) IDF_VMCNT_CASE(12)
+    IDF_VMCNT_CASE(13) IDF_VMCNT_CASE(14) IDF_VMCNT_CASE(15) IDF_VMCNT_CASE(16)
+#undef IDF_VMCNT_CASE
 }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>
 __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g) {
     constexpr int NWT = WM * WN, NW = NWT * KS;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int CH = KC / 4, NS = 3;                          // 16-B chunks per tile row; LDS stages
+    constexpr int CH = KC / 4;                                  // 16-B chunks per tile row (NS = LDS stages)
     constexpr int RSL = 256 + 4;                                // A_LN: padded row stride of the normalised rows
     constexpr int A_STAGE = APRO == A_LN ? 0 : BM * KC, STAGE = A_STAGE + BN * KC;
     constexpr int A_LN_FLOATS = APRO == A_LN ? BM * RSL : 0;
     constexpr int IA = A_STAGE / 256, IB = BN * KC / 256, IPC = IA + IB, LPC = IPC / NW;
-    constexpr int RED = KS > 1 ? NWT * 64 * TM * TN * 4 : 0;
-    static_assert(IPC % NW == 0 && LPC >= 1 && LPC <= 8, "chunk loads must split evenly over the waves");
+    constexpr int RED = KS > 1 ? (KS - 1) * NWT * 64 * TM * TN * 4 : 0;
+    static_assert(IPC % NW == 0 && LPC >= 1 && (NS - 2) * LPC <= 16 && NS >= 3 && NS <= 6, "chunk loads must split evenly over the waves");
     static_assert((CH / 4) % KS == 0 && TM >= 1 && TN >= 1 && (CH == 8 || CH == 16), "tile shape");
     static_assert(APRO != A_TOKT, "token gather uses the register-staged kernel");
     constexpr int SMEM = A_LN_FLOATS + NS * STAGE;
@@ -367,14 +364,24 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
             dst[j] = A_STAGE + ib * 256;
         }
     }
+    // wait until chunk `c` has landed: the chunks issued after it (at most NS-2, fewer near the end) may keep flying
+    auto wait_landed = [&](int c) {
+        const int ahead = min(NS - 2, nk - 1 - c);
+        if (ahead <= 0) wait_vmcnt<0>();
+        else if (ahead == 1) wait_vmcnt<LPC>();
+        else if (ahead == 2) { if constexpr (NS >= 4) wait_vmcnt<2 * LPC>(); }
+        else if (ahead == 3) { if constexpr (NS >= 5) wait_vmcnt<3 * LPC>(); }
+        else { if constexpr (NS >= 6) wait_vmcnt<4 * LPC>(); }
+    };
     auto issue = [&](int kc, int st) {
 #pragma unroll
         for (int j = 0; j < LPC; ++j)
             __builtin_amdgcn_global_load_lds((const void *)(src[j] + kc * KC), (lds_ptr_t)(stages + st * STAGE + dst[j]), 16, 0, 0);
     };
 
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nk) issue(c, c);
     float rres[TM][TN][4], bvs[TN];
     load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
     if constexpr (EPI == E_RESID) {
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
             if (g.xn_out && nt_ == 0 && m < M) *reinterpret_cast<float4 *>(g.xn_out + (size_t)m * 256 + lane * 4) = v;
         }
     }
-    // chunk 0 landed (chunk 1 may still fly); the compiler's own waits for the ordinary loads above can only be stricter
-    if (nk > 1) wait_vmcnt<LPC>(); else wait_vmcnt<0>();
+    // chunk 0 landed (later chunks may still fly); the compiler's own waits for the ordinary loads above can only be stricter
+    wait_landed(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (g.probe && tid == 0) g.probe[wg * 4 + 1] = clock64();
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 
     int st = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 2 < nk) issue(kc + 2, st >= 1 ? st - 1 : 2);          // stage (kc+2) % 3, last read in iteration kc-1
+        if (kc + NS - 1 < nk) issue(kc + NS - 1, st >= 1 ? st - 1 : NS - 1);   // stage (kc-1) % NS, last read in iteration kc-1
         const float *Ab = APRO == A_LN ? Aln + kc * KC : stages + st * STAGE;
         const float *Bb = stages + st * STAGE + A_STAGE;
 #pragma unroll
@@ -456,39 +463,42 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 #pragma unroll
                 for (int j = 0; j < TN; ++j) IDF_MFMA4(acc[i][j], a[i].w, b[j].w);
         }
-        // chunk kc+1 must have landed before anyone reads it; chunk kc+2 (just issued) may keep flying
-        if (kc + 2 < nk) wait_vmcnt<LPC>(); else wait_vmcnt<0>();
+        // chunk kc+1 must have landed before anyone reads it; the chunks issued after it may keep flying
+        wait_landed(kc + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        st = st == 2 ? 0 : st + 1;
+        st = st == NS - 1 ? 0 : st + 1;
     }
     if (g.probe && tid == 0) g.probe[wg * 4 + 2] = clock64();
 
     if constexpr (KS > 1) {
         // all LDS reads of the k-loop are behind the last barrier: reuse the buffer for the partial tiles
+        constexpr int SLAB = NWT * 64 * TM * TN * 4;
         float *red = smem + (size_t)(wt * 64 + lane) * (TM * TN * 4);
-        if (ks == 1) {
+        if (ks > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4 *>(red + (i * TN + j) * 4) = acc[i][j];
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4 *>(red + (ks - 1) * SLAB + (i * TN + j) * 4) = acc[i][j];
         }
         __syncthreads();
         if (ks == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < KS - 1; ++q)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4 *>(red + (i * TN + j) * 4);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4 *>(red + q * SLAB + (i * TN + j) * 4);
         }
     }
     if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>
 inline void launch_glds(hipStream_t s, const Args &g) {
     dim3 grid((unsigned)(idf_cdiv(g.M, BM) * idf_cdiv(g.N, BN)));
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI>), grid, dim3(WM * WN * KS * 64), 0, s, g);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI, NS>), grid, dim3(WM * WN * KS * 64), 0, s, g);
 }
 
 }  // namespace idf_gemm

@@ -323,3 +323,33 @@ def test_gemm_f32_epilogues_vs_torch_fp32(lib):
         close(linear(xd, wd), x.double() @ w.double().T, 2e-6, 'no bias')
     with pytest.raises(RuntimeError):
         linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0
+
+
+# ------------------------------------------------------------------------------------------ other BASELINE configurations
+@pytest.mark.parametrize('B,T', [(32, 100), (32, 35), (1, 30)])
+def test_other_configs_run_and_match_oracle_step(smpl, B, T):
+    """BASELINE config #3 (B=32 with the correction predictor), the reference's default clip length (T=35) and a single
+    clip: one plain step + one corrected step of the sampler against the oracle (the per-op tests cover the rest)."""
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    P = 2048 if B == 32 and T == 100 else 256
+    bt = fx._clip(100 + B + T, B, T, P)
+    y = fx.model_kwargs_y(bt, T)
+    model = MDM(fx.mdm_weights(), device=DEV)
+    corr = make_correction(smpl, T, P)
+    x = bt['noise']
+    ts = torch.full((B,), 250, dtype=torch.int64)
+    x0 = model(x.to(DEV), ts.to(DEV), y={'cond': bt['cond'].to(DEV)})
+    ref0 = oden.mdm_forward(fx.mdm_weights(), x, ts, bt['cond'])
+    close(x0, ref0, 1e-4, 'denoiser B=%d T=%d' % (B, T))
+XX
+        m = y['inpainting_mask']
+        xin = ref0 * (~m) + y['inpainted_motion'] * m
+        got = corr(xin.clone().to(DEV), ts.to(DEV), {'y': dev(y)})
+        ref = ocor.denoised_fn(xin.clone(), ts, {'y': dict(y, smpl=fx.smpl_model(), obj_model=fx.objproj_weights())}, past_len=fx.PAST)
+        close(got, ref, 1e-4, 'correction B=%d T=%d' % (B, T))
+    else:
+        diff = create_gaussian_diffusion('cosine', 1000)
+        out = diff.p_sample_loop(model, tuple(x.shape), noise=x.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)},
+                                 denoised_fn=corr, seed=3, n_steps=501)           # crosses the first correction step (t = 500)
+        assert torch.isfinite(out).all()

@@ -17,26 +17,26 @@ using namespace idf_gemm;
 std::vector<float> hA;
 struct Shape { const char *name; int M, N, K, epi; };
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int EPI>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int EPI, int NS>
 void launch_any(const Args &g) {
     if constexpr (KS == 0) launch<BM, BN, WM, WN, KC, A_PLAIN, EPI>(0, g);
-    else launch_glds<BM, BN, WM, WN, KS, KC, A_PLAIN, EPI>(0, g);
+    else launch_glds<BM, BN, WM, WN, KS, KC, A_PLAIN, EPI, NS>(0, g);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int EPI>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int EPI, int NS>
 void run(const char *cfg, const Shape &sh, Args g, long long *probe_d) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     g.probe = nullptr;
-    for (int i = 0; i < 20; ++i) launch_any<BM, BN, WM, WN, KS, KC, EPI>(g);
+    for (int i = 0; i < 20; ++i) launch_any<BM, BN, WM, WN, KS, KC, EPI, NS>(g);
     CK(hipDeviceSynchronize());
     const int n = 200;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < n; ++i) launch_any<BM, BN, WM, WN, KS, KC, EPI>(g);
+    for (int i = 0; i < n; ++i) launch_any<BM, BN, WM, WN, KS, KC, EPI, NS>(g);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const int nwg = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     g.probe = probe_d;
-    launch_any<BM, BN, WM, WN, KS, KC, EPI>(g);
+    launch_any<BM, BN, WM, WN, KS, KC, EPI, NS>(g);
     CK(hipDeviceSynchronize());
     std::vector<long long> p(nwg * 4);
     CK(hipMemcpy(p.data(), probe_d, p.size() * 8, hipMemcpyDeviceToHost));
@@ -79,25 +79,17 @@ int main() {
     for (const Shape &sh : shapes) {
         Args g{};
         g.A = A; g.lda = sh.K; g.K = sh.K; g.W = W; g.bias = bias; g.C = C; g.ldc = sh.N; g.M = sh.M; g.N = sh.N; g.resid = R; g.T = 100;
-#define RUN(BM, BN, WM, WN, KS, KC)                                                                     \
-    if (sh.epi == E_GELU) run<BM, BN, WM, WN, KS, KC, E_GELU>(#BM "x" #BN " w" #WM "x" #WN " ks" #KS " kc" #KC, sh, g, probe); \
-    else run<BM, BN, WM, WN, KS, KC, E_RESID>(#BM "x" #BN " w" #WM "x" #WN " ks" #KS " kc" #KC, sh, g, probe);
-        // KS = 0: register-staged kernel; KS >= 1: LDS-DMA pipeline with KS k-slices per workgroup
-        RUN(32, 64, 2, 2, 0, 32)
-        RUN(32, 32, 2, 2, 0, 32)
-        RUN(32, 64, 2, 2, 1, 32)
-        RUN(32, 64, 2, 2, 1, 64)
-        RUN(32, 64, 2, 2, 2, 64)
-        RUN(64, 64, 2, 2, 1, 32)
-        RUN(64, 64, 2, 2, 1, 64)
-        RUN(64, 64, 2, 2, 2, 32)
-        RUN(64, 64, 2, 2, 2, 64)
-        RUN(32, 32, 2, 2, 1, 64)
-        RUN(32, 32, 2, 2, 2, 64)
-        RUN(64, 32, 2, 2, 1, 32)
-        RUN(64, 32, 2, 2, 2, 64)
-        RUN(32, 128, 2, 4, 1, 64)
-        RUN(64, 128, 2, 4, 1, 32)
+#define RUN(BM, BN, WM, WN, KS, KC, NS)                                                                     \
+    if (sh.epi == E_GELU) run<BM, BN, WM, WN, KS, KC, E_GELU, NS>(#BM "x" #BN " ks" #KS " kc" #KC " ns" #NS, sh, g, probe); \
+    else run<BM, BN, WM, WN, KS, KC, E_RESID, NS>(#BM "x" #BN " ks" #KS " kc" #KC " ns" #NS, sh, g, probe);
+        // KS = 0: register-staged kernel; KS >= 1: LDS-DMA pipeline with KS k-slices per workgroup, NS stages
+        RUN(32, 32, 2, 2, 2, 64, 3)
+        RUN(32, 32, 2, 2, 4, 64, 3)
+        RUN(32, 32, 2, 2, 4, 64, 4)
+        RUN(64, 32, 2, 2, 1, 32, 3)
+        RUN(64, 32, 2, 2, 2, 64, 3)
+        RUN(64, 64, 2, 2, 4, 64, 3)
+        RUN(64, 64, 2, 2, 2, 32, 3)
     }
     return 0;
 }

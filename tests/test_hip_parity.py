@@ -342,7 +342,7 @@ def test_other_configs_run_and_match_oracle_step(smpl, B, T):
     x0 = model(x.to(DEV), ts.to(DEV), y={'cond': bt['cond'].to(DEV)})
     ref0 = oden.mdm_forward(fx.mdm_weights(), x, ts, bt['cond'])
     close(x0, ref0, 1e-4, 'denoiser B=%d T=%d' % (B, T))
-XX
+    if B * T <= 200:                                          # the CPU oracle's SMPL + NN pass is slow: bound it
         m = y['inpainting_mask']
         xin = ref0 * (~m) + y['inpainted_motion'] * m
         got = corr(xin.clone().to(DEV), ts.to(DEV), {'y': dev(y)})

@@ -38,6 +38,9 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
     raise NotImplementedError('unknown beta schedule: %s' % schedule_name)
 
 
+GRAPH_BLOCKS = (49, 7, 1)          # plain steps per captured hipGraph (49 = the gap between two correction steps)
+
+
 class GaussianDiffusion:
     """START_X / FIXED_SMALL diffusion (the reference's create_gaussian_diffusion configuration)."""
 
@@ -99,27 +102,33 @@ class GaussianDiffusion:
         st = self._graphs.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),
-                                 state=torch.zeros(4, dtype=torch.int64, device=dev), keep=(mu8, gc, cond, model_kwargs))
+                                 state=torch.zeros(4, dtype=torch.int64, device=dev), keep=(mu8, gc, cond, model_kwargs), graphs={})
             model(st.x, st.ts, out=st.x0, **model_kwargs)            # warm-up: workspaces, kernel attributes
             torch.cuda.synchronize(dev)
-            st.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.graph):
-                model(st.x, st.ts, out=st.x0, **model_kwargs)
-                posterior(st.x, st.x0, gc, mu8, st)
             if len(self._graphs) > 8:
                 self._graphs.clear()
             self._graphs[key] = st
+
+        def graph_of(k):
+            """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
+            if k not in st.graphs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(k):
+                        model(st.x, st.ts, out=st.x0, **model_kwargs)
+                        posterior(st.x, st.x0, gc, mu8, st)
+                st.graphs[k] = g
+            return st.graphs[k]
         t_start = self.num_timesteps - 1
         st.x.copy_(img)
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         gate = getattr(denoised_fn, 'is_active', None)
-        dump = []
-        for it, i in enumerate(range(t_start, t_start - todo, -1)):
-            if denoised_fn is None or (gate is not None and not gate(i)):
-                st.graph.replay()
-            else:
+        active = lambda i: denoised_fn is not None and (gate is None or gate(i))
+        dump, it, i, end = [], 0, t_start, t_start - todo
+        while i > end:
+            if active(i):
                 x0 = model(st.x, st.ts, out=st.x0, **model_kwargs)
                 if has_mask:
                     _lib.check(lib.interdiff_inpaint(_lib.dptr(x0), _lib.dptr(gc), _lib.dptr(mu8), x0.numel(), _lib.stream()), 'inpaint')
@@ -127,7 +136,18 @@ class GaussianDiffusion:
                 t.host_value = i
                 x0 = denoised_fn(x0, t, model_kwargs).contiguous()
                 posterior(st.x, x0, None, None, st)
-            if dump_steps is not None and it in dump_steps:
+                k = 1
+            else:
+                # length of the plain run ahead (up to the next hook step / dump point / end), replayed in the
+                # largest captured block sizes: 989 plain steps of a 1000-step sample take ~25 graph launches
+                run = 1
+                while i - run > end and not active(i - run) and not (dump_steps is not None and (it + run - 1) in dump_steps):
+                    run += 1
+                k = next(b for b in GRAPH_BLOCKS if b <= run)
+                graph_of(k).replay()
+            i -= k
+            it += k
+            if dump_steps is not None and (it - 1) in dump_steps:
                 dump.append(st.x.clone())
         return dump if dump_steps is not None else st.x.clone()
 

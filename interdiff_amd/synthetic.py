@@ -63,7 +63,49 @@ def mdm_state_dict(seed=233, d=256, ff=1024, n_body=135, n_obj=9, n_queries=10):
             norm(p + '.norm%d' % k)
     linear('bodyFinalLinear', n_body, d)
     linear('objFinalLinear', n_obj, d)
+    # ---- encoder side ("next" row N1; drawn AFTER everything above so the decoder weights keep their values):
+    # encoder.layers.{0..7} (std: self_attn, QaN: queries/wk; linear1/2, norm1/2) and pcEmbedding = PointNet2Encoder
+    # (model/layers.py:111-140; pointnet2_ops 3.0.0 build_shared_mlp naming: mlps.<scale>.{0,3,6} conv, {1,4,7} BatchNorm)
+    for l in range(N_LAYERS):
+        p = 'encoder.layers.%d' % l
+        if l in QAN_LAYERS:
+            sd[p + '.queries'] = _f32(rs.normal(-1.0 / np.sqrt(d), 1.0 / np.sqrt(d), (n_queries, d)))
+            sd[p + '.wk'] = _f32(rs.normal(-1.0 / np.sqrt(n_queries), 1.0 / np.sqrt(n_queries), (n_queries, 1)))
+        else:
+            mha(p + '.self_attn')
+        linear(p + '.linear1', ff, d)
+        linear(p + '.linear2', d, ff)
+        for k in (1, 2):
+            norm(p + '.norm%d' % k)
+    for s_, specs in enumerate(PC_MLPS):
+        for m_, spec in enumerate(specs):
+            for l_ in range(3):
+                cin, cout = spec[l_], spec[l_ + 1]
+                q = 'pcEmbedding.SA_modules.%d.mlps.%d' % (s_, m_)
+                sd['%s.%d.weight' % (q, 3 * l_)] = _f32(rs.standard_normal((cout, cin, 1, 1)) * np.sqrt(2.0 / cin))
+                sd['%s.%d.weight' % (q, 3 * l_ + 1)] = _f32(1.0 + 0.1 * rs.standard_normal(cout))
+                sd['%s.%d.bias' % (q, 3 * l_ + 1)] = _f32(0.1 * rs.standard_normal(cout))
+                sd['%s.%d.running_mean' % (q, 3 * l_ + 1)] = _f32(0.1 * rs.standard_normal(cout))
+                sd['%s.%d.running_var' % (q, 3 * l_ + 1)] = _f32(rs.uniform(0.5, 1.5, cout))
+    linear('pcEmbedding.Linear', d - 3, 256)
     return sd
+
+
+# shared-MLP channel plans of PointNet2Encoder(c_in=1, c_out=256, num_keypoints=1): +3 = use_xyz (model/layers.py:118-138)
+PC_MLPS = (((1 + 3, 16, 16, 32), (1 + 3, 32, 32, 64)), ((96 + 3, 64, 64, 128), (96 + 3, 64, 96, 128)))
+
+
+def make_embedding_inputs(seed=77, B=3, T=35, n_points=2048):
+    """Inputs of MDM._get_embeddings in tensor form: axis-angle body pose [T,B,66], translations, object pose, and an
+    object point cloud that lives on a ~0.4 m box surface-ish shell (so that the 5-20 cm ball queries find neighbours)."""
+    rs = np.random.RandomState(seed)
+    walk = lambda shape0, scale, step: scale * rs.standard_normal((1,) + shape0) + np.cumsum(step * rs.standard_normal((T,) + shape0), axis=0)
+    pts = rs.uniform(-0.2, 0.2, (B, n_points, 3))
+    ax = rs.randint(0, 3, size=(B, n_points))
+    np.put_along_axis(pts, ax[..., None], np.sign(np.take_along_axis(pts, ax[..., None], axis=2)) * 0.2, axis=2)   # onto the faces of the box
+    pts[:, 7] = 1e-3 * rs.standard_normal((B, 3))             # a point with |p|^2 <= 1e-3: furthest-point sampling must skip it
+    return dict(body_pose=_f32(walk((B, 66), 0.3, 0.02)), body_trans=_f32(walk((B, 3), 0.1, 0.016)),
+                obj_angles=_f32(walk((B, 3), 1.0, 0.03)), obj_trans=_f32(walk((B, 3), 0.3, 0.01)), obj_points=_f32(pts))
 
 
 # ----------------------------------------------------------------------------

@@ -119,3 +119,40 @@ def mdm_forward(sd, x, ts, cond, rotary=ROTARY_DEFAULT, n_body=135):
         h = qan_layer(h, cond, sd, p, rotary) if l in QAN_LAYERS else std_layer(h, cond, sd, p)
     out = torch.cat([_lin(h, sd, 'bodyFinalLinear'), _lin(h, sd, 'objFinalLinear')], dim=-1)
     return out.permute(1, 2, 0).unsqueeze(1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Encoder / conditioning ("next" row N1): MDM._get_embeddings (model/diffusion_smpl.py:195-223) with the 8-layer
+# encoder [std, QaN x6, std] (:19-70; nn.TransformerEncoderLayer post-norm gelu, sublayers.py:36-205).
+# ---------------------------------------------------------------------------------------------------------------
+def enc_std_layer(x, sd, p):
+    """torch.nn.TransformerEncoderLayer, norm_first=False."""
+    x = _ln(x + _mha(x, x, sd, p + '.self_attn'), sd, p + '.norm1')
+    return _ln(x + _ffn(x, sd, p), sd, p + '.norm2')
+
+
+def enc_qan_layer(src, sd, p, rotary=ROTARY_DEFAULT):
+    """sublayers.py:140-161 (norm_first=False; stochastic depth identity, round trip kept)."""
+    x = _ln(src + qan_block(src, sd, p, rotary), sd, p + '.norm1')
+    x = _ln(x + _ffn(x, sd, p), sd, p + '.norm2')
+    return src + (x - src)
+
+
+def get_embeddings(sd, body_pose, body_trans, obj_angles, obj_trans, obj_points, past_len, rotary=ROTARY_DEFAULT):
+    """body_pose [T,B,66] axis-angle, body_trans [T,B,3], obj_angles [T,B,3] axis-angle, obj_trans [T,B,3],
+    obj_points [B,P,3]  ->  (cond [past_len,B,256], gt [T,B,144])."""
+    from . import rotations as R
+    from .pointnet2 import pointnet2_encode
+    T, B, _ = body_pose.shape
+    pc = pointnet2_encode(sd, obj_points)[None]                                       # [1,B,256]
+    body6 = R.matrix_to_rotation_6d(R.axis_angle_to_matrix(body_pose.reshape(T, B, -1, 3))).reshape(T, B, -1)
+    obj6 = R.matrix_to_rotation_6d(R.axis_angle_to_matrix(obj_angles.reshape(T, B, -1, 3))).reshape(T, B, -1)
+    gt = torch.cat([body6, body_trans, obj6, obj_trans], dim=2)
+    body, obj = torch.cat([body6, body_trans], dim=2), torch.cat([obj6, obj_trans], dim=2)
+    h = _lin(body[:past_len], sd, 'bodyEmbedding') + _lin(obj[:past_len], sd, 'objEmbedding') + pc
+    pe = sd['PositionalEmbedding.pe'][:, 0] if 'PositionalEmbedding.pe' in sd else positional_table()
+    h = h + pe[:past_len, None].to(h.dtype)
+    for l in range(N_LAYERS):
+        p = 'encoder.layers.%d' % l
+        h = enc_qan_layer(h, sd, p, rotary) if l in QAN_LAYERS else enc_std_layer(h, sd, p)
+    return h, gt

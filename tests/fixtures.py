@@ -137,3 +137,11 @@ def eval_inputs():
     bt = _clip(21, B, T, P)
     batch = dict(gt=bt['gt'], cond=bt['cond'], hand_pose=bt['hand_pose'], beta=bt['beta'], obj_points=bt['obj_points'])
     return batch, bt['noise'], NoiseStream(7000)
+
+
+EMB_SHAPE = (35, 3, 2048)              # T, B, P : MDM._get_embeddings (encoder side, "next" row N1)
+
+
+def embedding_inputs():
+    T, B, P = EMB_SHAPE
+    return {k: _t(v) for k, v in syn.make_embedding_inputs(seed=77, B=B, T=T, n_points=P).items()}

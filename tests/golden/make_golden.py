@@ -17,6 +17,8 @@ What each fixture pins (reference file:line in brackets):
   denoised_fn.npz  eval_smpl_short.denoised_fn            [eval_smpl_short.py:84-130]
   loop.npz         GaussianDiffusion.p_sample_loop, full 1000 steps, with the reference MDM and
                    the reference denoised_fn, injected per-step noise [gaussian_diffusion.py:598-736]
+  embed.npz        MDM._get_embeddings: the reference's own embedding / encoder code around the PointNet++ stub
+                   (sampling and grouping indices from oracle/pointnet2.py: parity unpinned) [model/diffusion_smpl.py:195-223]
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
@@ -170,6 +172,17 @@ def main():
     finally:
         gd.th.randn_like = real_randn_like
     save('loop.npz', **{'dump_%d' % s: np_(v) for s, v in zip(fx.LOOP_DUMPS, dumps)})
+
+    # ---- encoder side: MDM._get_embeddings on the reference module (dataset batch stand-in)
+    T, B, P = fx.EMB_SHAPE
+    ei = fx.embedding_inputs()
+    net.args.past_len = fx.PAST
+    pose156 = torch.cat([ei['body_pose'], torch.zeros(T, B, 90)], dim=2)
+    rb = {'frames': [{'smplfit_params': {'pose': pose156[t], 'trans': ei['body_trans'][t]},
+                      'objfit_params': {'angle': ei['obj_angles'][t], 'trans': ei['obj_trans'][t]}} for t in range(T)],
+          'obj_points': torch.cat([ei['obj_points'], torch.zeros(B, P, 3)], dim=2)}
+    cond, gt = type(net)._get_embeddings(net, rb, None)
+    save('embed.npz', cond=np_(cond), gt=np_(gt))
 
     # ---- eval glue: the reference's sample_once_proj / get_gt / metrics on a tiny clip, 50-step schedule.
     # The dataset batch and the encoder (_get_embeddings: a "next" row) are stand-ins that hand back our tensors.

@@ -47,9 +47,38 @@ def install():
     tv.ops = mod('torchvision.ops',
                  stochastic_depth=lambda x, p, mode, training=True: x if (p == 0.0 or not training) else (_ for _ in ()).throw(NotImplementedError()))
 
-    class _SA(torch.nn.Module):            # encoder-only dependency ("next" row); never called
-        def __init__(self, *a, **k):
+    # --- pointnet2_ops.pointnet2_modules.PointnetSAModuleMSG (CUDA-only third party, "next" row N1): the module
+    # structure / parameter names of pointnet2_ops 3.0.0 (mlps = ModuleList of Sequential(Conv2d 1x1 no bias,
+    # BatchNorm2d, ReLU) x 3, +3 input channels for use_xyz) with torch's own conv / batch-norm doing the MLP, while the
+    # sampling / grouping indices come from the oracle's restatement (oracle/pointnet2.py: parity unpinned).
+    from oracle import pointnet2 as opn
+
+    class _SA(torch.nn.Module):
+        def __init__(self, npoint, radii, nsamples, mlps, use_xyz=True, bn=True):
             super().__init__()
+            self.npoint, self.radii, self.nsamples = npoint, list(radii), list(nsamples)
+            self.mlps = torch.nn.ModuleList()
+            for spec in mlps:
+                spec = list(spec)
+                if use_xyz:
+                    spec[0] += 3
+                layers = []
+                for i in range(1, len(spec)):
+                    layers += [torch.nn.Conv2d(spec[i - 1], spec[i], kernel_size=1, bias=not bn), torch.nn.BatchNorm2d(spec[i]),
+                               torch.nn.ReLU(True)]
+                self.mlps.append(torch.nn.Sequential(*layers))
+
+        def forward(self, xyz, features):
+            B = xyz.shape[0]
+            fidx = opn.furthest_point_sample(xyz, self.npoint)
+            new_xyz = torch.gather(xyz, 1, fidx[:, :, None].expand(B, self.npoint, 3))
+            outs = []
+            for r, ns, mlp in zip(self.radii, self.nsamples, self.mlps):
+                idx = opn.ball_query(r, ns, xyz, new_xyz)
+                bi = torch.arange(B)[:, None, None]
+                g = torch.cat([xyz[bi, idx] - new_xyz[:, :, None, :], features.permute(0, 2, 1)[bi, idx]], dim=3).permute(0, 3, 1, 2)
+                outs.append(mlp(g.contiguous()).max(dim=3)[0])
+            return new_xyz, torch.cat(outs, dim=1)
     pn = mod('pointnet2_ops')
     pn.pointnet2_modules = mod('pointnet2_ops.pointnet2_modules', PointnetSAModuleMSG=_SA)
     mod('smplx')

@@ -172,3 +172,24 @@ def test_eval_glue_and_metrics():
                      full('body_gt')[past:], verts_ref[past:], smpl['faces'], batch['obj_points'])
     for k, v in m.items():
         close(v, z['m_' + k], 1e-4 if k != 'penetrate' else 2e-2, 'metric ' + k)
+
+
+def test_get_embeddings_encoder_side():
+    """"Next" row N1: oracle MDM._get_embeddings (PointNet++ restatement + embeddings + 8-layer encoder) vs the reference's
+    own module run (tests/golden/embed.npz); plus the properties the restated PointNet++ ops must have."""
+    from oracle import pointnet2 as opn
+    z = fx.golden('embed.npz')
+    ei = fx.embedding_inputs()
+    cond, gt = oden.get_embeddings(fx.mdm_weights(), ei['body_pose'], ei['body_trans'], ei['obj_angles'], ei['obj_trans'],
+                                   ei['obj_points'], fx.PAST)
+    close(cond, z['cond'], 1e-5, 'cond')
+    close(gt, z['gt'], 1e-6, 'gt')
+    xyz = ei['obj_points'][:1]
+    idx = opn.furthest_point_sample(xyz, 64)[0]
+    assert idx[0] == 0 and len(set(idx.tolist())) == 64 and 7 not in idx.tolist()       # point 7 has |p|^2 <= 1e-3: skipped
+    d = ((xyz[0, idx][:, None] - xyz[0, idx][None]) ** 2).sum(-1)
+    assert d[1:, 0].min() > 0.01                                                         # spread out
+    bq = opn.ball_query(0.1, 16, xyz, xyz[:, :5])
+    for m in range(5):
+        hits = torch.nonzero(((xyz[0] - xyz[0, m]) ** 2).sum(-1) < 0.01)[:, 0][:16]
+        assert torch.equal(bq[0, m, :len(hits)], hits) and (bq[0, m, len(hits):] == hits[0]).all()

@@ -134,8 +134,11 @@ typedef struct {
     int64_t out_w, out_b;      /* [C][256] = [bodyFinalLinear ; objFinalLinear]          */
     int64_t temb_table;        /* [n_steps][256] = time_embed(pe[t]) (weights-only const) */
     int64_t pe;                /* [max_T][256] positional table rows 0..max_T-1          */
-    int32_t max_T, _pad;
+    int32_t max_T, has_encoder;
     idf_mdm_layer layer[IDF_MDM_LAYERS];
+    /* encoder side ("next" row, MDM._get_embeddings): [std, QaN x6, std] without cross-attention; uses sa_*, qc, wk,
+     * ff*, ln_w/ln_b[0..1] (= norm1, norm2); valid when has_encoder != 0 */
+    idf_mdm_layer enc_layer[IDF_MDM_LAYERS];
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
@@ -158,6 +161,33 @@ int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, in
 int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x,
                           const int64_t *ts, int32_t B, int32_t T, float *x0,
                           void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Conditioning path ("next" row of SURVEY.md §8(f)): MDM._get_embeddings (model/diffusion_smpl.py:195-223) minus
+ * the dataset plumbing.
+ *  interdiff_pointnet2_encode   replaces PointNet2Encoder.forward (model/layers.py:141-175) with one key point:
+ *      obj_points [B,P,3] (P <= 2048) -> pc [B,256] = [key-point xyz | Linear(SA2 features)]; eval BatchNorm folded
+ *      into the shared-MLP convolutions at pack time (weights [cout][cin] + bias per layer).
+ *  interdiff_mdm_encode         replaces bodyEmbedding/objEmbedding + PositionalEmbedding + encoder:
+ *      x_past [B,1,C,Tp] (the first Tp = past_len frames of the token tensor), pc [B,256] -> cond [Tp,B,256].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t w[3], b[3];        /* offsets into the arena: folded conv*BN weight [c[l+1]][c[l]], bias [c[l+1]]        */
+    int32_t c[4];              /* channel plan (input includes the 3 xyz channels)                                 */
+} idf_pn_mlp;
+
+typedef struct {
+    const float *arena;
+    idf_pn_mlp sa1[2];         /* radii 0.05 / 0.1, 16 / 32 samples: 4-16-16-32, 4-32-32-64                        */
+    idf_pn_mlp sa2[2];         /* radii 0.1 / 0.2, 16 / 32 samples: 99-64-64-128, 99-64-96-128                     */
+    int64_t lin_w, lin_b;      /* Linear [253][256], [253]                                                         */
+} idf_pointnet2;
+
+int interdiff_pointnet2_encode(const idf_pointnet2 *pn, const float *obj_points, int32_t B, int32_t P, float *out,
+                               void *stream);
+size_t interdiff_mdm_encode_workspace_bytes(int32_t B, int32_t Tp);
+int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, const float *x_past, int32_t B, int32_t Tp,
+                         float *cond, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Sampler step   replaces p_mean_variance's inpainting + q_posterior mean and p_sample's

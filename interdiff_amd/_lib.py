@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -34,8 +34,16 @@ class MdmLayer(C.Structure):
 class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
-                ('temb_table', i64), ('pe', i64), ('max_T', i32), ('_pad', i32),
-                ('layer', MdmLayer * MDM_LAYERS)]
+                ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS)]
+
+
+class PnMlp(C.Structure):
+    _fields_ = [('w', i64 * 3), ('b', i64 * 3), ('c', i32 * 4)]
+
+
+class PointNet2(C.Structure):
+    _fields_ = [('arena', vp), ('sa1', PnMlp * 2), ('sa2', PnMlp * 2), ('lin_w', i64), ('lin_b', i64)]
 
 
 class ObjProj(C.Structure):
@@ -65,6 +73,9 @@ _SIGS = {
     'interdiff_nn_argmin': (C.c_int, [vp, i32, vp, i32, i64, vp, vp]),
     'interdiff_point2point_signed': (C.c_int, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'interdiff_gemm_f32': (C.c_int, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'interdiff_pointnet2_encode': (C.c_int, [C.POINTER(PointNet2), vp, i32, i32, vp, vp]),
+    'interdiff_mdm_encode_workspace_bytes': (sz, [i32, i32]),
+    'interdiff_mdm_encode': (C.c_int, [C.POINTER(MdmWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     'interdiff_mdm_memctx_floats': (sz, [i32]),
     'interdiff_mdm_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),

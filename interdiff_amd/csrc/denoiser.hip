@@ -69,14 +69,15 @@ constexpr int TR = 16;
 constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
 constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
-template <bool QAN>
+template <bool QAN, bool CROSS = true>
 __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
                                                        const float *__restrict__ wk, const float *__restrict__ ln1_w,
                                                        const float *__restrict__ ln1_b, const float *__restrict__ G,
                                                        const float *__restrict__ g0, const float *__restrict__ VWT,
                                                        const float *__restrict__ bout, const float *__restrict__ ln2_w,
-                                                       const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T) {
+                                                       const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
+                                                       int out_frame_major /* encoder output: row = t*B + b */) {
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + NQ * TR * 4 + TR * 4 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
@@ -91,10 +92,12 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     const size_t rowbase = (size_t)b * T;
     // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
     const int rown = wave * 4 + kq;
-    const float *Gb = G + (size_t)b * HM * D, *g0b = g0 + b * HM, *VWTb = VWT + (size_t)b * D * HMP;
+    const float *Gb = CROSS ? G + (size_t)b * HM * D : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
+    const float *VWTb = CROSS ? VWT + (size_t)b * D * HMP : nullptr;
 
     float4 gv[4][3];                              // folded-score operand fragments, prefetched one phase ahead
     auto prefetch_g = [&]() {
+        if constexpr (!CROSS) return;
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
             }
             ln_row16(xc, ln1_w, ln1_b, li);
-            row16_store(xc, x1s + rown * RS, li);
+            if constexpr (CROSS) row16_store(xc, x1s + rown * RS, li);
+            else if (t0 + rown < T) row16_store(xc, x2_out + (out_frame_major ? (size_t)(t0 + rown) * gridDim.y + b : rowbase + t0 + rown) * D, li);
         }
     } else {
         const int t = t0 + rown;
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         if (t < T) row16_load(ra, u_in + (rowbase + t) * D, li);
         prefetch_g();
         ln_row16(ra, ln1_w, ln1_b, li);
-        row16_store(ra, x1s + rown * RS, li);
+        if constexpr (CROSS) row16_store(ra, x1s + rown * RS, li);
+        else if (t < T) row16_store(ra, x2_out + (out_frame_major ? (size_t)t * gridDim.y + b : rowbase + t) * D, li);
     }
+    if constexpr (!CROSS) return;                  // encoder layers: no memory to attend to, x1 is the FFN input
     __syncthreads();
     float4 vw[HMP / 16][4];
     {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
@@ -487,6 +493,82 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
     return IDF_OK;
 }
 
+namespace {
+__global__ void iota_kernel(int64_t *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+}  // namespace
+
+extern "C" size_t interdiff_mdm_encode_workspace_bytes(int32_t B, int32_t Tp) {
+    const size_t N = (size_t)B * Tp;
+    return idf_align(N * (5 * D + 3 * D + FF) * sizeof(float)) + idf_align((size_t)B * sizeof(int64_t));
+}
+
+// Encoder side: u0 = [body | obj].W_in^T + b_in + pc[b] + pe[t] over the Tp past frames, then the 8 encoder layers
+// (model/diffusion_smpl.py:217-221).  Same kernels as the decoder; the row block runs without the cross-attention
+// phases, the last LayerNorm writes the frame-major [Tp,B,256] layout the decoder's memory folding expects.
+extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, const float *x_past, int32_t B, int32_t Tp,
+                                    float *cond, void *ws, size_t ws_bytes, void *stream) {
+    if (!w || !pc || !x_past || !cond || !ws || B <= 0 || Tp <= 0) return IDF_E_INVAL;
+    if (!w->has_encoder || Tp > w->max_T || Tp > ATTN_MAX_T || w->C > 256 || (w->C & 3)) return IDF_E_INVAL;
+    if (ws_bytes < interdiff_mdm_encode_workspace_bytes(B, Tp)) return IDF_E_NOMEM;
+    hipStream_t s = idf_stream(stream);
+    const float *ar = w->arena;
+    const int N = B * Tp, C = w->C, T = Tp;
+    Ws k = carve(ws, N);
+    int64_t *iota = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * (5 * D + 3 * D + FF) * sizeof(float)));
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)idf_cdiv(B, 256)), dim3(256), 0, s, iota, B);
+    {
+        Args g{};
+        g.A = x_past; g.K = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
+        g.ts = iota; g.temb = pc; g.pe = ar + w->pe; g.n_steps = B;            // "+ temb[ts[b]]" adds pc[b]
+        launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
+    }
+    float *u_in = k.uA, *u_tmp = k.uB;
+    const float *lnp_w = nullptr, *lnp_b = nullptr;
+    const int TP = (T + 15) & ~15;
+    const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(self_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float))) != hipSuccess)
+        return IDF_E_LAUNCH;
+    const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
+    for (int l = 0; l < L; ++l) {
+        const idf_mdm_layer &ly = w->enc_layer[l];
+        if (ly.is_qan) {
+            hipLaunchKernelGGL((rowblock_kernel<true, false>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0);
+        } else {
+            Args g{};
+            g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T;
+            run_gemm<A_LN, E_BIAS>(CFG_QKV, s, g);
+            hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
+            Args o{};
+            o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
+            o.N = D; o.resid = k.xn; o.T = T;
+            run_gemm<A_PLAIN, E_RESID>(CFG_OUTPROJ, s, o);
+            hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0);
+        }
+        Args f1{};
+        f1.A = k.x2; f1.lda = D; f1.K = D; f1.W = ar + ly.ff1_w; f1.bias = ar + ly.ff1_b; f1.C = k.hid; f1.ldc = FF; f1.M = N;
+        f1.N = FF; f1.T = T;
+        run_gemm<A_PLAIN, E_GELU>(CFG_FFN1, s, f1);
+        Args f2{};
+        f2.A = k.hid; f2.lda = FF; f2.K = FF; f2.W = ar + ly.ff2_w; f2.bias = ar + ly.ff2_b; f2.C = u_in; f2.ldc = D; f2.M = N;
+        f2.N = D; f2.resid = k.x2; f2.T = T;
+        run_gemm<A_PLAIN, E_RESID>(CFG_FFN2, s, f2);
+        lnp_w = ar + ly.ln_w[1];
+        lnp_b = ar + ly.ln_b[1];
+    }
+    // cond[t][b][:] = LN2_last(u[b*T + t])
+    hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
+
 extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts,
                                      int32_t B, int32_t T, float *x0, void *ws, size_t ws_bytes, void *stream) {
     if (!w || !memctx || !x || !ts || !x0 || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
@@ -526,7 +608,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
             hipLaunchKernelGGL((rowblock_kernel<true>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T);
+                               ar + ly.ln_b[1], k.x2, T, 0);
         } else {
             // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
             Args g{};
@@ -545,7 +627,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
             hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T);
+                               ar + ly.ln_b[1], k.x2, T, 0);
         }
         // hid = gelu(x2.W1^T + b1) ; u3 = x2 + hid.W2^T + b2  (into the dead layer-input buffer)
         Args f1{};

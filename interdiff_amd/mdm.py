@@ -122,9 +122,51 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         for k in range(3):
             ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
             ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
+    # encoder side (MDM._get_embeddings, "next" row): [std, QaN x6, std] without cross-attention
+    w.has_encoder = 1 if 'encoder.layers.0.linear1.weight' in sd else 0
+    if w.has_encoder:
+        for l in range(LAYERS):
+            p, ly = 'encoder.layers.%d.' % l, w.enc_layer[l]
+            ly.is_qan = 1 if (p + 'queries') in sd else 0
+            if ly.is_qan:
+                ly.qc = ar.add(qan_constants(g(p + 'queries'), rotary))
+                ly.wk = ar.add(g(p + 'wk').reshape(-1))
+            else:
+                ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
+                ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
+                ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
+                ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
+            ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
+            ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
+            for k in range(2):
+                ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
+                ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
     arena = ar.tensor(device)
     w.arena = arena.data_ptr()
     return w, arena
+
+
+def pack_pointnet2(sd, device, prefix='pcEmbedding', eps=1e-5):
+    """PointNet2Encoder weights (model/layers.py:111-140; pointnet2_ops 3.0.0 naming ``SA_modules.<i>.mlps.<scale>.{0,3,6}`` conv,
+    ``{1,4,7}`` BatchNorm) -> (PointNet2 struct, arena).  Eval-mode BatchNorm is folded into the bias-free 1x1 convolutions
+    in float64: W' = W * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)."""
+    f = lambda k: _np(sd[k]).astype(np.float64)
+    ar = _Arena()
+    pn = _lib.PointNet2()
+    for si, dst in ((0, pn.sa1), (1, pn.sa2)):
+        for sc in range(2):
+            q = '%s.SA_modules.%d.mlps.%d' % (prefix, si, sc)
+            for l in range(3):
+                W = f('%s.%d.weight' % (q, 3 * l))[:, :, 0, 0]
+                bn = '%s.%d' % (q, 3 * l + 1)
+                sc_ = f(bn + '.weight') / np.sqrt(f(bn + '.running_var') + eps)
+                dst[sc].w[l] = ar.add(W * sc_[:, None])
+                dst[sc].b[l] = ar.add(f(bn + '.bias') - f(bn + '.running_mean') * sc_)
+                dst[sc].c[l], dst[sc].c[l + 1] = W.shape[1], W.shape[0]
+    pn.lin_w, pn.lin_b = ar.add(f(prefix + '.Linear.weight')), ar.add(f(prefix + '.Linear.bias'))
+    arena = ar.tensor(device)
+    pn.arena = arena.data_ptr()
+    return pn, arena
 
 
 class MDM:
@@ -136,6 +178,9 @@ class MDM:
         self.device = torch.device(device)
         self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
         self._mem_key, self._memctx, self._ws = None, None, None
+        self.pn = self.pn_arena = None
+        if 'pcEmbedding.Linear.weight' in state_dict:
+            self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
 
     # -- nn.Module-ish surface the sampler touches (gaussian_diffusion.py:688-689, eval_smpl_short.py:428)
     def parameters(self):
@@ -170,6 +215,29 @@ class MDM:
         self._mem_key = (cond.data_ptr(), cond._version, tuple(cond.shape))
         self._memctx = memctx
         return memctx
+
+    def _get_embeddings(self, body_pose, body_trans, obj_angles, obj_trans, obj_points, past_len=10):
+        """``MDM._get_embeddings`` (model/diffusion_smpl.py:195-223) on tensors instead of the dataset's dict-of-lists:
+        body_pose [T,B,66] axis-angle, body_trans [T,B,3], obj_angles [T,B,3] axis-angle, obj_trans [T,B,3],
+        obj_points [B,P,3]  ->  (cond [past_len,B,256], gt [T,B,144])."""
+        from . import transforms as tr
+        if self.pn is None or not self.w.has_encoder:
+            raise RuntimeError('this state_dict has no encoder / pcEmbedding weights')
+        T, B, _ = body_pose.shape
+        pts = obj_points.contiguous().float()
+        pc = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.interdiff_pointnet2_encode(C.byref(self.pn), _lib.dptr(pts), B, pts.shape[1], _lib.dptr(pc), _lib.stream()),
+                   'pointnet2_encode')
+        body6 = tr.matrix_to_rotation_6d(tr.axis_angle_to_matrix(body_pose.reshape(T, B, -1, 3))).reshape(T, B, -1)
+        obj6 = tr.matrix_to_rotation_6d(tr.axis_angle_to_matrix(obj_angles.reshape(T, B, -1, 3))).reshape(T, B, -1)
+        gt = torch.cat([body6, body_trans.float(), obj6, obj_trans.float()], dim=2)                       # [T,B,144]
+        x_past = gt[:past_len].permute(1, 2, 0).unsqueeze(1).contiguous()                                # [B,1,144,past]
+        need = self.lib.interdiff_mdm_encode_workspace_bytes(B, past_len)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        cond = torch.empty(past_len, B, D, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.interdiff_mdm_encode(C.byref(self.w), _lib.dptr(pc), _lib.dptr(x_past), B, past_len, _lib.dptr(cond),
+                                                 _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_encode')
+        return cond, gt
 
     def forward(self, x, timesteps, y=None, out=None):
         if y is None or 'cond' not in y:

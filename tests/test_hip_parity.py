@@ -353,3 +353,28 @@ def test_other_configs_run_and_match_oracle_step(smpl, B, T):
         out = diff.p_sample_loop(model, tuple(x.shape), noise=x.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)},
                                  denoised_fn=corr, seed=3, n_steps=501)           # crosses the first correction step (t = 500)
         assert torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------------ encoder side ("next" row N1)
+def test_get_embeddings_golden(mdm):
+    """HIP MDM._get_embeddings (PointNet++ object encoder + embeddings + 8-layer encoder) against the reference's own module
+    run (tests/golden/embed.npz) and the oracle; then the conditioning drives a decoder forward."""
+    from oracle import pointnet2 as opn
+    z = fx.golden('embed.npz')
+    ei = fx.embedding_inputs()
+    d = dev(ei)
+    cond, gt = mdm._get_embeddings(d['body_pose'], d['body_trans'], d['obj_angles'], d['obj_trans'], d['obj_points'], fx.PAST)
+    close(gt, z['gt'], 1e-6, 'gt vs reference golden')
+    close(cond, z['cond'], 1e-4, 'cond vs reference golden')
+    # the object encoder alone, including a cloud with fewer than 2048 points and one whose balls are empty
+    from interdiff_amd import _lib
+    import ctypes as C
+    for pts in (ei['obj_points'], ei['obj_points'][:, :700], 3.0 * ei['obj_points'][:2]):
+        ref = opn.pointnet2_encode(fx.mdm_weights(), pts)
+        got = torch.empty(pts.shape[0], 256, device=DEV)
+        pd = pts.contiguous().to(DEV)
+        _lib.check(mdm.lib.interdiff_pointnet2_encode(C.byref(mdm.pn), _lib.dptr(pd), pts.shape[0], pts.shape[1], _lib.dptr(got), _lib.stream()))
+        close(got, ref, 1e-5, 'pointnet2 P=%d' % pts.shape[1])
+    x, ts, _ = fx.mdm_inputs(3, 35)
+    close(mdm(x.to(DEV), ts.to(DEV), y={'cond': cond}), oden.mdm_forward(fx.mdm_weights(), x, ts, torch.from_numpy(z['cond'])), 1e-4,
+          'decoder on the HIP conditioning')

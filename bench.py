@@ -200,6 +200,19 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
         log('kernel profile done')
+    enc_ms = None
+    if rank == 0:
+        # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
+        ei = tt(syn.make_embedding_inputs(seed=77, B=B_PER_GPU, T=T, n_points=P), dev)
+        args_e = (ei['body_pose'], ei['body_trans'], ei['obj_angles'], ei['obj_trans'], ei['obj_points'], PAST)
+        model._get_embeddings(*args_e)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            model._get_embeddings(*args_e)
+        e1.record()
+        e1.synchronize()
+        enc_ms = e0.elapsed_time(e1) / 5
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(assets, tt({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in bt.items()}),
@@ -235,6 +248,8 @@ def main():
         line['denoiser_forward'] = dict(us=1e3 * dn / nfw, achieved_tflops=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12,
                                         frac_of_f32_mfma_peak=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12 / PEAK_F32_MFMA_TFLOPS)
         line['kernels_us_event_to_event'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}    # includes the launch gap + event records
+    if enc_ms is not None:
+        line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)
     if cpu:
         line['cpu_baseline'] = cpu
     print(json.dumps(line))

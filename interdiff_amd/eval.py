@@ -96,6 +96,50 @@ def smooth(obj, body, verts, jtrs, pelvis, future_len):
     return tuple(out)
 
 
+def batch_from_raw(model, raw, past_len=10):
+    """Dataset-side quantities -> the clip batch of this module, through the HIP conditioning path.
+    raw: body_pose [T,B,66] axis-angle, hand_pose [T,B,90], body_trans [T,B,3], obj_angles [T,B,3] axis-angle,
+    obj_trans [T,B,3], beta [T,B,10], obj_points [B,P,3]."""
+    cond, gt = model._get_embeddings(raw['body_pose'], raw['body_trans'], raw['obj_angles'], raw['obj_trans'], raw['obj_points'], past_len)
+    return dict(gt=gt.permute(1, 2, 0).unsqueeze(1).contiguous(), cond=cond, hand_pose=raw['hand_pose'].contiguous(),
+                beta=raw['beta'].contiguous(), obj_points=raw['obj_points'].contiguous())
+
+
+def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=0, **loop_kw):
+    """Autoregressive long-horizon forecasting (eval_smpl_long.py:26-84,273-285; BASELINE config #4).
+
+    Upstream this path is unreleased/broken (``denormalize`` / ``correct`` are undefined, ``get_batch`` copies clip 0 into
+    every clip and ``--autoregressive`` is never passed: SURVEY.md §2 row 17), so the semantics are fixed here, per clip,
+    following what ``get_batch`` does for its one clip: the last ``past_len`` predicted frames become the next window's
+    past, translated so that the pelvis of their first frame is the origin (orientation untouched: rotation = I upstream),
+    future frames padded with the last past frame, new conditioning through ``_get_embeddings``, sample, translate back,
+    append the window's future frames.  Every clip keeps its chain on its own GPU: no exchange between ranks.
+    Returns (obj [T+K*F,B,6], body [T+K*F,B,159], verts, jtr, pelvis) in the first window's coordinate frame."""
+    smpl = correction.smpl
+    T = raw['body_pose'].shape[0]
+    fut = T - past_len
+    def run(bt, sd):
+        nz = torch.randn(bt['gt'].shape, device=bt['gt'].device, generator=torch.Generator(device=bt['gt'].device).manual_seed(sd))
+        if mode == 'correction':
+            return sample_once_proj(model, diffusion, correction, bt, past_len, noise=nz, seed=sd, **loop_kw)
+        return sample_once(model, diffusion, smpl, bt, past_len, noise=nz, seed=sd, **loop_kw)
+    obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len), seed)
+    for k in range(windows):
+        pb, po = body[-past_len:], obj[-past_len:]
+        centroid = pelvis[-past_len].clone()                                        # [B,3] origin of the next window
+        pad = lambda a: torch.cat([a, a[-1:].expand(fut, *a.shape[1:])], dim=0).contiguous()
+        nxt = dict(body_pose=pad(pb[..., :66]), hand_pose=pad(pb[..., 66:156]), body_trans=pad(pb[..., -3:] - centroid),
+                   obj_angles=pad(po[..., :3]), obj_trans=pad(po[..., 3:] - centroid), beta=raw['beta'], obj_points=raw['obj_points'])
+        o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len), seed + 1 + k)
+        o, b_ = o.clone(), b_.clone()
+        o[..., 3:] += centroid
+        b_[..., -3:] += centroid
+        v, j, p = v + centroid[None, :, None, :], j + centroid[None, :, None, :], p + centroid
+        obj, body = torch.cat([obj, o[past_len:]], dim=0), torch.cat([body, b_[past_len:]], dim=0)
+        verts, jtr, pelvis = torch.cat([verts, v[past_len:]], dim=0), torch.cat([jtr, j[past_len:]], dim=0), torch.cat([pelvis, p[past_len:]], dim=0)
+    return obj, body, verts, jtr, pelvis
+
+
 class Metrics:
     """``metrics(obj_pred, body_jtr, body, obj_gt, body_jtr_gt, body_gt, verts, faces, obj_points)`` (:24-81) on
     ``interdiff_metrics``; owns its workspace.  ``correction`` supplies the mesh topology / packed SMPL handle."""

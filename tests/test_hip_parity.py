@@ -378,3 +378,30 @@ def test_get_embeddings_golden(mdm):
     x, ts, _ = fx.mdm_inputs(3, 35)
     close(mdm(x.to(DEV), ts.to(DEV), y={'cond': cond}), oden.mdm_forward(fx.mdm_weights(), x, ts, torch.from_numpy(z['cond'])), 1e-4,
           'decoder on the HIP conditioning')
+
+
+def test_long_horizon_rollout(mdm, smpl):
+    """Autoregressive rollout (BASELINE config #4; upstream path is broken, semantics fixed in eval.sample_long): window 0 is
+    the short-horizon sample, every appended window is consistent with the body model in the first window's frame, and the
+    chain is translation-covariant from window 1 on (each window is re-centred on its own first pelvis)."""
+    from interdiff_amd import eval as ev, synthetic as syn
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P, past, steps, K = 14, 2, 128, fx.PAST, 20, 2
+    ei = {k: torch.from_numpy(v).to(DEV) for k, v in syn.make_embedding_inputs(seed=5, B=B, T=T, n_points=P).items()}
+    g = torch.Generator().manual_seed(2)
+    raw = dict(ei, hand_pose=(0.1 * torch.randn(T, B, 90, generator=g)).to(DEV), beta=torch.randn(1, B, 10, generator=g).expand(T, B, 10).contiguous().to(DEV))
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=steps)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', steps)
+    obj, body, verts, jtr, pelvis = ev.sample_long(model, diff, corr, raw, K, past, seed=11)
+    F = T - past
+    assert obj.shape == (T + K * F, B, 6) and body.shape == (T + K * F, B, 159) and verts.shape[0] == T + K * F
+    assert torch.isfinite(verts).all()
+    nz = torch.randn(B, 1, 144, T, device=DEV, generator=torch.Generator(device=DEV).manual_seed(11))
+    o0, b0, v0, j0, p0 = ev.sample_once_proj(model, diff, corr, ev.batch_from_raw(model, raw, past), past, noise=nz, seed=11)
+    assert torch.equal(obj[:T], o0) and torch.equal(verts[:T], v0)
+    assert torch.equal(pelvis, jtr[:, :, 0])
+    flat = body.reshape(-1, 159)
+    v_chk, j_chk, _, _ = smpl(flat[:, :-3], th_betas=raw['beta'][:1].expand(T + K * F, B, 10).reshape(-1, 10), th_trans=flat[:, -3:])
+    close(v_chk.reshape(verts.shape), verts, 1e-5, 'appended windows are SMPL(body) in the first window frame')

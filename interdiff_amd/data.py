@@ -1,0 +1,125 @@
+"""BEHAVE clip ETL ("next" row N2 of SURVEY.md §8(f)): on-disk sequence -> canonicalised clip batch in the tensor schema the
+HIP path consumes (``eval.batch_from_raw``).
+
+Restates data/dataset_smpl.py:44-56 (files: ``smpl_fit_all.npz`` {poses [F,156], betas [F,10], trans [F,3]},
+``object_fit_all.npz`` {angles [F,3], trans [F,3], frame_times}), :93-100 (test windows: consecutive fragments of
+past_len + future_len frames) and :105-204 (``__getitem__``: every clip is expressed in the frame of its first pose --
+origin at the first pelvis, yaw of the first global orientation removed).  Host-side numpy/scipy like the reference (this is
+dataset plumbing, not the hot path); the one heavy step, the per-frame pelvis = SMPL joint 0 over the whole sequence
+(:57,68), runs on the GPU through ``SMPL_Layer``.  Contact labels / per-vertex data / rendering inputs of the reference
+records are not produced (the sampler never reads them)."""
+import os
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+
+def load_behave_sequence(seq_dir):
+    """data/dataset_smpl.py:44-47."""
+    with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
+        obj_angles, obj_trans = f['angles'], f['trans']
+    with np.load(os.path.join(seq_dir, 'smpl_fit_all.npz'), allow_pickle=True) as f:
+        poses, betas, trans = f['poses'], f['betas'], f['trans']
+    n = min(len(poses), len(obj_angles))
+    return dict(poses=poses[:n], betas=betas[:n], trans=trans[:n], obj_angles=obj_angles[:n], obj_trans=obj_trans[:n], seq_name=os.path.basename(seq_dir))
+
+
+def load_ply_vertices(path):
+    """Vertices of an ASCII or binary-little-endian PLY (e.g. objects/backpack/backpack_f1000.ply), centred like
+    prepare_behave.py:89-94 centres the template (mean of the vertices)."""
+    with open(path, 'rb') as f:
+        header, fmt, nv, props = [], None, 0, []
+        in_vertex = False
+        while True:
+            line = f.readline().decode('ascii', 'ignore').strip()
+            header.append(line)
+            if line.startswith('format'):
+                fmt = line.split()[1]
+            elif line.startswith('element'):
+                in_vertex = line.split()[1] == 'vertex'
+                if in_vertex:
+                    nv = int(line.split()[2])
+            elif line.startswith('property') and in_vertex:
+                props.append((line.split()[1], line.split()[2]))
+            elif line == 'end_header':
+                break
+        if fmt == 'ascii':
+            rows = [f.readline().split() for _ in range(nv)]
+            v = np.array([[float(r[0]), float(r[1]), float(r[2])] for r in rows], dtype=np.float64)
+        else:
+            np_t = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'float64': '<f8', 'uchar': 'u1', 'uint8': 'u1', 'int': '<i4', 'uint': '<u4',
+                    'short': '<i2', 'ushort': '<u2', 'char': 'i1'}
+            dt = np.dtype([(name, np_t[t]) for t, name in props])
+            rec = np.frombuffer(f.read(nv * dt.itemsize), dtype=dt, count=nv)
+            v = np.stack([rec['x'], rec['y'], rec['z']], axis=1).astype(np.float64)
+    return v - v.mean(0)
+
+
+def sample_points(vertices, n, seed=0):
+    """n object points from the template vertices (the reference samples the SURFACE with trimesh at preparation time,
+    prepare_behave.py:89-94,130 -- not reproducible here; vertices are repeated / sub-sampled deterministically instead)."""
+    rs = np.random.RandomState(seed)
+    idx = rs.permutation(len(vertices))[:n] if len(vertices) >= n else np.concatenate([np.arange(len(vertices)), rs.randint(0, len(vertices), n - len(vertices))])
+    return vertices[idx].astype(np.float32)
+
+
+def sequence_pelvis(seq, smpl, device='cuda', chunk=512):
+    """Joint 0 of SMPL over every frame (data/dataset_smpl.py:57,68), on the GPU."""
+    out = []
+    for s in range(0, len(seq['poses']), chunk):
+        pose = torch.from_numpy(np.asarray(seq['poses'][s:s + chunk], dtype=np.float32)).to(device)
+        betas = torch.from_numpy(np.asarray(seq['betas'][s:s + chunk], dtype=np.float32)).to(device)
+        trans = torch.from_numpy(np.asarray(seq['trans'][s:s + chunk], dtype=np.float32)).to(device)
+        out.append(smpl(pose, th_betas=betas, th_trans=trans, want_v_posed=False)[1][:, 0].cpu().numpy())
+    return np.float32(np.concatenate(out))
+
+
+def test_windows(n_frames, past_len, future_len, sample_rate=1):
+    """Start frames of the test split (data/dataset_smpl.py:93-96: one clip per fragment, offset 0)."""
+    fragment = (past_len + future_len) * sample_rate
+    return [i * fragment for i in range(n_frames // fragment)]
+
+
+def canonicalize_clip(seq, pelvis, start, past_len, future_len, sample_rate=1):
+    """data/dataset_smpl.py:105-160: the clip [start, start + T*rate) in the frame of its first pose.
+    Returns dict(pose [T,156], trans [T,3], betas [T,10], obj_angles [T,3], obj_trans [T,3], pelvis [T,3], centroid, rotation)."""
+    T = past_len + future_len
+    out = {k: [] for k in ('pose', 'trans', 'betas', 'obj_angles', 'obj_trans', 'pelvis')}
+    centroid = rotation = None
+    for i in range(start, start + T * sample_rate, sample_rate):
+        pose, trans = seq['poses'][i].copy(), seq['trans'][i].copy()
+        angle, otrans = seq['obj_angles'][i].copy(), seq['obj_trans'][i].copy()
+        pel = pelvis[i].copy()
+        if i == start:
+            centroid = pel
+            go = Rotation.from_rotvec(pose[:3]).as_matrix()
+            nrm = np.sqrt(go[0, 0] ** 2 + go[2, 0] ** 2)
+            cos, sin = go[0, 0] / nrm, go[2, 0] / nrm
+            rotation_v = np.eye(3).astype(np.float32)
+            rotation_v[[0, 2, 0, 2], [0, 2, 2, 0]] = np.array([cos, cos, -sin, sin])
+            rotation = np.linalg.inv(rotation_v).astype(np.float32)
+        trans = trans - centroid
+        pel = pel - centroid
+        pel_orig = pel - trans                                   # pelvis position in the original smpl coordinate system
+        trans = np.dot(trans + pel_orig, rotation.T) - pel_orig
+        pel = np.dot(pel, rotation.T)
+        pose[:3] = (Rotation.from_matrix(rotation) * Rotation.from_rotvec(pose[:3])).as_rotvec()
+        otrans = np.dot(otrans - centroid, rotation.T)
+        angle = (Rotation.from_matrix(rotation) * Rotation.from_rotvec(angle)).as_rotvec()
+        for k, v in (('pose', pose), ('trans', trans), ('betas', seq['betas'][i]), ('obj_angles', angle), ('obj_trans', otrans), ('pelvis', pel)):
+            out[k].append(np.asarray(v))
+    res = {k: np.stack(v) for k, v in out.items()}
+    res.update(centroid=centroid, rotation=rotation)
+    return res
+
+
+def collate_raw(clips, obj_points, device='cuda'):
+    """List of canonicalised clips (same T) + object points [P,3] or [B,P,3] -> the ``raw`` dict of eval.batch_from_raw:
+    body_pose [T,B,66], hand_pose [T,B,90], body_trans, obj_angles, obj_trans [T,B,3], beta [T,B,10], obj_points [B,P,3]."""
+    st = lambda k: torch.from_numpy(np.stack([np.asarray(c[k], dtype=np.float32) for c in clips], axis=1)).to(device)
+    pose = st('pose')
+    pts = np.asarray(obj_points, dtype=np.float32)
+    if pts.ndim == 2:
+        pts = np.repeat(pts[None], len(clips), axis=0)
+    return dict(body_pose=pose[..., :66].contiguous(), hand_pose=pose[..., 66:].contiguous(), body_trans=st('trans'), obj_angles=st('obj_angles'),
+                obj_trans=st('obj_trans'), beta=st('betas'), obj_points=torch.from_numpy(pts).to(device))

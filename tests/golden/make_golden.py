@@ -19,6 +19,8 @@ What each fixture pins (reference file:line in brackets):
                    the reference denoised_fn, injected per-step noise [gaussian_diffusion.py:598-736]
   embed.npz        MDM._get_embeddings: the reference's own embedding / encoder code around the PointNet++ stub
                    (sampling and grouping indices from oracle/pointnet2.py: parity unpinned) [model/diffusion_smpl.py:195-223]
+  etl.npz          data/dataset_smpl.py Dataset.__getitem__ (clip canonicalisation) on three windows of the shipped BEHAVE
+                   sequence Date01_Sub01_backpack_back; inputs (the windows' raw frames) are stored next to the outputs
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
@@ -183,6 +185,47 @@ def main():
           'obj_points': torch.cat([ei['obj_points'], torch.zeros(B, P, 3)], dim=2)}
     cond, gt = type(net)._get_embeddings(net, rb, None)
     save('embed.npz', cond=np_(cond), gt=np_(gt))
+
+    # ---- ETL: the reference Dataset.__getitem__ on the one real sequence (records built by hand: __init__ needs the
+    # licensed SMPL-H pkl and contact.npz / info.json which are not shipped); pelvis = joint 0 of the synthetic body model
+    import importlib
+    from oracle import smpl as osmpl
+    sys.modules.pop('data.dataset_smpl', None)
+    dsm = importlib.import_module('data.dataset_smpl')
+    seq_dir = '/root/reference/interdiff/data/behave/sequence/Date01_Sub01_backpack_back'
+    with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
+        o_ang, o_tr = f['angles'], f['trans']
+    with np.load(os.path.join(seq_dir, 'smpl_fit_all.npz'), allow_pickle=True) as f:
+        poses, betas, trans = f['poses'], f['betas'], f['trans']
+    past, fut = fx.PAST, 25
+    Tw = past + fut
+    starts = [0, 35, 700]
+    sel = np.concatenate([np.arange(s0, s0 + Tw) for s0 in starts])
+    pel = np.zeros((len(poses), 3), np.float32)
+    pel[sel] = np_(osmpl.smpl_forward(model, torch.from_numpy(poses[sel]), torch.from_numpy(betas[sel]), torch.from_numpy(trans[sel]))[1][:, 0])
+
+    class Lazy:                                            # per-frame arrays the sampler never reads
+        def __init__(self, shape): self.shape = shape
+        def __getitem__(self, i): return np.zeros(self.shape, np.float32)
+    ds = dsm.Dataset.__new__(dsm.Dataset)
+    ds.past_len, ds.future_len, ds.sample_rate, ds.num_verts = past, fut, 1, 6890
+    ds.data = [dict(gender='male', obj_name='backpack', obj_angles=o_ang, obj_trans=o_tr, poses=poses, betas=betas, trans=trans, pelvis=pel,
+                    left_foot=pel, right_foot=pel, seq_name='Date01_Sub01_backpack_back', obj_points=np.zeros((8, 6), np.float32),
+                    obj_contact_label=Lazy((0,)).__class__((0,)), human_verts=Lazy((6890, 6)), contact_label=Lazy((0,)),
+                    ground_joint_label=np.full(len(poses), 10))]
+    ds.data[0]['obj_contact_label'] = [np.zeros(0, np.int64)] * len(poses)
+    ds.data[0]['contact_label'] = [np.zeros(0, np.int64)] * len(poses)
+    ds.idx2frame = [(0, s0, 1) for s0 in starts]
+    out = dict(starts=np.array(starts), sel=sel, poses=poses[sel], betas=betas[sel], trans=trans[sel], obj_angles=o_ang[sel], obj_trans=o_tr[sel], pelvis=pel[sel])
+    for w in range(len(starts)):
+        rec = ds[w]
+        out['pose_%d' % w] = np.stack([fr['smplfit_params']['pose'] for fr in rec['frames']])
+        out['trans_%d' % w] = np.stack([fr['smplfit_params']['trans'] for fr in rec['frames']])
+        out['angle_%d' % w] = np.stack([fr['objfit_params']['angle'] for fr in rec['frames']])
+        out['otrans_%d' % w] = np.stack([fr['objfit_params']['trans'] for fr in rec['frames']])
+        out['pelvis_%d' % w] = np.stack([fr['pelvis'] for fr in rec['frames']])
+        out['centroid_%d' % w], out['rotation_%d' % w] = rec['centroid'], rec['rotation']
+    save('etl.npz', **out)
 
     # ---- eval glue: the reference's sample_once_proj / get_gt / metrics on a tiny clip, 50-step schedule.
     # The dataset batch and the encoder (_get_embeddings: a "next" row) are stand-ins that hand back our tensors.

@@ -100,3 +100,44 @@ def test_gloo_sharding_world2():
     import torch.multiprocessing as mp
     from interdiff_amd import dist as idist
     mp.spawn(idist._selftest_worker, args=(2, 29517), nprocs=2, join=True)
+
+
+def test_behave_etl_matches_reference_dataset(tmp_path):
+    """"Next" row N2: clip canonicalisation + file formats + windows of interdiff_amd/data.py against the reference's own
+    Dataset.__getitem__ on three windows of the shipped BEHAVE sequence (tests/golden/etl.npz holds the raw frames and the
+    reference's outputs)."""
+    import numpy as np
+    from interdiff_amd import data as D
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'etl.npz'))
+    sel, starts = z['sel'], z['starts']
+    F = int(sel.max()) + 1
+    full = lambda a: _scatter(F, sel, a)
+    seq = dict(poses=full(z['poses']), betas=full(z['betas']), trans=full(z['trans']), obj_angles=full(z['obj_angles']), obj_trans=full(z['obj_trans']))
+    pelvis = full(z['pelvis'])
+    # round trip through the on-disk format the loader expects
+    d = tmp_path / 'Date01_Sub01_backpack_back'
+    d.mkdir()
+    np.savez(d / 'smpl_fit_all.npz', poses=seq['poses'], betas=seq['betas'], trans=seq['trans'])
+    np.savez(d / 'object_fit_all.npz', angles=seq['obj_angles'], trans=seq['obj_trans'], frame_times=np.arange(F))
+    loaded = D.load_behave_sequence(str(d))
+    assert all(np.array_equal(loaded[k], seq[k]) for k in seq)
+    assert D.test_windows(1408, 10, 25)[:3] == [0, 35, 70] and len(D.test_windows(1408, 10, 25)) == 40
+    for w, s0 in enumerate(starts):
+        c = D.canonicalize_clip(loaded, pelvis, int(s0), 10, 25)
+        for ours, ref in (('pose', 'pose_%d'), ('trans', 'trans_%d'), ('obj_angles', 'angle_%d'), ('obj_trans', 'otrans_%d'), ('pelvis', 'pelvis_%d')):
+            a, b = np.asarray(c[ours], np.float64), z[ref % w].astype(np.float64)
+            assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max()), (ours, w, np.abs(a - b).max())
+        assert np.allclose(c['centroid'], z['centroid_%d' % w]) and np.allclose(c['rotation'], z['rotation_%d' % w])
+        assert np.abs(c['pelvis'][0]).max() < 1e-6                                   # first pelvis is the origin
+        R0 = __import__('scipy.spatial.transform', fromlist=['Rotation']).Rotation.from_rotvec(c['pose'][0, :3]).as_matrix()
+        assert abs(R0[2, 0]) < 1e-5                                                   # yaw of the first frame removed
+    clips = [D.canonicalize_clip(loaded, pelvis, int(s0), 10, 25) for s0 in starts]
+    raw = D.collate_raw(clips, np.zeros((64, 3), np.float32), device='cpu')
+    assert raw['body_pose'].shape == (35, 3, 66) and raw['hand_pose'].shape == (35, 3, 90) and raw['obj_points'].shape == (3, 64, 3)
+
+
+def _scatter(F, sel, a):
+    import numpy as np
+    out = np.zeros((F,) + a.shape[1:], a.dtype)
+    out[sel] = a
+    return out

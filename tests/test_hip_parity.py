@@ -405,3 +405,38 @@ def test_long_horizon_rollout(mdm, smpl):
     flat = body.reshape(-1, 159)
     v_chk, j_chk, _, _ = smpl(flat[:, :-3], th_betas=raw['beta'][:1].expand(T + K * F, B, 10).reshape(-1, 10), th_trans=flat[:, -3:])
     close(v_chk.reshape(verts.shape), verts, 1e-5, 'appended windows are SMPL(body) in the first window frame')
+
+
+def test_real_behave_clips_end_to_end(mdm, smpl):
+    """Rows N2 -> N1 -> sampler -> correction -> metrics on REAL BEHAVE motion (three windows of the shipped sequence, stored in
+    tests/golden/etl.npz): on-GPU pelvis for the ETL, canonicalised clips, HIP conditioning, a short diffusion with the
+    correction hook, metrics against the clips' own ground truth."""
+    from interdiff_amd import data as D, eval as ev, synthetic as syn
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    z = fx.golden('etl.npz')
+    sel, starts = z['sel'], z['starts']
+    F = int(sel.max()) + 1
+    def full(a):
+        out = np.zeros((F,) + a.shape[1:], a.dtype)
+        out[sel] = a
+        return out
+    seq = dict(poses=full(z['poses']), betas=full(z['betas']), trans=full(z['trans']), obj_angles=full(z['obj_angles']), obj_trans=full(z['obj_trans']))
+    pelvis = D.sequence_pelvis(seq, smpl, device=DEV)
+    close(pelvis[sel], z['pelvis'], 1e-5, 'pelvis of the sequence (HIP SMPL) vs the oracle pelvis used for the golden')
+    past, fut, P, steps = 10, 25, 256, 20
+    clips = [D.canonicalize_clip(seq, pelvis, int(s0), past, fut) for s0 in starts]
+    pts = syn.make_embedding_inputs(seed=3, B=1, T=2, n_points=P)['obj_points'][0]
+    raw = D.collate_raw(clips, pts, device=DEV)
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=steps)
+    corr = make_correction(smpl, past + fut, P)
+    diff = create_gaussian_diffusion('cosine', steps)
+    batch = ev.batch_from_raw(model, raw, past)
+    # tokens of the past frames must survive the round trip through the sampler's inpainting untouched
+    obj, body, verts, jtr, pelvis_s = ev.sample_once_proj(model, diff, corr, batch, past, seed=4)
+    obj_gt, jtr_gt, body_gt, faces = ev.get_gt(batch, smpl)
+    close(jtr[:past], jtr_gt[:past], 1e-5, 'past frames are the ground truth')
+    close(body_gt[..., 66:156], raw['hand_pose'], 0, 'hands pass through')
+    m = ev.Metrics(corr)(obj[past:], jtr[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces, raw['obj_points'])
+    assert all(torch.isfinite(v).all() and v.shape == (3,) for v in m.values())
+    assert (m['penetrate'] >= 0).all() and (m['penetrate'] <= 1).all()

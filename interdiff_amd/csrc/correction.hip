@@ -77,12 +77,12 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 }
 
 // ---- K4: per-frame contact analysis -------------------------------------------------------------------
-// One workgroup (CT threads = 8 waves, two per SIMD) per frame; every thread owns QP object points as QP/2 PACKED
+// One workgroup (CT threads = 16 waves, four per SIMD) per frame; every thread owns QP object points as QP/2 PACKED
 // pairs: the exact-arithmetic distance (dx*dx + dy*dy) + dz*dz of a pair against the LDS-broadcast vertex is
 // 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add (no FMA contraction, so the argmin is bit-identical to geometry.hip
 // and to the oracle), then compare + 2 selects per point.
-constexpr int CT = 512;                // threads per workgroup
-constexpr int QP = 4;                  // object points per thread (P <= CT*QP = 2048)
+constexpr int CT = 1024;               // threads per workgroup
+constexpr int QP = 2;                  // object points per thread (P <= CT*QP = 2048)
 constexpr int MAXM = 128;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -236,11 +236,11 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
                    int32_t *label, float *o2h, int64_t nn_from) {
     const int M = c->n_markers;
     const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
-    if (lds > 160 * 1024 - 4096) return IDF_E_INVAL;
+    if (lds > 160 * 1024 - 8192) return IDF_E_INVAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 4096) != hipSuccess)
+                                160 * 1024 - 8192) != hipSuccess)
             return IDF_E_LAUNCH;
         attr_set = true;
     }

@@ -48,7 +48,7 @@ def _sinc_half(angle):
 
 
 def axis_angle_to_quaternion(aa):
-    ang = torch.sqrt((aa * aa).sum(-1, keepdim=True))
+    ang = torch.norm(aa, p=2, dim=-1, keepdim=True)            # torch.norm: zero subgradient at the origin (autograd users)
     return torch.cat([torch.cos(ang * 0.5), aa * _sinc_half(ang)], dim=-1)
 
 
@@ -67,6 +67,15 @@ def axis_angle_to_matrix(aa):
     return quaternion_to_matrix(axis_angle_to_quaternion(aa))
 
 
+def _sqrt_positive_part(x):
+    """sqrt(max(0, x)) with a ZERO subgradient where x <= 0 (pytorch3d's helper of the same name; matters only for
+    autograd -- oracle/optimization.py -- the forward values equal sqrt(clamp(x, 0)))."""
+    ret = torch.zeros_like(x)
+    pos = x > 0
+    ret[pos] = torch.sqrt(x[pos])
+    return ret
+
+
 def matrix_to_quaternion(m):
     """Four-candidate method of 0.7.2 (floor 0.1, argmax pick, NO sign
     standardisation of w)."""
@@ -75,7 +84,7 @@ def matrix_to_quaternion(m):
     m20, m21, m22 = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
     tr = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22,
                       1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
-    q_abs = torch.sqrt(torch.clamp(tr, min=0.0))
+    q_abs = _sqrt_positive_part(tr)
     cand = torch.stack([
         torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
         torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
@@ -89,7 +98,7 @@ def matrix_to_quaternion(m):
 
 
 def quaternion_to_axis_angle(q):
-    n = torch.sqrt((q[..., 1:] * q[..., 1:]).sum(-1, keepdim=True))
+    n = torch.norm(q[..., 1:], p=2, dim=-1, keepdim=True)
     half = torch.atan2(n, q[..., 0:1])
     ang = 2.0 * half
     return q[..., 1:] / _sinc_half(ang)

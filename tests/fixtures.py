@@ -145,3 +145,25 @@ EMB_SHAPE = (35, 3, 2048)              # T, B, P : MDM._get_embeddings (encoder 
 def embedding_inputs():
     T, B, P = EMB_SHAPE
     return {k: _t(v) for k, v in syn.make_embedding_inputs(seed=77, B=B, T=T, n_points=P).items()}
+
+
+OPT_SHAPE = (12, 96)                   # T, P : physics post-optimisation ("next" row N4), one clip
+OPT_ITERS = (151, 152, 153, 154)       # iteration numbers ii the golden run executes (ratio = ii/350, saving starts after 150)
+
+
+def optim_inputs(seed=9000, T=None, P=None):
+    """One clip in optimization.py's schema: pose [T,156] axis-angle, trans, obj_angles, obj_trans [T,3], betas [T,10],
+    obj_points [P,3].  Slow motion (some foot frames are 'static'), a few hand joints exactly at the identity, the object
+    overlapping the body so that the collision term and both contact-radius cases are exercised."""
+    T = T or OPT_SHAPE[0]
+    P = P or OPT_SHAPE[1]
+    rs = np.random.RandomState(seed)
+    pose = 0.3 * rs.standard_normal((1, 156)) + np.cumsum(0.004 * rs.standard_normal((T, 156)), axis=0)
+    pose[:, 66 + 9:66 + 18] = 0.0                                   # three hand joints at exactly zero rotation
+    pose[:, :3] = np.array([2.9, 0.5, -0.3]) + np.cumsum(0.004 * rs.standard_normal((T, 3)), axis=0)   # root angle near pi (BEHAVE-like)
+    trans = 0.1 * rs.standard_normal((1, 3)) + np.cumsum(0.002 * rs.standard_normal((T, 3)), axis=0)
+    obj_angles = rs.standard_normal((1, 3)) + np.cumsum(0.02 * rs.standard_normal((T, 3)), axis=0)
+    obj_trans = trans + np.array([0.25, 0.1, -0.2]) + np.cumsum(0.004 * rs.standard_normal((T, 3)), axis=0)
+    betas = np.repeat(rs.standard_normal((1, 10)), T, axis=0)
+    obj_points = rs.uniform(-0.25, 0.25, (P, 3))
+    return tuple(_t(np.float32(a)) for a in (pose, trans, obj_angles, obj_trans, betas, obj_points))

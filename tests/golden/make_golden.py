@@ -21,6 +21,9 @@ What each fixture pins (reference file:line in brackets):
                    (sampling and grouping indices from oracle/pointnet2.py: parity unpinned) [model/diffusion_smpl.py:195-223]
   etl.npz          data/dataset_smpl.py Dataset.__getitem__ (clip canonicalisation) on three windows of the shipped BEHAVE
                    sequence Date01_Sub01_backpack_back; inputs (the windows' raw frames) are stored next to the outputs
+  optim.npz        optimization.optimize (physics post-optimisation, "next" row N4) on one synthetic clip, restricted to the
+                   iteration numbers fx.OPT_ITERS: its printed losses, the parameters and gradients its Adam sees at each of
+                   them, the parameters after the last, and the record it returns [optimization.py:19-173]
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
@@ -95,7 +98,61 @@ def ref_objproj(T, past_len=10):
     return op
 
 
+def gen_optim():
+    """Run the reference's optimize() (optimization.py:19-173) on fx.optim_inputs().  Patches, all outside the arithmetic:
+    SMPL_Layer(model files) -> the reference layer class filled with the synthetic model; ``range`` inside the module ->
+    the iteration numbers fx.OPT_ITERS; optim.Adam -> the same Adam, recording the gradients / parameters it is handed."""
+    import io
+    import contextlib
+    import builtins
+    refshim.install()
+    opt = refshim.load('optimization')
+    model = fx.smpl_model()
+    L = ref_smpl(model)
+    L.center_idx = 0
+    opt.SMPL_Layer = lambda **kw: L
+    opt.range = lambda n: list(fx.OPT_ITERS) if n == 200 else builtins.range(n)
+    rec = {}
+
+    class Adam(torch.optim.Adam):
+        def step(self, *a, **k):
+            ps = self.param_groups[0]['params']
+            rec.setdefault('grads', []).append([p.grad.detach().clone() for p in ps])
+            rec.setdefault('before', []).append([p.detach().clone() for p in ps])
+            r = super().step(*a, **k)
+            rec['params'] = [p.detach().clone() for p in ps]
+            return r
+    opt.optim = Namespace(Adam=Adam)
+    pose, trans, obj_angles, obj_trans, betas, obj_points = fx.optim_inputs()
+    T = pose.shape[0]
+    data = dict(gender='male', obj_name='backpack', start_frame=0,
+                obj_points=np.concatenate([np_(obj_points), np.zeros_like(np_(obj_points))], axis=1),
+                frames=[dict(smplfit_params=dict(pose=np_(pose[t]), trans=np_(trans[t]), betas=np_(betas[t])),
+                             objfit_params=dict(angle=np_(obj_angles[t]), trans=np_(obj_trans[t]))) for t in range(T)])
+    buf = io.StringIO()
+    with torch.enable_grad(), contextlib.redirect_stdout(buf):
+        out = opt.optimize(0, data)
+    losses = []
+    for line in buf.getvalue().strip().splitlines():
+        parts = [q for q in line.split('|') if ':' in q]
+        losses.append([float(q.split(':')[1]) for q in parts])
+    names = ('body', 'transl', 'glo', 'obj_transl', 'obj_rot', 'hand')         # optimization.py:136
+    res = dict(losses=np.array(losses, np.float64))
+    for i, n in enumerate(names):           # grad_/before_ [K, ...]: what Adam was handed at each executed iteration; param_: after the last
+        res['grad_' + n] = np.stack([np_(g[i]) for g in rec['grads']])
+        res['before_' + n] = np.stack([np_(g[i]) for g in rec['before']])
+        res['param_' + n] = np_(rec['params'][i])
+    res['pose'] = np.stack([fr['smplfit_params']['pose'] for fr in out['frames']])
+    res['trans'] = np.stack([fr['smplfit_params']['trans'] for fr in out['frames']])
+    res['obj_angles'] = np.stack([fr['objfit_params']['angle'] for fr in out['frames']])
+    res['obj_trans'] = np.stack([fr['objfit_params']['trans'] for fr in out['frames']])
+    print(res['losses'])
+    save('optim.npz', **res)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'optim':
+        return gen_optim()
     # ---- real correction checkpoint -> plain arrays (must exist before fx.objproj_weights())
     ck = torch.load('/root/reference/interdiff/checkpoints/correction.ckpt', map_location='cpu', weights_only=False)
     save('correction_ckpt.npz', **{k[len('model.'):]: np_(v) for k, v in ck['state_dict'].items()})
@@ -190,7 +247,6 @@ def main():
     # licensed SMPL-H pkl and contact.npz / info.json which are not shipped); pelvis = joint 0 of the synthetic body model
     import importlib
     from oracle import smpl as osmpl
-    sys.modules.pop('data.dataset_smpl', None)
     dsm = importlib.import_module('data.dataset_smpl')
     seq_dir = '/root/reference/interdiff/data/behave/sequence/Date01_Sub01_backpack_back'
     with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:

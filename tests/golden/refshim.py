@@ -104,7 +104,7 @@ def install():
     pl.loggers = mod('pytorch_lightning.loggers')
     ps = mod('psbody')
     ps.mesh = mod('psbody.mesh', Mesh=None)
-    mod('data.dataset_smpl', Dataset=None, OBJECT_PATH='')
+    mod('data.dataset_smpl', Dataset=None, OBJECT_PATH='', MODEL_PATH='')
     rd = mod('render')
     rd.mesh_viz = mod('render.mesh_viz', visualize_body_obj=None)
     mod('train_correction_smpl', LitInteraction=None)

@@ -193,3 +193,24 @@ def test_get_embeddings_encoder_side():
     for m in range(5):
         hits = torch.nonzero(((xyz[0] - xyz[0, m]) ** 2).sum(-1) < 0.01)[:, 0][:16]
         assert torch.equal(bq[0, m, :len(hits)], hits) and (bq[0, m, len(hits):] == hits[0]).all()
+
+
+def test_optimization_golden():
+    """oracle/optimization.py against the reference's own optimize() (optimization.py:19-173) run on the same clip:
+    losses and gradients at the parameters the reference's Adam saw.  Iteration 1 starts AT the initial pose, where
+    verts - verts_gt is rounding noise and its sign (the verts_reg gradient, 0.01/T per vertex) is implementation noise:
+    gradients are compared from the second executed iteration on."""
+    from oracle import optimization as oo
+    g = fx.golden('optim.npz')
+    model = fx.smpl_model()
+    inp = fx.optim_inputs()
+    for k, ii in enumerate(fx.OPT_ITERS[:3]):
+        params = {n: torch.from_numpy(g['before_' + n][k]) for n in oo.PARAM_ORDER}
+        parts, grads = oo.loss_and_grads(model, params, *inp, ii)
+        np.testing.assert_allclose(parts.numpy(), g['losses'][k], atol=6e-5, rtol=2e-5)       # printed with 4 decimals
+        if k == 0:
+            continue
+        for n in oo.PARAM_ORDER:
+            ref = g['grad_' + n][k]
+            assert np.abs(grads[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, n
+            assert ((grads[n].numpy() == 0) == (ref == 0)).all(), n                             # exact-zero pattern (Adam leaves those untouched)

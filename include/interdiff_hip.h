@@ -270,6 +270,73 @@ int interdiff_metrics(const idf_correction_ctx *c, const float *obj_pred, const 
                       void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Physics post-optimisation ("next" row N4)   replaces optimization.py:19-173 (optimize):
+ * Adam (lr 1e-3) over the rotation MATRICES of the 52 SMPL-H joints and of the object plus the two
+ * translations of every frame, loss = penetration + regularisers + temporal smoothness + static-foot
+ * term (calc_loss, :54-121), hand-written backward (no autograd).  B clips of T frames are optimised
+ * side by side (frame n = b*T + t); the reference does one clip per call.
+ *
+ * Parameter row of a frame, IDF_OPT_NP floats: R[52][9] (global, 21 body, 30 hand joints; row-major
+ * matrices) | body translation [3] | object translation [3] | object rotation [9].
+ * Every pointer of idf_opt_state is DEVICE memory owned by the caller (interdiff_amd/optimize.py
+ * allocates them as torch tensors): nothing is allocated inside the library.
+ * ---------------------------------------------------------------------------------- */
+#define IDF_OPT_NP 483
+#define IDF_OPT_NLOSS 6      /* per-frame partials: collision, verts_reg, feet, reg (L1), reg_v (smoothness), unused */
+typedef struct {
+    const idf_correction_ctx *geo;   /* smpl model, faces, vertex->face adjacency (objproj / markers unused) */
+    const float   *blendT;           /* [KB][K3P] : transpose of smpl->blend, K3P = 3V rounded up to 1024, zero padded */
+    const int32_t *jv_ptr;           /* [J+1]  skinning weights by joint (CSR): entries of joint j are [jv_ptr[j], jv_ptr[j+1]) */
+    const int32_t *jv_vtx;           /* [nnz]  vertex of the entry */
+    const float   *jv_w;             /* [nnz]  weight of the entry */
+    int32_t K3P, _pad;
+} idf_opt_ctx;
+
+typedef struct {
+    int32_t B, T, P, max_iters;
+    /* inputs */
+    const float *betas;              /* [N][10] */
+    const float *obj_points;         /* [B][P][3] canonical object points */
+    /* optimiser state, [N][IDF_OPT_NP] each */
+    float *param, *init, *grad, *m, *v, *best;
+    /* per-iteration scratch */
+    float *pose, *tr;                /* [N][156] axis-angle of param, [N][3] */
+    float *verts, *vposed, *verts_gt, *normals, *gv;     /* [N][V][3] */
+    float *jtr;                      /* [N][J][3] */
+    float *pts, *y2x;                /* [N][P][3] */
+    float *y2x_signed, *x2y_signed;  /* [N][P], [N][V] */
+    int32_t *yidx, *xidx;            /* [N][P], [N][V] */
+    float *dvposed;                  /* [N][K3P]  (columns >= 3V stay zero) */
+    float *dA;                       /* [N][J][12] */
+    float *dfeat;                    /* [K3P/1024][N][KB] split-K partials */
+    float *gtr;                      /* [N][3] */
+    float *lossf;                    /* [N][IDF_OPT_NLOSS] */
+    float *loss;                     /* [B][4] total, collision, reg, reg_v of the last iteration (optimization.py:113-119) */
+    float *loss_hist;                /* [max_iters][B][4] */
+    float *best_loss;                /* [B] */
+    int32_t *flag;                   /* [B] 1 = this iteration is the clip's best so far (after iteration 150, :147) */
+    uint8_t *foot_static;            /* [N][2] frame t vs t+1, left / right foot (:47-52) */
+    int32_t *foot_cnt;               /* [B][2] */
+    int32_t *ctl;                    /* [4]: iteration number ii, Adam steps done, -, - (device side so that steps can be graph-captured) */
+    void *smpl_ws; size_t smpl_ws_bytes;     /* interdiff_smpl_workspace_bytes(smpl, N) */
+} idf_opt_state;
+
+/* pose [N][156] axis-angle, trans / obj_angles / obj_trans [N][3] (optimization.py:20-32) -> param = init, zeroed moments,
+ * verts_gt, static-foot flags; ctl = {first_iter, 0}. */
+int interdiff_optimize_init(const idf_opt_ctx *c, const idf_opt_state *st, const float *pose, const float *trans,
+                            const float *obj_angles, const float *obj_trans, int32_t first_iter, void *stream);
+/* loss + gradient at the current param (grad, loss, lossf are left for inspection); no update. */
+int interdiff_optimize_loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream);
+/* one iteration of the loop at optimization.py:139-165: loss_grad, Adam step, best-iterate bookkeeping, ctl advance. */
+int interdiff_optimize_step(const idf_opt_ctx *c, const idf_opt_state *st, void *stream);
+/* best iterate -> pose [N][156], trans, obj_angles, obj_trans [N][3] (optimization.py:150-172). */
+int interdiff_optimize_finish(const idf_opt_ctx *c, const idf_opt_state *st, float *pose, float *trans, float *obj_angles,
+                              float *obj_trans, void *stream);
+/* HOST-side instance of the device inline that back-propagates through matrix_to_axis_angle + the SMPL Rodrigues for
+ * n joints (R [n][9], g_out [n][9] -> g_in [n][9]); lets the CPU test suite check the derivative code without a GPU. */
+int interdiff_debug_joint_map_vjp(const float *R, const float *g_out, float *g_in, int32_t n);
+
+/* ------------------------------------------------------------------------------------
  * Live per-kernel timing for bench.py's `roofline` block (not on the product path).
  * Between profile_begin and profile_end every kernel launch of the library is preceded by a
  * hipEventRecord on its stream; profile_end synchronises and attributes the time between

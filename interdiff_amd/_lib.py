@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -58,6 +58,20 @@ class CorrectionCtx(C.Structure):
                 ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('_pad', i32)]
 
 
+class OptCtx(C.Structure):
+    _fields_ = [('geo', C.POINTER(CorrectionCtx)), ('blendT', vp), ('jv_ptr', vp), ('jv_vtx', vp), ('jv_w', vp), ('K3P', i32), ('_pad', i32)]
+
+
+OPT_NP, OPT_NLOSS = 483, 6
+_OPT_PTRS = ('betas', 'obj_points', 'param', 'init', 'grad', 'm', 'v', 'best', 'pose', 'tr', 'verts', 'vposed', 'verts_gt', 'normals', 'gv',
+             'jtr', 'pts', 'y2x', 'y2x_signed', 'x2y_signed', 'yidx', 'xidx', 'dvposed', 'dA', 'dfeat', 'gtr', 'lossf', 'loss', 'loss_hist',
+             'best_loss', 'flag', 'foot_static', 'foot_cnt', 'ctl', 'smpl_ws')
+
+
+class OptState(C.Structure):
+    _fields_ = [('B', i32), ('T', i32), ('P', i32), ('max_iters', i32)] + [(k, vp) for k in _OPT_PTRS] + [('smpl_ws_bytes', sz)]
+
+
 _SIGS = {
     'interdiff_abi_version': (C.c_int, []),
     'interdiff_build_info': (C.c_char_p, []),
@@ -92,6 +106,11 @@ _SIGS = {
     'interdiff_metrics_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_metrics': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                     vp, vp, sz, vp]),
+    'interdiff_optimize_init': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp, vp, vp, vp, i32, vp]),
+    'interdiff_optimize_loss_grad': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp]),
+    'interdiff_optimize_step': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp]),
+    'interdiff_optimize_finish': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp, vp, vp, vp, vp]),
+    'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'interdiff_tune': (C.c_int, [i32, i32]),

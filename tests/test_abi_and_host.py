@@ -141,3 +141,33 @@ def _scatter(F, sel, a):
     out = np.zeros((F,) + a.shape[1:], a.dtype)
     out[sel] = a
     return out
+
+
+def test_joint_map_vjp_host_matches_autograd():
+    """The derivative code of csrc/rot_dual.h (rotation -> matrix_to_axis_angle -> SMPL Rodrigues, "next" row N4) is
+    host+device inline; its host instance (interdiff_debug_joint_map_vjp) must equal torch autograd of the oracle,
+    including the exact-zero entries at identity rotations (Adam never moves those)."""
+    import ctypes  # noqa: F401
+    from interdiff_amd import _lib
+    from oracle import rotations as rot
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    n = 64
+    aa = 0.8 * rs.standard_normal((n, 3)).astype(np.float32)
+    aa[0] = 0
+    aa[1] = [3.0, 0.5, -0.3]            # all four quaternion candidates get picked
+    aa[2] = [0, 3.1, 0.2]
+    aa[3] = [0.1, 3.0, 3.0]
+    aa[4] = [1e-4, 0, 0]
+    R = rot.axis_angle_to_matrix(torch.from_numpy(aa))
+    R = R + 2e-3 * torch.from_numpy(rs.standard_normal((n, 3, 3)).astype(np.float32)) * (torch.arange(n) >= 5)[:, None, None]
+    R = R.clone().requires_grad_(True)
+    g = torch.from_numpy(rs.standard_normal((n, 3, 3)).astype(np.float32))
+    with torch.enable_grad():
+        rot.rodrigues_smpl(rot.matrix_to_axis_angle(R)).backward(g)
+    ref = R.grad.numpy().reshape(n, 9)
+    Rn, gn = np.ascontiguousarray(R.detach().numpy().reshape(n, 9)), np.ascontiguousarray(g.numpy().reshape(n, 9))
+    out = np.zeros((n, 9), np.float32)
+    assert lib.interdiff_debug_joint_map_vjp(Rn.ctypes.data, gn.ctypes.data, out.ctypes.data, n) == 0
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert ((out == 0) == (ref == 0)).all()

@@ -159,6 +159,38 @@ def cpu_baseline(assets, bt_cpu, y_cpu):
                 steps_per_sec=steps_per_s)
 
 
+def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
+    """Physics post-optimisation ("next" row N4, optimization.py:19-173) at BASELINE.json configs[4]'s per-GPU share:
+    16 clips x (10 past + 10 future) frames, 2048 object points, the full 200 Adam iterations, clips side by side."""
+    from interdiff_amd.optimize import PhysicsOptimizer
+    keys = ('pose', 'trans', 'obj_angles', 'obj_trans', 'betas', 'obj_points')
+    bt = syn.make_optim_batch(seed=1, B=B, T=T, n_points=n_points)
+    opt = PhysicsOptimizer(smpl, device=dev)
+    batch = [torch.from_numpy(bt[k]).to(dev) for k in keys]
+    opt.optimize(*batch, iters=range(0, 5))
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = opt.optimize(*batch)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    pairs = B * T * n_points * smpl.cmodel.V                       # distances per iteration, each serves both NN questions
+    out = dict(workload='optimization.py: %d clips x %d frames, %d object points, 200 Adam iterations' % (B, T, n_points),
+               ms_per_iteration=best / 200 * 1e3, clips_per_sec=B / best, saved=bool(res['saved'].all()),
+               nn_scan=dict(kernel='opt_nn_kernel', bound='valu', pairs_per_iteration=pairs,
+                            note='62% of an iteration; 17.1 VALU instructions per vertex per thread (2 points, packed fp32), see profiles/'))
+    if with_cpu:
+        from oracle import optimization as oo
+        model = {k: torch.from_numpy(v) for k, v in smpl_np.items()}
+        one = [torch.from_numpy(bt[k][0]) for k in keys]
+        t0 = time.perf_counter()
+        oo.optimize(model, *one, iters=[151])
+        out['cpu_port_s_per_iteration_per_clip'] = time.perf_counter() - t0
+        out['cpu_sample'] = '1 Adam iteration (torch autograd oracle) of 1 clip, %d threads' % torch.get_num_threads()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -166,6 +198,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-postopt', action='store_true')
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     rank, world, local = idist.init_from_env('nccl' if args.gpus > 1 else None)
@@ -213,6 +246,10 @@ def main():
         e1.record()
         e1.synchronize()
         enc_ms = e0.elapsed_time(e1) / 5
+    post = None
+    if rank == 0 and not args.no_postopt:
+        post = postopt_bench(corr.smpl, assets[1], dev, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        log('post-optimisation bench done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(assets, tt({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in bt.items()}),
@@ -250,6 +287,8 @@ def main():
         line['kernels_us_event_to_event'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}    # includes the launch gap + event records
     if enc_ms is not None:
         line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)
+    if post:
+        line['post_optimisation'] = post                    # "next" row N4 (optimization.py), outside the timed region
     if cpu:
         line['cpu_baseline'] = cpu
     print(json.dumps(line))

@@ -301,11 +301,12 @@ typedef struct {
     float *param, *init, *grad, *m, *v, *best;
     /* per-iteration scratch */
     float *pose, *tr;                /* [N][156] axis-angle of param, [N][3] */
-    float *verts, *vposed, *verts_gt, *normals, *gv;     /* [N][V][3] */
+    float *verts, *vposed, *verts_gt, *gv;               /* [N][V][3] */
     float *jtr;                      /* [N][J][3] */
     float *pts, *y2x;                /* [N][P][3] */
-    float *y2x_signed, *x2y_signed;  /* [N][P], [N][V] */
-    int32_t *yidx, *xidx;            /* [N][P], [N][V] */
+    float *y2x_signed;               /* [N][P] signed distance of every object point to its nearest vertex */
+    int32_t *yidx;                   /* [N][P] that vertex */
+    int32_t *near;                   /* [N][V] 1 = some object point within 0.5 m (optimization.py:74-75) */
     float *dvposed;                  /* [N][K3P]  (columns >= 3V stay zero) */
     float *dA;                       /* [N][J][12] */
     float *dfeat;                    /* [K3P/1024][N][KB] split-K partials */

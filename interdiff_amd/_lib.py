@@ -63,8 +63,8 @@ class OptCtx(C.Structure):
 
 
 OPT_NP, OPT_NLOSS = 483, 6
-_OPT_PTRS = ('betas', 'obj_points', 'param', 'init', 'grad', 'm', 'v', 'best', 'pose', 'tr', 'verts', 'vposed', 'verts_gt', 'normals', 'gv',
-             'jtr', 'pts', 'y2x', 'y2x_signed', 'x2y_signed', 'yidx', 'xidx', 'dvposed', 'dA', 'dfeat', 'gtr', 'lossf', 'loss', 'loss_hist',
+_OPT_PTRS = ('betas', 'obj_points', 'param', 'init', 'grad', 'm', 'v', 'best', 'pose', 'tr', 'verts', 'vposed', 'verts_gt', 'gv',
+             'jtr', 'pts', 'y2x', 'y2x_signed', 'yidx', 'near', 'dvposed', 'dA', 'dfeat', 'gtr', 'lossf', 'loss', 'loss_hist',
              'best_loss', 'flag', 'foot_static', 'foot_cnt', 'ctl', 'smpl_ws')
 
 

@@ -1,10 +1,10 @@
 // Physics post-optimisation for gfx950 ("next" row N4 of SURVEY.md §8(f)): optimization.py:19-173 of the reference.
 //
 // The reference runs torch autograd over ~2500 tiny kernels per Adam iteration (Python loops over 52 joints in the SMPL
-// layer, a [T,P,V,3] distance tensor for the contact radius).  Here one iteration is 18 launches with a hand-written
+// layer, a [T,P,V,3] distance tensor for the contact radius).  Here one iteration is 17 launches with a hand-written
 // backward pass:
-//   forward   param -> axis-angle (matrix_to_axis_angle), SMPL (smpl.hip), vertex normals + both nearest-neighbour
-//             searches (geometry.hip);
+//   forward   param -> axis-angle (matrix_to_axis_angle), SMPL (smpl.hip), ONE nearest-neighbour scan for both the
+//             point->vertex argmin and the vertex contact-radius mask, normals only at the nearest vertices;
 //   loss      per frame: penetration term + vertex regulariser, d/dverts staged in LDS (the scatter onto nearest
 //             vertices is an LDS atomic add), d/d object pose reduced in the same workgroup;
 //   skinning^T  per vertex: d/dv_posed = (sum_s w A)^T g ; per (frame, joint): dA = sum_v w g (x) [v_posed;1] over the
@@ -16,6 +16,7 @@
 #include "common.h"
 #include "rot_math.h"
 #include "rot_dual.h"
+#include <cfloat>
 
 namespace {
 
@@ -92,11 +93,130 @@ __global__ __launch_bounds__(256) void opt_objpts_kernel(const float *__restrict
     for (int r = 0; r < 3; ++r) o[r] = (x[0] * R[r * 3] + x[1] * R[r * 3 + 1] + x[2] * R[r * 3 + 2]) + t[r];
 }
 
+// ---- both nearest-neighbour questions of calc_loss in ONE scan (optimization.py:64-65,74-75) ------------------------------
+// point2point_signed needs, per object point, the nearest vertex (tools.py:45-50); the contact-radius mask needs, per
+// vertex, whether ANY object point lies within 0.5 m.  Both read the same P x V distances, so one pass serves both: every
+// thread owns two object points as a packed pair (exact (dx*dx + dy*dy) + dz*dz, no FMA contraction, lowest index wins:
+// the argmin is bit-identical to geometry.hip and to the oracle), vertices stream through LDS in chunks with their id in
+// .w, and the per-vertex "some point is near" bit is a wave ballot folded into a 64-bit scalar mask (SALU work that
+// overlaps the VALU of the other waves), OR-ed into LDS once per 64 vertices.
+constexpr int NN_T = 256, NN_RC = 1024;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ pts, int P, const float *__restrict__ verts, int V,
+                                                      int32_t *__restrict__ yidx, int32_t *__restrict__ near /* [N][V], zeroed */) {
+    __shared__ __attribute__((aligned(16))) float4 rs[NN_RC + 4];
+    __shared__ unsigned nfw[NN_RC / 32];
+    const int64_t n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i0 = blockIdx.x * NN_T * 2 + tid, i1 = i0 + NN_T;
+    const float *pn = pts + (size_t)n * P * 3, *vn = verts + (size_t)n * V * 3;
+    const float FAR = 3e18f;
+    const v2f QX = v2f{i0 < P ? pn[3 * i0] : FAR, i1 < P ? pn[3 * i1] : FAR};
+    const v2f QY = v2f{i0 < P ? pn[3 * i0 + 1] : FAR, i1 < P ? pn[3 * i1 + 1] : FAR};
+    const v2f QZ = v2f{i0 < P ? pn[3 * i0 + 2] : FAR, i1 < P ? pn[3 * i1 + 2] : FAR};
+    v2f best = v2f{FLT_MAX, FLT_MAX};
+    int b0 = 0, b1 = 0;
+    for (int c0 = 0; c0 < V; c0 += NN_RC) {
+        __syncthreads();
+        for (int j = tid; j < NN_RC + 4; j += NN_T) {
+            const int v = c0 + j;
+            rs[j] = (v < V && j < NN_RC) ? make_float4(vn[3 * v], vn[3 * v + 1], vn[3 * v + 2], __int_as_float(v))
+                                         : make_float4(-FAR, -FAR, -FAR, 0.f);
+        }
+        if (tid < NN_RC / 32) nfw[tid] = 0;
+        __syncthreads();
+        const int cn = (min(NN_RC, V - c0) + 63) & ~63;
+        {
+#pragma clang fp contract(off)
+            // software pipeline with two register sets: the LDS records of the next four vertices are in flight while the
+            // current four are scored
+            float4 ra[4], rb[4];
+            auto score = [&](const float4 (&r)[4], int k0, unsigned long long &mask) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 p = r[u];
+                    const v2f dx = QX - v2f{p.x, p.x}, dy = QY - v2f{p.y, p.y}, dz = QZ - v2f{p.z, p.z};
+                    const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2.x < best.x) { best.x = d2.x; b0 = __float_as_int(p.w); }
+                    if (d2.y < best.y) { best.y = d2.y; b1 = __float_as_int(p.w); }
+                    // sqrt(d2) < 0.5 (optimization.py:75) <=> d2 < 0.25 up to the rounding of the last ulp
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(d2.x < 0.25f) | __builtin_amdgcn_ballot_w64(d2.y < 0.25f);
+                    unsigned bit;                                     // (bal != 0) on the scalar unit
+                    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bit) : "s"(bal) : "scc");
+                    mask |= (unsigned long long)bit << (k0 + u);
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ra[u] = rs[u];
+            for (int g = 0; g < cn; g += 64) {
+                unsigned long long mask = 0;
+#pragma unroll 1
+                for (int u8 = 0; u8 < 64; u8 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rb[u] = rs[g + u8 + 4 + u];
+                    score(ra, u8, mask);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ra[u] = rs[g + u8 + 8 + u];          // rs has 4 pad records
+                    score(rb, u8 + 4, mask);
+                }
+                if (lane == 0 && mask) {
+                    atomicOr(&nfw[g >> 5], (unsigned)mask);
+                    atomicOr(&nfw[(g >> 5) + 1], (unsigned)(mask >> 32));
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < NN_RC; j += NN_T)
+            if ((nfw[j >> 5] >> (j & 31)) & 1u) near[(size_t)n * V + c0 + j] = 1;      // several point blocks may store the same 1
+    }
+    if (i0 < P) yidx[(size_t)n * P + i0] = b0;
+    if (i1 < P) yidx[(size_t)n * P + i1] = b1;
+}
+
+__device__ __forceinline__ float3 ld3(const float *p) { return make_float3(p[0], p[1], p[2]); }
+__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// vector to the nearest vertex, its norm, and the inside/outside sign from the vertex normal (tools.py:55-61) -- the normal
+// (data/tools.py:4-40) is evaluated for the nearest vertices only, in the reference's accumulation order.
+__global__ __launch_bounds__(256) void opt_signed_kernel(const float *__restrict__ pts, int P, const float *__restrict__ verts, int V,
+                                                         const int32_t *__restrict__ yidx, const int32_t *__restrict__ faces,
+                                                         const int32_t *__restrict__ adj_ptr, const int32_t *__restrict__ adj_face,
+                                                         const int32_t *__restrict__ adj_corner, float *__restrict__ y2x_signed,
+                                                         float *__restrict__ y2x) {
+    const int64_t n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float *vn = verts + (size_t)n * V * 3;
+    const int v = yidx[(size_t)n * P + i];
+    float3 acc = make_float3(0.f, 0.f, 0.f);
+    for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) {
+        const int f = adj_face[e], c = adj_corner[e];
+        const float3 p0 = ld3(vn + 3 * faces[3 * f]), p1 = ld3(vn + 3 * faces[3 * f + 1]), p2 = ld3(vn + 3 * faces[3 * f + 2]);
+        float3 nn;
+        if (c == 1) nn = cross3(sub3(p2, p1), sub3(p0, p1));
+        else if (c == 2) nn = cross3(sub3(p0, p2), sub3(p1, p2));
+        else nn = cross3(sub3(p1, p0), sub3(p2, p0));
+        acc.x += nn.x; acc.y += nn.y; acc.z += nn.z;
+    }
+    const float nl = fmaxf(sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z), 1e-6f);
+    const float *q = pts + ((size_t)n * P + i) * 3, *pv = vn + 3 * v;
+    const float vx = q[0] - pv[0], vy = q[1] - pv[1], vz = q[2] - pv[2];
+    const float dt = (acc.x / nl) * vx + (acc.y / nl) * vy + (acc.z / nl) * vz;
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    y2x_signed[(size_t)n * P + i] = d * (dt > 0.f ? 1.f : (dt < 0.f ? -1.f : 0.f));
+    float *o = y2x + ((size_t)n * P + i) * 3;
+    o[0] = vx; o[1] = vy; o[2] = vz;
+}
+
 // ---- loss on the geometry + its gradient with respect to vertices and object pose (optimization.py:66-79) ---------------
 constexpr int LG_T = 512, LG_W = LG_T / 64, LG_R = 17;
 
 __global__ __launch_bounds__(LG_T) void opt_lossgrad_kernel(const float *__restrict__ verts, const float *__restrict__ verts_gt, int V,
-                                                            const float *__restrict__ y2x_signed, const float *__restrict__ x2y_signed,
+                                                            const float *__restrict__ y2x_signed, const int32_t *__restrict__ near,
                                                             const int32_t *__restrict__ yidx, const float *__restrict__ y2x,
                                                             const float *__restrict__ obj_points, int P, int T,
                                                             const int32_t *__restrict__ ctl, float *__restrict__ gv_out,
@@ -113,7 +233,7 @@ __global__ __launch_bounds__(LG_T) void opt_lossgrad_kernel(const float *__restr
 #pragma unroll
     for (int k = 0; k < LG_R; ++k) acc[k] = 0.f;
     for (int i = tid; i < 3 * V; i += LG_T) {
-        const float wv = x2y_signed[(size_t)n * V + i / 3] < 0.5f ? 0.f : 0.01f;          // :72-76
+        const float wv = near[(size_t)n * V + i / 3] ? 0.f : 0.01f;                      // :72-76
         const float d = vn[i] - vg[i];
         gvs[i] = wv * invT * sgn(d);
         acc[16] += wv * fabsf(d);
@@ -479,8 +599,8 @@ bool valid(const idf_opt_ctx *c, const idf_opt_state *st) {
     if (m->J != NJ || m->n_betas != 10 || m->KB % 16 != 0 || c->K3P % KSLICE != 0 || c->K3P < 3 * m->V) return false;
     if (st->B < 1 || st->T < 3 || st->P < 1 || (size_t)m->V * 3 * sizeof(float) > 150 * 1024) return false;
     const void *need[] = {st->betas, st->obj_points, st->param, st->init, st->grad, st->m, st->v, st->best, st->pose, st->tr, st->verts,
-                          st->vposed, st->verts_gt, st->normals, st->gv, st->jtr, st->pts, st->y2x, st->y2x_signed, st->x2y_signed,
-                          st->yidx, st->xidx, st->dvposed, st->dA, st->dfeat, st->gtr, st->lossf, st->loss, st->best_loss, st->flag,
+                          st->vposed, st->verts_gt, st->gv, st->jtr, st->pts, st->y2x, st->y2x_signed, st->near,
+                          st->yidx, st->dvposed, st->dA, st->dfeat, st->gtr, st->lossf, st->loss, st->best_loss, st->flag,
                           st->foot_static, st->foot_cnt, st->ctl, st->smpl_ws};
     for (const void *p : need)
         if (!p) return false;
@@ -497,11 +617,11 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
     hipLaunchKernelGGL(opt_objpts_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->param, st->obj_points, P, T, st->pts);
     int rc = interdiff_smpl_forward(m, st->pose, st->betas, st->tr, N, st->verts, st->jtr, st->vposed, st->smpl_ws, st->smpl_ws_bytes, stream);
     if (rc) return rc;
-    rc = interdiff_vertex_normals(st->verts, N, V, c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, st->normals, stream);
-    if (rc) return rc;
-    rc = interdiff_point2point_signed(st->verts, V, st->pts, P, N, st->normals, nullptr, st->y2x_signed, st->x2y_signed, st->yidx, st->xidx,
-                                      st->y2x, nullptr, stream);
-    if (rc) return rc;
+    if (hipMemsetAsync(st->near, 0, (size_t)N * V * sizeof(int32_t), s) != hipSuccess) return IDF_E_LAUNCH;
+    hipLaunchKernelGGL(opt_nn_kernel, dim3((unsigned)idf_cdiv(P, NN_T * 2), (unsigned)N), dim3(NN_T), 0, s, st->pts, P, st->verts, V, st->yidx,
+                       st->near);
+    hipLaunchKernelGGL(opt_signed_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->pts, P, st->verts, V, st->yidx,
+                       c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, st->y2x_signed, st->y2x);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(opt_lossgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
@@ -510,7 +630,7 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
         attr_set = true;
     }
     hipLaunchKernelGGL(opt_lossgrad_kernel, dim3((unsigned)N), dim3(LG_T), (size_t)V * 3 * sizeof(float), s, st->verts, st->verts_gt, V,
-                       st->y2x_signed, st->x2y_signed, st->yidx, st->y2x, st->obj_points, P, T, st->ctl, st->gv, st->grad, st->gtr, st->lossf);
+                       st->y2x_signed, st->near, st->yidx, st->y2x, st->obj_points, P, T, st->ctl, st->gv, st->grad, st->gtr, st->lossf);
     // A [N][J][12] sits behind the feature rows in the SMPL workspace (smpl.hip: interdiff_smpl_forward)
     const float *A = reinterpret_cast<const float *>(reinterpret_cast<const char *>(st->smpl_ws) + idf_align((size_t)N * m->KB * sizeof(float)));
     hipLaunchKernelGGL(opt_skin_vertex_kernel, dim3((unsigned)idf_cdiv(V, 256), (unsigned)N), dim3(256), 0, s, *m, A, st->gv, c->K3P, st->dvposed);

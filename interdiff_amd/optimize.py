@@ -62,8 +62,8 @@ class PhysicsOptimizer:
         f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
         i = lambda *s: torch.zeros(*s, dtype=torch.int32, device=self.device)
         bufs = dict(betas=f(N, 10), obj_points=f(B, P, 3), param=f(N, NP), init=f(N, NP), grad=f(N, NP), m=f(N, NP), v=f(N, NP), best=f(N, NP),
-                    pose=f(N, 156), tr=f(N, 3), verts=f(N, V, 3), vposed=f(N, V, 3), verts_gt=f(N, V, 3), normals=f(N, V, 3), gv=f(N, V, 3),
-                    jtr=f(N, J, 3), pts=f(N, P, 3), y2x=f(N, P, 3), y2x_signed=f(N, P), x2y_signed=f(N, V), yidx=i(N, P), xidx=i(N, V),
+                    pose=f(N, 156), tr=f(N, 3), verts=f(N, V, 3), vposed=f(N, V, 3), verts_gt=f(N, V, 3), gv=f(N, V, 3),
+                    jtr=f(N, J, 3), pts=f(N, P, 3), y2x=f(N, P, 3), y2x_signed=f(N, P), yidx=i(N, P), near=i(N, V),
                     dvposed=f(N, self.K3P), dA=f(N, J, 12), dfeat=f(self.K3P // KSLICE, N, self.KB), gtr=f(N, 3), lossf=f(N, _lib.OPT_NLOSS),
                     loss=f(B, 4), loss_hist=f(max_iters, B, 4), best_loss=f(B), flag=i(B),
                     foot_static=torch.zeros(N, 2, dtype=torch.uint8, device=self.device), foot_cnt=i(B, 2), ctl=i(4))

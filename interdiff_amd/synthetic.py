@@ -203,3 +203,17 @@ def make_clip_batch(seed=233, B=16, T=100, past_len=10, n_points=2048, d=256, n_
         noise=_f32(rs.standard_normal((B, 1, 144, T))),
         past_len=past_len,
     )
+
+
+def make_optim_batch(seed=1, B=16, T=20, n_points=2048):
+    """Clips in optimization.py's schema ("next" row N4; :216 uses past 10 + future 10 frames): pose [B,T,156] axis-angle,
+    trans / obj_angles / obj_trans [B,T,3], betas [B,T,10], obj_points [B,P,3] -- slow motion, the object overlapping the
+    body so that the penetration term is active."""
+    rs = np.random.RandomState(seed)
+    pose = 0.3 * rs.standard_normal((B, 1, 156)) + np.cumsum(0.01 * rs.standard_normal((B, T, 156)), axis=1)
+    trans = 0.1 * rs.standard_normal((B, 1, 3)) + np.cumsum(0.005 * rs.standard_normal((B, T, 3)), axis=1)
+    obj_angles = rs.standard_normal((B, 1, 3)) + np.cumsum(0.02 * rs.standard_normal((B, T, 3)), axis=1)
+    obj_trans = trans + 0.25 * rs.standard_normal((B, 1, 3)) + np.cumsum(0.004 * rs.standard_normal((B, T, 3)), axis=1)
+    betas = np.repeat(rs.standard_normal((B, 1, 10)), T, axis=1)
+    return dict(pose=_f32(pose), trans=_f32(trans), obj_angles=_f32(obj_angles), obj_trans=_f32(obj_trans), betas=_f32(betas),
+                obj_points=_f32(rs.uniform(-0.25, 0.25, (B, n_points, 3))))

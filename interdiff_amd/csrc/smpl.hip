@@ -7,12 +7,13 @@
 //       regressor is folded into the shape basis on the host), the kinematic chain staged in LDS,
 //       rest-pose removal; emits the blend-shape feature row [R_1..R_{J-1} - I | beta | 1] and the
 //       per-joint 3x4 transforms A.
-//   kernel 2 (16 frames x 64 vertices per workgroup): ONE fp32-MFMA GEMM feat[16,KB] x blend[KB,192]
+//   kernel 2 (32 frames x 64 vertices per workgroup): ONE fp32-MFMA GEMM feat[32,KB] x blend[KB,192]
 //       gives v_posed (template, shape and pose blend shapes in one contraction: 95% of the FLOPs),
 //       staged through LDS, then the <=S-bone skinning sum, the 3x4 apply and the translation in
 //       the epilogue.  Nothing per-vertex except the final vertices ever reaches HBM.
 #include "common.h"
 #include "rot_math.h"
+#include <algorithm>
 
 namespace {
 
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const idf_smpl_model m, c
     }
 }
 
-constexpr int FT = 16, VT = 64, NTC = 3 * VT;          // frames / vertices / coordinates per workgroup
+constexpr int FT = 32, VT = 64, NTC = 3 * VT;          // frames / vertices / coordinates per workgroup
+constexpr int FM = FT / 16;                             // 16-frame MFMA tiles per workgroup (each basis fragment is reused FM times)
 constexpr int AQS = FT * 4 + 4;                         // padded quad stride of the feature image
 constexpr int STS = NTC + 1;                            // stage row stride
 
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_mod
                                                               float *__restrict__ v_posed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int KB = m.KB, V = m.V, J = m.J, S = m.S, nq = KB / 4;
-    float *As = sm, *stage = sm + nq * AQS;
+    float *As = sm, *stage = sm;                       // the stage image reuses the feature image once the contraction is done
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     // frame tiles on blockIdx.x (fast) so that concurrently resident workgroups share one slice of the
     // blend basis in L2; vertex tiles on blockIdx.y
@@ -112,33 +114,52 @@ __global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_mod
         bval[t] = nrow < 3 * V;
         brow[t] = m.blend + (size_t)(bval[t] ? nrow : 0) * KB + kq * 4;
     }
-    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[FM][3];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ng = KB / 16;
-    float4 bc[3], bn[3];
+    // the basis fragments come straight from global memory (each is used by this wave only): three register sets keep the
+    // loads of groups g+1 and g+2 in flight behind the 8*FM*3 MFMAs of group g
+    float4 b0[3], b1[3], b2[3];
+    auto ldg = [&](float4 (&dst)[3], int gi) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) bc[t] = bval[t] ? *reinterpret_cast<const float4 *>(brow[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g = 0; g < ng; ++g) {
-        if (g + 1 < ng) {
+        for (int t = 0; t < 3; ++t)
+            dst[t] = (bval[t] && gi < ng) ? *reinterpret_cast<const float4 *>(brow[t] + gi * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto mac = [&](const float4 (&bc)[3], int gi) {
+        if (gi >= ng) return;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                bn[t] = bval[t] ? *reinterpret_cast<const float4 *>(brow[t] + (g + 1) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < FM; ++i) {
+            const float4 a = *reinterpret_cast<const float4 *>(As + (gi * 4 + kq) * AQS + (i * 16 + li) * 4);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc[t].x, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc[t].y, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bc[t].z, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bc[t].w, acc[i][t], 0, 0, 0);
         }
-        const float4 a = *reinterpret_cast<const float4 *>(As + (g * 4 + kq) * AQS + li * 4);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bc[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bc[t].w, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) bc[t] = bn[t];
+    };
+    ldg(b0, 0);
+    ldg(b1, 1);
+    for (int g = 0; g < ng; g += 3) {
+        ldg(b2, g + 2);
+        mac(b0, g);
+        ldg(b0, g + 3);
+        mac(b1, g + 1);
+        ldg(b1, g + 4);
+        mac(b2, g + 2);
     }
+    __syncthreads();                                   // every wave is done reading As
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(kq * 4 + r) * STS + (wave * 3 + t) * 16 + li] = acc[t][r];
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + kq * 4 + r) * STS + (wave * 3 + t) * 16 + li] = acc[i][t][r];
     __syncthreads();
 
 #pragma unroll
@@ -188,7 +209,15 @@ extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose
     float *A = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * m->KB * sizeof(float)));
     idf_prof_mark(IDF_K_SMPL_POSE, s);
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((unsigned)N), dim3(64), 0, s, *m, pose, betas, trans, feat, A, jtr);
-    const size_t lds = ((size_t)(m->KB / 4) * AQS + (size_t)FT * STS) * sizeof(float);
+    const size_t lds = std::max((size_t)(m->KB / 4) * AQS, (size_t)FT * STS) * sizeof(float);
+    if (lds > 150 * 1024) return IDF_E_INVAL;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(smpl_blend_skin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+            hipSuccess)
+            return IDF_E_LAUNCH;
+        attr_set = true;
+    }
     idf_prof_mark(IDF_K_SMPL_BLEND_SKIN, s);
     hipLaunchKernelGGL(smpl_blend_skin_kernel, dim3((unsigned)idf_cdiv(N, FT), (unsigned)idf_cdiv(m->V, VT)), dim3(256), lds, s, *m,
                        feat, A, trans, N, verts, v_posed);

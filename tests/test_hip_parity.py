@@ -515,3 +515,32 @@ def test_optimize_batch_and_full_schedule(phys):
     assert (ls[199, :, 1] / w[199] < 0.8 * ls[1, :, 1] / w[1]).all()      # the un-weighted penetration depth must have gone down
     assert bool(full['saved'].all())
     assert torch.isfinite(full['pose']).all() and torch.isfinite(full['obj_angles']).all()
+
+
+@pytest.mark.gpu
+def test_config1_skeleton_plumbing_sampler(lib):
+    """BASELINE config #1 (eval_skeleton_no_correction.py: HO-GCN skeleton tokens C = 63+36+7 = 106, B=1, T=20, a 50-step
+    cosine schedule, identity denoised_fn :82-83).  The skeleton denoiser is not a kernel target (SURVEY.md §2 row 8);
+    what config #1 exercises is the sampler with an odd channel count, so a deterministic stand-in takes the model's
+    place on both sides: HIP inpaint / posterior kernels vs the oracle loop, all 50 steps, injected noise."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    B, C, T, steps = 1, 106, 20, 50
+    rs = np.random.RandomState(106)
+    w = fx._randn(rs, C, C) * (0.5 / np.sqrt(C))
+    gt, noise = fx._randn(rs, B, 1, C, T), fx._randn(rs, B, 1, C, T)
+    mask = torch.ones(B, 1, C, T, dtype=torch.bool)
+    mask[..., fx.PAST:] = False
+    stream_a, stream_b = fx.NoiseStream(61), fx.NoiseStream(61)
+
+    def make_model(wd):
+        def model(x, t, y=None):
+            return torch.tanh(torch.einsum('dc,bgct->bgdt', wd, x)) * (1.0 + 0.01 * t.float().view(-1, 1, 1, 1) / steps)
+        return model
+    y = dict(inpainting_mask=mask, inpainted_motion=gt)
+    ref = odf.p_sample_loop(make_model(w), (B, 1, C, T), odf.make_schedule(steps), noise.clone(), lambda i, x: stream_a.next_like(x),
+                            {'y': y}, denoised_fn=lambda x, t, kw: x)
+    diff = create_gaussian_diffusion('cosine', steps)
+    got = diff.p_sample_loop(make_model(w.to(DEV)), (B, 1, C, T), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)},
+                             denoised_fn=lambda x, t, kw: x, device=DEV, step_noise=lambda i, x: stream_b.next_like(x).to(DEV))
+    close(got, ref, 1e-5, 'config #1 sampler chain')
+    assert torch.equal(got.cpu()[..., :fx.PAST], gt[..., :fx.PAST]) or (got.cpu()[..., :fx.PAST] - ref[..., :fx.PAST]).abs().max() < 1e-6

@@ -228,6 +228,7 @@ def main():
     wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all()
     log('timed region: %d steps in %.3f s' % (K, wall))
+    idist.shutdown()              # no collective after this point: rank 0 alone takes the profile / baseline legs below
 
     prof = None
     if rank == 0 and not args.no_kernel_profile:

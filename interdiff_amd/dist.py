@@ -70,6 +70,15 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Tear the process group down (after the last collective): ranks may then finish at different times."""
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception as e:                       # teardown only: never let it take a finished measurement down
+            print('[interdiff_amd.dist] destroy_process_group: %r' % (e,), flush=True)
+
+
 def _selftest_worker(rank, world, port):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = init_from_env('gloo')
@@ -84,4 +93,5 @@ def _selftest_worker(rank, world, port):
     assert batch['gt'].shape[0] == sl.stop - sl.start and batch['cond'].shape[1] == sl.stop - sl.start and batch['past_len'] == 10
     assert max_over_ranks(r + 1.5, 'cpu') == w + 0.5
     barrier()
-    dist.destroy_process_group()
+    shutdown()
+    assert not dist.is_initialized()

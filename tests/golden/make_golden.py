@@ -247,6 +247,7 @@ def main():
     # licensed SMPL-H pkl and contact.npz / info.json which are not shipped); pelvis = joint 0 of the synthetic body model
     import importlib
     from oracle import smpl as osmpl
+    sys.modules.pop('data.dataset_smpl', None)
     dsm = importlib.import_module('data.dataset_smpl')
     seq_dir = '/root/reference/interdiff/data/behave/sequence/Date01_Sub01_backpack_back'
     with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
@@ -312,6 +313,9 @@ def main():
     sub = fx.vertex_subset()
     save('eval.npz', obj=np_(obj), body=np_(body), verts=np_(verts[:, :, sub]), jtr=np_(jtrs), pelvis=np_(pelvis),
          obj_gt=np_(obj_gt), jtr_gt=np_(jtr_gt), body_gt=np_(body_gt), **{'m_' + k: np_(v) for k, v in met.items()})
+
+    # ---- physics post-optimisation ("next" row N4)
+    gen_optim()
 
 
 if __name__ == '__main__':

@@ -544,3 +544,61 @@ def test_config1_skeleton_plumbing_sampler(lib):
                              denoised_fn=lambda x, t, kw: x, device=DEV, step_noise=lambda i, x: stream_b.next_like(x).to(DEV))
     close(got, ref, 1e-5, 'config #1 sampler chain')
     assert torch.equal(got.cpu()[..., :fx.PAST], gt[..., :fx.PAST]) or (got.cpu()[..., :fx.PAST] - ref[..., :fx.PAST]).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T', [(1, 11), (2, 16), (3, 17), (1, 49), (5, 64), (2, 208), (64, 20)])
+def test_denoiser_edge_sizes(mdm, B, T):
+    """Ragged tiles everywhere: T below / at / just above one 16-token row block, M = B*T not a multiple of any GEMM tile,
+    the longest supported clip (ATTN_MAX_T = 208) and BASELINE config #4's batch on one GPU."""
+    x, ts, cond = fx.mdm_inputs(B, T)
+    got = mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+    ref = oden.mdm_forward(fx.mdm_weights(), x, ts, cond)
+    close(got, ref, 1e-4, 'denoiser B=%d T=%d' % (B, T))
+
+
+@pytest.mark.gpu
+def test_denoiser_rejects_unsupported_sizes(mdm):
+    """Above the longest supported clip the entry point refuses (IDF_E_INVAL -> RuntimeError); nothing falls back."""
+    x, ts, cond = fx.mdm_inputs(1, 224)
+    with pytest.raises((RuntimeError, ValueError)):
+        mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,B,P', [(11, 1, 1), (12, 2, 63), (13, 1, 1000), (11, 2, 2048)])
+def test_correction_edge_sizes(smpl, T, B, P):
+    """Correction hook with ragged point counts (a single point, below one wave, not a multiple of the workgroup, the
+    maximum 2048) and a single future frame: output and the discrete decisions against the oracle."""
+    corr = make_correction(smpl, T, P)
+    corr.debug = {}
+    bt = fx._clip(700 + P, B, T, P)
+    y = fx.model_kwargs_y(bt, T)
+    rs = np.random.RandomState(P)
+    x = bt['gt'] + 0.05 * fx._randn(rs, *bt['gt'].shape)
+    t = torch.full((B,), 250, dtype=torch.int64)
+    got = corr(x.clone().to(DEV), t.to(DEV), {'y': dev(y)})
+    ref = ocor.denoised_fn(x.clone(), t, {'y': dict(y, smpl=fx.smpl_model(), obj_model=fx.objproj_weights())}, past_len=fx.PAST)
+    close(got, ref, 1e-4, 'correction T=%d B=%d P=%d' % (T, B, P))
+    terms = ocor.correction_terms(x.clone(), dict(y, smpl=fx.smpl_model()), fx.PAST)
+    assert torch.equal(corr.debug['condition'].cpu().bool(), terms['condition'])
+    assert torch.equal(corr.debug['contact'].cpu().long(), terms['contact'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,P', [(3, 5), (7, 300)])
+def test_optimize_edge_sizes_vs_oracle(phys, T, P):
+    """Shortest clip the smoothness terms are defined for (T = 3) and ragged point counts: loss parts and gradients of one
+    evaluation away from the initial pose (two Adam steps of the oracle first) against the autograd oracle."""
+    from oracle import optimization as oo
+    inp = fx.optim_inputs(seed=9100 + T, T=T, P=P)
+    model = fx.smpl_model()
+    warm = oo.optimize(model, *inp, iters=[151, 152])
+    parts, grads = oo.loss_and_grads(model, warm['params'], *inp, 153)
+    got_parts, got = phys.loss_and_grads({k: v.cuda() for k, v in warm['params'].items()}, *[a.cuda() for a in inp], 153)
+    np.testing.assert_allclose(got_parts.cpu().numpy(), parts.numpy(), rtol=2e-4, atol=1e-5)
+    for n in oo.PARAM_ORDER:
+        ref = grads[n].numpy()
+        assert np.abs(got[n].cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, n
+    with pytest.raises((RuntimeError, ValueError)):
+        phys.optimize(*[a[:2].cuda() if a.shape[0] == T else a.cuda() for a in inp])      # T = 2: smoothness undefined

@@ -361,12 +361,13 @@ __global__ __launch_bounds__(256) void opt_dfeat_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < DF_MT; ++i) red[wave][i][lane] = acc[i];
     __syncthreads();
-    const int i = wave;                                           // wave w finishes frame tile w
-    const f32x4 a = red[0][i][lane], b = red[1][i][lane], c = red[2][i][lane], d = red[3][i][lane];
+    for (int i = wave; i < DF_MT; i += 4) {                       // wave w finishes frame tiles w, w+4
+        const f32x4 a = red[0][i][lane], b = red[1][i][lane], c = red[2][i][lane], d = red[3][i][lane];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + i * 16 + kq * 4 + r;
-        if (row < M) part[((size_t)sl * M + row) * KB + c0 + li] = (a[r] + b[r]) + (c[r] + d[r]);
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + i * 16 + kq * 4 + r;
+            if (row < M) part[((size_t)sl * M + row) * KB + c0 + li] = (a[r] + b[r]) + (c[r] + d[r]);
+        }
     }
 }
 

@@ -602,3 +602,45 @@ def test_optimize_edge_sizes_vs_oracle(phys, T, P):
         assert np.abs(got[n].cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, n
     with pytest.raises((RuntimeError, ValueError)):
         phys.optimize(*[a[:2].cuda() if a.shape[0] == T else a.cuda() for a in inp])      # T = 2: smoothness undefined
+
+
+@pytest.mark.gpu
+def test_optimize_real_behave_motion(phys, smpl):
+    """Row N4 on REAL BEHAVE motion (windows of the shipped sequence stored in tests/golden/etl.npz; root rotations near pi,
+    real hand poses): three canonicalised 20-frame clips side by side through the full 200-iteration schedule.  One
+    loss/gradient evaluation is checked against the autograd oracle on the first clip; the run must stay finite, save an
+    iterate after iteration 150 and not move the poses further than 200 Adam steps can."""
+    from interdiff_amd import data as D, synthetic as syn
+    from oracle import optimization as oo
+    z = fx.golden('etl.npz')
+    sel, starts = z['sel'], z['starts']
+    F = int(sel.max()) + 1
+
+    def full(a):
+        out = np.zeros((F,) + a.shape[1:], a.dtype)
+        out[sel] = a
+        return out
+    seq = dict(poses=full(z['poses']), betas=full(z['betas']), trans=full(z['trans']), obj_angles=full(z['obj_angles']), obj_trans=full(z['obj_trans']))
+    pelvis = D.sequence_pelvis(seq, smpl, device=DEV)
+    T, P = 20, 512
+    clips = [D.canonicalize_clip(seq, pelvis, int(s0), 10, 10) for s0 in starts]
+    pts = syn.make_embedding_inputs(seed=3, B=1, T=2, n_points=P)['obj_points'][0]
+    st = lambda k: torch.from_numpy(np.stack([np.asarray(c[k], dtype=np.float32) for c in clips]))
+    args = [st('pose'), st('trans'), st('obj_angles'), st('obj_trans'), st('betas'), torch.from_numpy(np.repeat(pts[None], len(clips), 0))]
+    assert args[0].shape == (3, T, 156)
+    # one evaluation vs the oracle (clip 0, away from the initial pose)
+    one = [a[0] for a in args]
+    model = fx.smpl_model()
+    warm = oo.optimize(model, *one, iters=[151])
+    parts, grads = oo.loss_and_grads(model, warm['params'], *one, 152)
+    got_parts, got = phys.loss_and_grads({k: v.cuda() for k, v in warm['params'].items()}, *[a.cuda() for a in one], 152)
+    np.testing.assert_allclose(got_parts.cpu().numpy(), parts.numpy(), rtol=2e-4, atol=1e-5)
+    for n in oo.PARAM_ORDER:
+        ref = grads[n].numpy()
+        assert np.abs(got[n].cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, n
+    res = phys.optimize(*[a.cuda() for a in args])
+    assert bool(res['saved'].all()) and torch.isfinite(res['losses']).all()
+    for k, a in (('pose', args[0]), ('trans', args[1]), ('obj_angles', args[2]), ('obj_trans', args[3])):
+        assert torch.isfinite(res[k]).all()
+    # 200 steps of at most ~lr each (Adam's m/sqrt(v) exceeds 1 only mildly and briefly)
+    assert (res['trans'].cpu() - args[1]).abs().max() <= 0.3 and (res['obj_trans'].cpu() - args[3]).abs().max() <= 0.3

@@ -35,8 +35,8 @@ def shard_batch(batch, rank, world, batch_dims):
     out = {}
     for k, v in batch.items():
         if isinstance(v, torch.Tensor) and k in batch_dims:
-            n = v.shape[batch_dims[k]]
-            out[k] = v.narrow(batch_dims[k], shard_slice(n, rank, world).start, shard_slice(n, rank, world).stop - shard_slice(n, rank, world).start).contiguous()
+            sl = shard_slice(v.shape[batch_dims[k]], rank, world)
+            out[k] = v.narrow(batch_dims[k], sl.start, sl.stop - sl.start).contiguous()
         else:
             out[k] = v
     return out

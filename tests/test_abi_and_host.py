@@ -147,7 +147,6 @@ def test_joint_map_vjp_host_matches_autograd():
     """The derivative code of csrc/rot_dual.h (rotation -> matrix_to_axis_angle -> SMPL Rodrigues, "next" row N4) is
     host+device inline; its host instance (interdiff_debug_joint_map_vjp) must equal torch autograd of the oracle,
     including the exact-zero entries at identity rotations (Adam never moves those)."""
-    import ctypes  # noqa: F401
     from interdiff_amd import _lib
     from oracle import rotations as rot
     lib = _lib.load()

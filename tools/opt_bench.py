@@ -8,7 +8,6 @@ import json
 import os
 import sys
 import time
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))

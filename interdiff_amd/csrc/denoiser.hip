@@ -453,10 +453,11 @@ extern "C" int interdiff_tune(int32_t key, int32_t value) {
 
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias): the token GEMM of the denoiser as a standalone op (fp32 MFMA, LDS-DMA
 // pipeline).  epi: 0 bias, 1 bias + erf-GELU, 2 bias + residual (resid has leading dimension ldc).  cfg 0 = the tile
-// configuration the FFN call sites ship with.  K % 64 == 0, N % 16 == 0.
+// configuration the FFN call sites ship with.  K % 64 == 0, N % 16 == 0, lda / ldc % 4 == 0, A / C 16-byte aligned.
 extern "C" int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float *bias, const float *resid, float *C,
                                   int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t cfg, void *stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K & 63) || (N & 15) || (epi == 2 && !resid) || epi < 0 || epi > 2) return IDF_E_INVAL;
+    if ((ldc & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(A) & 15)) return IDF_E_INVAL;   // 16-B row stores / loads
     Args g{};
     g.A = A; g.lda = lda; g.K = K; g.W = W; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.resid = resid; g.T = 1;
     hipStream_t s = idf_stream(stream);

@@ -125,6 +125,35 @@ __device__ __forceinline__ void epilogue(const Args &g, const f32x4 (&acc)[TM][T
     }
 }
 
+// Row-major epilogues (bias | gelu | +residual) leave through LDS: the accumulator layout (16 columns x 4 rows per lane group)
+// would store 64-B row segments four bytes per lane; staged in `cs` (BM x (BN+4) floats, free once the k-loop's last barrier
+// has passed), every lane stores 16 B and a wave covers whole 128-B lines.  Same arithmetic as epilogue<>: bit-identical output.
+// Needs N % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C (true at every call site; checked in interdiff_gemm_f32).
+template <int BM, int BN, int TM, int TN, int EPI, int NT>
+__device__ __forceinline__ void epilogue_rows(const Args &g, float *cs, const f32x4 (&acc)[TM][TN], const float (&rres)[TM][TN][4],
+                                              const float (&bvs)[TN], bool writer, int wrow0, int wcol0, int kq, int li, int m0, int n0,
+                                              int tid) {
+    constexpr int CS = BN + 4, Q = BN / 4;
+    if (writer) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bvs[j];
+                    if constexpr (EPI == E_GELU) v = gelu_fast(v);
+                    if constexpr (EPI == E_RESID) v += rres[i][j][r];
+                    cs[(wrow0 + i * 16 + kq * 4 + r) * CS + wcol0 + j * 16 + li] = v;
+                }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * Q; idx += NT) {
+        const int row = idx / Q, c4 = idx - row * Q, gr = m0 + row, gc = n0 + c4 * 4;
+        if (gr < g.M && gc < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)gr * g.ldc + gc) = ld4(cs + row * CS + c4 * 4);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     constexpr int NT = WM * WN * 64;
@@ -282,7 +311,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     float rres[TM][TN][4], bvs[TN];
     load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
     if constexpr (EPI == E_RESID) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
-    epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_BIAS || EPI == E_GELU || EPI == E_RESID) {
+        static_assert(BM * (BN + 4) <= A_FLOATS + 2 * QC * BQ, "C tile must fit the operand buffers");
+        epilogue_rows<BM, BN, TM, TN, EPI, NT>(g, smem, acc, rres, bvs, true, wm * TM * 16, wn * TN * 16, kq, li, m0, n0, tid);
+    } else {
+        epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    }
     if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
 }
 
@@ -491,7 +525,13 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
                     for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4 *>(red + q * SLAB + (i * TN + j) * 4);
         }
     }
-    if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_BIAS || EPI == E_GELU || EPI == E_RESID) {
+        static_assert(BM * (BN + 4) <= (SMEM > RED ? SMEM : RED), "C tile must fit the operand buffers");
+        if constexpr (KS > 1) __syncthreads();                    // the split-K partials have been read
+        epilogue_rows<BM, BN, TM, TN, EPI, NW * 64>(g, smem, acc, rres, bvs, ks == 0, wm * TM * 16, wn * TN * 16, kq, li, m0, n0, tid);
+    } else {
+        if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    }
     if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
 }
 

@@ -192,6 +192,7 @@ def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
 
 
 def main():
+    global B_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=STEPS)
@@ -199,7 +200,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-postopt', action='store_true')
+    ap.add_argument('--clips-per-gpu', type=int, default=B_PER_GPU,
+                    help='NOT the BASELINE configuration unless 16: batch-scaling experiments only (DESIGN.md §4.1)')
     args = ap.parse_args()
+    B_PER_GPU = args.clips_per_gpu
     torch.set_grad_enabled(False)
     rank, world, local = idist.init_from_env('nccl' if args.gpus > 1 else None)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus

@@ -440,7 +440,7 @@ void run_gemm(int cfg, hipStream_t s, const Args &g) {
     default: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
     }
 }
-constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 9;
+constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 6;
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 
 }  // namespace

@@ -66,8 +66,21 @@ def build_world(dev, rank):
     return model, corr, bt, y, (sd, smpl_np, osd)
 
 
-def run_steps(diff, model, corr, bt, y, n_steps, seed, use_graph=True):
-    return diff.p_sample_loop(model, tuple(bt['noise'].shape), noise=bt['noise'], clip_denoised=False,
+def step_window(K):
+    """Timesteps a K-step timed region covers.  K = 1000: the whole sample.  K < 1000: a window of the schedule holding the same
+    SHARE of gated correction steps as the whole sample (11 per 1000: t <= 500 and t % 50 == 0), so that a shorter run measures
+    the same per-step mix: the window ends on the round(K*11/1000)-th correction step counted from t = 500 (none below 46 steps)."""
+    if K >= STEPS:
+        return STEPS - 1, 11
+    n = int(round(K * 11 / 1000.0))
+    if n == 0:
+        return STEPS - 1, 0
+    last = 500 - 50 * (n - 1)                                  # window = [last + K - 1, last]
+    return last + K - 1, n
+
+
+def run_steps(diff, model, corr, bt, y, n_steps, seed, use_graph=True, first_t=None):
+    return diff.p_sample_loop(model, tuple(bt['noise'].shape), noise=bt['noise'], clip_denoised=False, first_t=first_t,
                               model_kwargs={'y': y}, denoised_fn=corr, seed=seed, n_steps=n_steps, use_graph=use_graph)
 
 
@@ -241,7 +254,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
-    out = run_steps(diff, model, corr, bt, y, K, seed=233)
+    t_first, _ = step_window(K)
+    out = run_steps(diff, model, corr, bt, y, K, seed=233, first_t=t_first)
     torch.cuda.synchronize()
     idist.barrier()
     wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
@@ -279,7 +293,7 @@ def main():
     if rank != 0:
         return
     Btot = B_PER_GPU * world
-    n_corr = sum(1 for i in range(STEPS - 1, STEPS - 1 - K, -1) if i <= 500 and i % 50 == 0)
+    n_corr = sum(1 for i in range(t_first, t_first - K, -1) if i <= 500 and i % 50 == 0)
     line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=K * Btot * T / wall,
                 unit='frame-steps/s', n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=1e3 * wall / K,
                 higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
@@ -287,7 +301,7 @@ def main():
                 config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
                                      '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
                                      'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
-                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, parallelism='clips sharded x%d' % world))
+                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, timesteps='%d..%d' % (t_first, t_first - K + 1), parallelism='clips sharded x%d' % world))
     if prof:
         dom = 'gemm_ffn2'
         us = dom_us

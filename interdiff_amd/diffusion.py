@@ -80,7 +80,7 @@ class GaussianDiffusion:
             self._tables[key] = torch.from_numpy(np.stack([self._c1, self._c2, sig, blend], axis=1).astype(np.float32)).contiguous().to(device)
         return self._tables[key]
 
-    def _graph_loop(self, model, img, model_kwargs, denoised_fn, seed, todo, dump_steps):
+    def _graph_loop(self, model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_start):
         lib = _lib.load()
         y = model_kwargs.get('y', {})
         B, dev = img.shape[0], img.device
@@ -119,7 +119,6 @@ class GaussianDiffusion:
                         posterior(st.x, st.x0, gc, mu8, st)
                 st.graphs[k] = g
             return st.graphs[k]
-        t_start = self.num_timesteps - 1
         st.x.copy_(img)
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
         st.ts.fill_(t_start)
@@ -174,11 +173,12 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
                       cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None, seed=0, n_steps=None,
-                      use_graph=True):
+                      use_graph=True, first_t=None):
         """Same keyword surface as the reference (:598-614).  Extra: ``step_noise`` (tensor [n,...] or callable
         (loop_index, x) -> tensor) for deterministic parity, ``seed`` for the in-kernel generator, ``n_steps`` to
         run only the first n iterations (t = T-1 .. T-n) -- used by the bench / short-chain parity tests, ``use_graph=False``
-        to force the eager route."""
+        to force the eager route, ``first_t`` to enter the schedule at that timestep with ``noise`` taken as x_{first_t}
+        (a window of the loop for measurements; default T-1)."""
         if clip_denoised:
             raise NotImplementedError('clip_denoised=True is not used on the eval path (eval_smpl_short.py:153)')
         if cond_fn is not None or skip_timesteps or init_image is not None or randomize_class or cond_fn_with_grad or const_noise:
@@ -199,13 +199,16 @@ class GaussianDiffusion:
                 m = y['inpainting_mask']
                 mu8, gc = (m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous(), y['inpainted_motion'].contiguous()
                 _lib.check(lib.interdiff_inpaint(_lib.dptr(img), _lib.dptr(gc), _lib.dptr(mu8), img.numel(), _lib.stream()), 'inpaint')
-        todo = self.num_timesteps if n_steps is None else int(n_steps)
+        t_first = self.num_timesteps - 1 if first_t is None else int(first_t)
+        if not 0 <= t_first < self.num_timesteps:
+            raise ValueError('first_t outside the schedule')
+        todo = t_first + 1 if n_steps is None else min(int(n_steps), t_first + 1)
         if (step_noise is None and use_graph and getattr(model, 'graph_safe', False) and img.is_cuda
                 and 'cond' in model_kwargs.get('y', {}) and os.environ.get('INTERDIFF_NO_GRAPH') != '1'):
-            return self._graph_loop(model, img, model_kwargs, denoised_fn, seed, todo, dump_steps)
+            return self._graph_loop(model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_first)
         ts = self._timesteps(shape[0], device)
         dump = []
-        for it, i in enumerate(range(self.num_timesteps - 1, self.num_timesteps - 1 - todo, -1)):
+        for it, i in enumerate(range(t_first, t_first - todo, -1)):
             t = ts[i]
             t.host_value = i
             if step_noise is None:

@@ -237,7 +237,7 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    K = max(1, min(args.steps, STEPS))
+    K = max(1, args.steps)                    # more than 1000 steps = whole samples back to back, then a window for the rest
     log('building world (weights, SMPL-H stand-in, clips) on %s' % dev)
     model, corr, bt, y, assets = build_world(dev, rank)
     log('world ready')
@@ -254,8 +254,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
-    t_first, _ = step_window(K)
-    out = run_steps(diff, model, corr, bt, y, K, seed=233, first_t=t_first)
+    n_full, rem = divmod(K, STEPS)
+    t_first, n_corr = (STEPS - 1, 11 * n_full) if n_full else step_window(rem)
+    for s_i in range(n_full):
+        out = run_steps(diff, model, corr, bt, y, STEPS, seed=233 + s_i)
+    if rem:
+        t_rem, n_rem = step_window(rem)
+        out = run_steps(diff, model, corr, bt, y, rem, seed=233 + n_full, first_t=t_rem)
+        if n_full:
+            n_corr += n_rem
     torch.cuda.synchronize()
     idist.barrier()
     wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
@@ -293,7 +300,6 @@ def main():
     if rank != 0:
         return
     Btot = B_PER_GPU * world
-    n_corr = sum(1 for i in range(t_first, t_first - K, -1) if i <= 500 and i % 50 == 0)
     line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=K * Btot * T / wall,
                 unit='frame-steps/s', n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=1e3 * wall / K,
                 higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
@@ -301,7 +307,7 @@ def main():
                 config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
                                      '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
                                      'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
-                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, timesteps='%d..%d' % (t_first, t_first - K + 1), parallelism='clips sharded x%d' % world))
+                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, timesteps=('%d..%d' % (t_first, t_first - K + 1)) if not n_full else ('%d whole sample(s)' % n_full + (' + %d..%d' % (t_rem, t_rem - rem + 1) if rem else '')), parallelism='clips sharded x%d' % world))
     if prof:
         dom = 'gemm_ffn2'
         us = dom_us

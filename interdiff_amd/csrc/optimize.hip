@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64) void opt_init_kernel(const float *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(64) void opt_setctl_kernel(int32_t *__restrict__ ctl, int32_t first_iter) {
+    if (threadIdx.x < 4) ctl[threadIdx.x] = threadIdx.x == 0 ? first_iter : 0;
+}
+
 __global__ __launch_bounds__(64) void opt_static_kernel(const float *__restrict__ jtr, int T, int J, uint8_t *__restrict__ foot_static,
                                                         int32_t *__restrict__ foot_cnt, float *__restrict__ best_loss) {
     const int b = blockIdx.x, f = threadIdx.x;
@@ -664,9 +668,7 @@ extern "C" int interdiff_optimize_init(const idf_opt_ctx *c, const idf_opt_state
         hipMemsetAsync(st->dvposed, 0, (size_t)N * c->K3P * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(st->flag, 0, (size_t)st->B * sizeof(int32_t), s) != hipSuccess)
         return IDF_E_LAUNCH;
-    const int32_t ctl[4] = {first_iter, 0, 0, 0};
-    if (hipMemcpyAsync(st->ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, s) != hipSuccess) return IDF_E_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return IDF_E_LAUNCH;      // ctl[] lives on this stack frame
+    hipLaunchKernelGGL(opt_setctl_kernel, dim3(1), dim3(64), 0, s, st->ctl, first_iter);
     // verts_gt / jtr_gt from the ORIGINAL axis-angle pose (optimization.py:43-45)
     const int rc = interdiff_smpl_forward(m, pose, st->betas, trans, N, st->verts_gt, st->jtr, nullptr, st->smpl_ws, st->smpl_ws_bytes, stream);
     if (rc) return rc;

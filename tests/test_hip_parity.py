@@ -644,3 +644,95 @@ def test_optimize_real_behave_motion(phys, smpl):
         assert torch.isfinite(res[k]).all()
     # 200 steps of at most ~lr each (Adam's m/sqrt(v) exceeds 1 only mildly and briefly)
     assert (res['trans'].cpu() - args[1]).abs().max() <= 0.3 and (res['obj_trans'].cpu() - args[3]).abs().max() <= 0.3
+
+
+@pytest.mark.gpu
+def test_optimize_writes_stay_inside_their_buffers(smpl):
+    """Every device buffer of the optimiser state is re-homed between two guard bands filled with a sentinel; after a
+    few iterations (and a loss/gradient evaluation) no band may have been touched."""
+    from interdiff_amd import _lib
+    from interdiff_amd.optimize import PhysicsOptimizer
+    GUARD = 4096
+
+    class Guarded(PhysicsOptimizer):
+        def _alloc(self, B, T, P, max_iters):
+            st, bufs = super()._alloc(B, T, P, max_iters)
+            if getattr(self, '_guards', None) is not None and self._guards[0] == (B, T, P, max_iters):
+                return st, bufs
+            guards = {}
+            for k in _lib._OPT_PTRS:
+                t = bufs[k]
+                nbytes = t.numel() * t.element_size()
+                raw = torch.full((nbytes + 2 * GUARD,), 0xA5, dtype=torch.uint8, device=t.device)
+                inner = raw[GUARD:GUARD + nbytes].view(t.dtype).view(t.shape)
+                inner.copy_(t)
+                bufs[k] = inner
+                guards[k] = raw
+                setattr(st, k, inner.data_ptr())
+            self._guards = ((B, T, P, max_iters), guards)
+            return st, bufs
+
+    opt = Guarded(smpl)
+    inp = [a.cuda() for a in fx.optim_inputs(seed=9200, T=7, P=130)]
+    res = opt.optimize(*inp, iters=range(150, 154))
+    assert torch.isfinite(res['losses']).all()
+    for k, raw in opt._guards[1].items():
+        assert bool((raw[:GUARD] == 0xA5).all()) and bool((raw[-GUARD:] == 0xA5).all()), 'out-of-bounds write next to %s' % k
+
+
+def _guarded(nbytes, dev, guard=4096):
+    raw = torch.full((nbytes + 2 * guard,), 0xA5, dtype=torch.uint8, device=dev)
+    return raw, raw[guard:guard + nbytes]
+
+
+def _intact(raw, guard=4096):
+    return bool((raw[:guard] == 0xA5).all()) and bool((raw[-guard:] == 0xA5).all())
+
+
+@pytest.mark.gpu
+def test_hot_path_writes_stay_inside_their_buffers(mdm, smpl):
+    """Guard bands around the denoiser workspace / memory context / output, the SMPL outputs and workspace and the correction
+    workspace at a ragged size: the exact byte counts the library asks for must be enough, and nothing may write past them."""
+    import ctypes as C
+    from interdiff_amd import _lib
+    B, T, P = 3, 37, 300
+    x, ts, cond = fx.mdm_inputs(B, T)
+    # denoiser: exact-size workspace, memctx and output between guards
+    need_ws = mdm.lib.interdiff_mdm_workspace_bytes(B, T)
+    raw_ws, ws = _guarded(need_ws, DEV)
+    raw_mc, mc = _guarded(mdm.lib.interdiff_mdm_memctx_floats(B) * 4, DEV)
+    raw_o, o = _guarded(B * 144 * T * 4, DEV)
+    saved = (mdm._ws, mdm._memctx, mdm._mem_key)
+    try:
+        mdm._ws, mdm._memctx, mdm._mem_key = ws, mc.view(torch.float32), None
+        out = o.view(torch.float32).view(B, 1, 144, T)
+        got = mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)}, out=out)
+        close(got, oden.mdm_forward(fx.mdm_weights(), x, ts, cond), 1e-4, 'guarded denoiser forward')
+    finally:
+        mdm._ws, mdm._memctx, mdm._mem_key = saved
+    assert _intact(raw_ws) and _intact(raw_mc) and _intact(raw_o)
+    # body model: exact-size outputs and workspace
+    N = 5
+    pose, betas, trans = fx.smpl_inputs(N)
+    V, J = smpl.cmodel.V, smpl.cmodel.J
+    raws = [_guarded(n, DEV) for n in (N * V * 12, N * J * 12, N * V * 12, smpl.lib.interdiff_smpl_workspace_bytes(C.byref(smpl.cmodel), N))]
+    verts, jtr, vp = (r[1].view(torch.float32) for r in raws[:3])
+    pd, bd, td = pose.to(DEV), betas.to(DEV), trans.to(DEV)          # keep the device copies alive across the launch
+    _lib.check(smpl.lib.interdiff_smpl_forward(C.byref(smpl.cmodel), _lib.dptr(pd), _lib.dptr(bd), _lib.dptr(td), N,
+                                               _lib.dptr(verts), _lib.dptr(jtr), _lib.dptr(vp), _lib.dptr(raws[3][1]), raws[3][1].numel(),
+                                               _lib.stream()), 'smpl_forward')
+    ref = osmpl.smpl_forward(fx.smpl_model(), pose, betas, trans)
+    close(verts.view(N, V, 3), ref[0], 1e-5, 'guarded smpl verts')
+    assert all(_intact(r[0]) for r in raws)
+    # correction hook: exact-size workspace
+    corr = make_correction(smpl, T, P)
+    raw_c, wsc = _guarded(corr.lib.interdiff_correction_workspace_bytes(C.byref(corr.ctx), B, T), DEV)
+    corr._ws = wsc
+    bt = fx._clip(800, B, T, P)
+    y = fx.model_kwargs_y(bt, T)
+    xin = bt['gt'].clone().to(DEV)
+    raw_x, xg = _guarded(xin.numel() * 4, DEV)
+    xg = xg.view(torch.float32).view(xin.shape)
+    xg.copy_(xin)
+    corr(xg, torch.full((B,), 250, dtype=torch.int64, device=DEV), {'y': dev(y)})
+    assert torch.isfinite(xg).all() and _intact(raw_c) and _intact(raw_x)

@@ -208,6 +208,9 @@ class GaussianDiffusion:
             return self._graph_loop(model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_first)
         ts = self._timesteps(shape[0], device)
         dump = []
+        cond = model_kwargs.get('y', {}).get('cond') if isinstance(model_kwargs.get('y', None), dict) else None
+        if cond is not None and hasattr(model, 'prepare_memory'):
+            model.prepare_memory(cond)                  # once per sample, like the graph route (never trust a cached fold across samples)
         for it, i in enumerate(range(t_first, t_first - todo, -1)):
             t = ts[i]
             t.host_value = i

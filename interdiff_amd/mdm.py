@@ -177,7 +177,7 @@ class MDM:
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
-        self._mem_key, self._memctx, self._ws = None, None, None
+        self._mem_key, self._mem_cond, self._memctx, self._ws = None, None, None, None
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -203,6 +203,7 @@ class MDM:
         if cond.shape[0] != MEM or cond.shape[2] != D:
             raise ValueError('cond must be [%d,B,%d]' % (MEM, D))
         B = cond.shape[1]
+        given = cond
         cond = cond.contiguous()
         need = self.lib.interdiff_mdm_memctx_floats(B)
         # the buffer is reused when the size matches: its address may be baked into a captured hipGraph
@@ -212,7 +213,11 @@ class MDM:
         _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                          _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),
                    'mdm_prepare_memory')
-        self._mem_key = (cond.data_ptr(), cond._version, tuple(cond.shape))
+        # forward() recognises "same memory as last time" by (address, version, shape) of the tensor it is handed; the tensor itself
+        # is kept alive here so that the allocator cannot hand its address to a DIFFERENT cond of the same shape (the outputs of
+        # _get_embeddings are written through raw pointers, so their version counter never moves)
+        self._mem_key = (given.data_ptr(), given._version, tuple(given.shape))
+        self._mem_cond = given
         self._memctx = memctx
         return memctx
 

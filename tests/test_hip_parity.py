@@ -736,3 +736,24 @@ def test_hot_path_writes_stay_inside_their_buffers(mdm, smpl):
     xg.copy_(xin)
     corr(xg, torch.full((B,), 250, dtype=torch.int64, device=DEV), {'y': dev(y)})
     assert torch.isfinite(xg).all() and _intact(raw_c) and _intact(raw_x)
+
+
+@pytest.mark.gpu
+def test_memory_fold_is_not_reused_for_a_recycled_cond_address(mdm):
+    """A new ``cond`` of the same shape that happens to get the address of a freed one (its version counter is 0 as well: the
+    encoder writes it through a raw pointer) must not be mistaken for the memory that was folded last."""
+    B, T = 2, 12
+    x, ts, cond = fx.mdm_inputs(B, T)
+    xd, tsd = x.to(DEV), ts.to(DEV)
+    c1 = cond.to(DEV)
+    a = mdm(xd, tsd, y={'cond': c1}).clone()
+    addr = c1.data_ptr()
+    del c1
+    from interdiff_amd import _lib
+    c2 = torch.empty(cond.shape, dtype=torch.float32, device=DEV)            # same size class: the allocator may reuse the block
+    _lib.check(mdm.lib.interdiff_randn(_lib.dptr(c2), c2.numel(), 77, 0, _lib.stream()), 'randn')   # raw-pointer write: version stays 0
+    assert c2._version == 0
+    b = mdm(xd, tsd, y={'cond': c2})
+    ref = oden.mdm_forward(fx.mdm_weights(), x, ts, c2.cpu())
+    close(b, ref, 1e-4, 'second memory (address %s)' % ('recycled' if c2.data_ptr() == addr else 'fresh'))
+    assert rel(a, b) > 1e-3

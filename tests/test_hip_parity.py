@@ -757,3 +757,28 @@ def test_memory_fold_is_not_reused_for_a_recycled_cond_address(mdm):
     ref = oden.mdm_forward(fx.mdm_weights(), x, ts, c2.cpu())
     close(b, ref, 1e-4, 'second memory (address %s)' % ('recycled' if c2.data_ptr() == addr else 'fresh'))
     assert rel(a, b) > 1e-3
+
+
+@pytest.mark.gpu
+def test_graph_cache_serves_new_samples_without_recapture(mdm, smpl):
+    """Two samples of the same shape with DIFFERENT cond / gt / mask tensors: the second one replays the first one's captured
+    graphs (no new capture) and still equals its own eager run bit for bit."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P = 12, 2, 64
+    diff = create_gaussian_diffusion('cosine', 1000)
+    corr = make_correction(smpl, T, P)
+    outs = []
+    for seed in (31, 32):
+        bt = fx._clip(seed, B, T, P)
+        y = dev(fx.model_kwargs_y(bt, T))
+        noise = bt['noise'].to(DEV)
+        g = diff.p_sample_loop(mdm, tuple(noise.shape), noise=noise, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=corr, seed=5,
+                               n_steps=120, first_t=560)
+        e = diff.p_sample_loop(mdm, tuple(noise.shape), noise=noise, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=corr, seed=5,
+                               n_steps=120, first_t=560, use_graph=False)
+        assert torch.equal(g, e)
+        outs.append(g)
+        if seed == 31:
+            n_graphs = {k: len(v.graphs) for k, v in diff._graphs.items()}
+    assert len(diff._graphs) == 1 and {k: len(v.graphs) for k, v in diff._graphs.items()} == n_graphs
+    assert not torch.equal(outs[0], outs[1])

@@ -36,11 +36,20 @@ class MeshTopology:
 
 
 def _topology(faces, V, device):
+    """Topology of the mesh `faces` describes, from a small cache keyed by CONTENT: the reference hands in a freshly repeated faces
+    tensor on every call (eval_smpl_short.py:98), so an address is neither stable nor unique.  One device compare per call; the hot
+    path holds a MeshTopology and never comes here."""
     f0 = faces[0] if faces.dim() == 3 else faces
-    key = (f0.data_ptr(), tuple(f0.shape), V, str(device))
-    if key not in _ADJ_CACHE:
-        _ADJ_CACHE[key] = MeshTopology(f0, V, device)
-    return _ADJ_CACHE[key]
+    key = (tuple(f0.shape), V, str(device))
+    f32 = f0.to(device=device, dtype=torch.int32)
+    for topo in _ADJ_CACHE.get(key, []):
+        if torch.equal(topo.faces, f32):
+            return topo
+    topo = MeshTopology(f0, V, device)
+    _ADJ_CACHE.setdefault(key, []).append(topo)
+    if len(_ADJ_CACHE[key]) > 4:
+        _ADJ_CACHE[key].pop(0)
+    return topo
 
 
 def vertex_normals(vertices, faces):

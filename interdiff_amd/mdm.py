@@ -178,6 +178,7 @@ class MDM:
         self.device = torch.device(device)
         self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
         self._mem_key, self._mem_cond, self._memctx, self._ws = None, None, None, None
+        self._ws_shape, self._ws_pool, self._memctx_pool = None, {}, {}
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -193,10 +194,17 @@ class MDM:
         return self
 
     def _workspace(self, B, T):
+        """Workspace for a (B, T) forward.  Buffers are NEVER released or replaced once handed out: their addresses may be
+        baked into a captured hipGraph that is replayed long after a call with another shape came by."""
         need = self.lib.interdiff_mdm_workspace_bytes(B, T)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        if self._ws is not None and self._ws.numel() >= need and self._ws_shape == (B, T):
+            return self._ws
+        ws = self._ws_pool.get((B, T))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_pool[(B, T)] = ws
+        self._ws, self._ws_shape = ws, (B, T)
+        return ws
 
     def prepare_memory(self, cond):
         """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands."""
@@ -206,9 +214,11 @@ class MDM:
         given = cond
         cond = cond.contiguous()
         need = self.lib.interdiff_mdm_memctx_floats(B)
-        # the buffer is reused when the size matches: its address may be baked into a captured hipGraph
-        memctx = self._memctx if (self._memctx is not None and self._memctx.numel() == need) else \
-            torch.empty(need, dtype=torch.float32, device=self.device)
+        # one buffer per batch size, reused for every sample and never released: its address may be baked into a captured hipGraph
+        memctx = self._memctx_pool.get(B)
+        if memctx is None or memctx.numel() != need:
+            memctx = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._memctx_pool[B] = memctx
         ws = self._workspace(B, 16)
         _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                          _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),

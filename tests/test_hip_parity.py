@@ -702,14 +702,26 @@ def test_hot_path_writes_stay_inside_their_buffers(mdm, smpl):
     raw_ws, ws = _guarded(need_ws, DEV)
     raw_mc, mc = _guarded(mdm.lib.interdiff_mdm_memctx_floats(B) * 4, DEV)
     raw_o, o = _guarded(B * 144 * T * 4, DEV)
-    saved = (mdm._ws, mdm._memctx, mdm._mem_key)
+    saved = (mdm._ws, mdm._ws_shape, mdm._mem_key, mdm._ws_pool.get((B, T)), mdm._ws_pool.get((B, 16)), mdm._memctx_pool.get(B))
     try:
-        mdm._ws, mdm._memctx, mdm._mem_key = ws, mc.view(torch.float32), None
+        mdm._ws, mdm._ws_shape, mdm._mem_key = None, None, None
+        mdm._ws_pool[(B, T)], mdm._memctx_pool[B] = ws, mc.view(torch.float32)
+        mdm._ws_pool.pop((B, 16), None)                         # the memory fold takes its own (B, 16) workspace: let it allocate
         out = o.view(torch.float32).view(B, 1, 144, T)
         got = mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)}, out=out)
         close(got, oden.mdm_forward(fx.mdm_weights(), x, ts, cond), 1e-4, 'guarded denoiser forward')
+        assert mdm._memctx.data_ptr() == mc.data_ptr() and mdm._ws.data_ptr() == ws.data_ptr()
     finally:
-        mdm._ws, mdm._memctx, mdm._mem_key = saved
+        mdm._ws, mdm._ws_shape, mdm._mem_key = saved[0], saved[1], None
+        for k, v in (((B, T), saved[3]), ((B, 16), saved[4])):
+            if v is None:
+                mdm._ws_pool.pop(k, None)
+            else:
+                mdm._ws_pool[k] = v
+        if saved[5] is None:
+            mdm._memctx_pool.pop(B, None)
+        else:
+            mdm._memctx_pool[B] = saved[5]
     assert _intact(raw_ws) and _intact(raw_mc) and _intact(raw_o)
     # body model: exact-size outputs and workspace
     N = 5
@@ -782,3 +794,27 @@ def test_graph_cache_serves_new_samples_without_recapture(mdm, smpl):
             n_graphs = {k: len(v.graphs) for k, v in diff._graphs.items()}
     assert len(diff._graphs) == 1 and {k: len(v.graphs) for k, v in diff._graphs.items()} == n_graphs
     assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_captured_graphs_survive_calls_with_other_shapes(mdm, smpl):
+    """A sample is captured at one batch size, a bigger batch then runs through the same denoiser (new workspace and memory
+    context), and the first shape's captured graphs are replayed: their baked-in buffers must still be theirs."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    T, P = 12, 64
+    small = fx._clip(41, 2, T, P)
+    big = fx._clip(42, 5, T, P)
+
+    def run(bt, use_graph):
+        y = dev(fx.model_kwargs_y(bt, T))
+        n = bt['noise'].to(DEV)
+        return diff.p_sample_loop(mdm, tuple(n.shape), noise=n, clip_denoised=False, model_kwargs={'y': y}, seed=9, n_steps=60,
+                                  use_graph=use_graph)
+    a1 = run(small, True)
+    junk = [torch.full((1 << 22,), float('nan'), device=DEV) for _ in range(8)]      # whatever gets freed is likely to land here
+    b1 = run(big, True)
+    del junk
+    junk = [torch.full((1 << 22,), float('nan'), device=DEV) for _ in range(8)]
+    a2 = run(small, True)
+    assert torch.equal(a1, a2) and torch.equal(a1, run(small, False)) and torch.equal(b1, run(big, False))

@@ -6,8 +6,10 @@ Mirrors ``sample_once_proj`` (:133-177), ``sample_once`` (:179-215), ``get_gt`` 
 
     gt [B,1,144,T]   cond [10,B,256]   hand_pose [T,B,90] (GT hands, NOT padded)   beta [T,B,10]   obj_points [B,P,3]
 
-torch is used for views / concatenation only; every arithmetic step (rot6d -> axis-angle, SMPL, nearest
-neighbours, the metric reductions) runs in libinterdiff_hip.so.
+torch is used for views / concatenation; every arithmetic step of the scored path (rot6d -> axis-angle, SMPL, nearest
+neighbours, the metric reductions) runs in libinterdiff_hip.so.  The only tensor arithmetic left to torch is a handful of
+elementwise adds outside it: the rendering-only ``smooth`` and the translation re-centring between the windows of
+``sample_long``.
 """
 import ctypes as C
 import torch

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/interdiff_hip.h"
 
 #define IDF_WAVE 64
@@ -19,6 +20,19 @@
 static inline hipStream_t idf_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t idf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t idf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute belongs to (kernel, device), so `done` is a per-kernel bit
+// mask of the devices it has been set on: an idempotent, lock-free cache (a racing thread merely sets the attribute twice),
+// not state -- a process that drives several GPUs gets the opt-in on each of them.
+static inline int idf_opt_in_lds(const void *fn, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return IDF_E_LAUNCH;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return IDF_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return IDF_E_LAUNCH;
+    done.fetch_or(bit, std::memory_order_release);
+    return IDF_OK;
+}
 
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
 extern bool g_idf_prof_on;

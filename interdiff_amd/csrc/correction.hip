@@ -237,13 +237,8 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
     const int M = c->n_markers;
     const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
     if (lds > 160 * 1024 - 8192) return IDF_E_INVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(corr_contact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 8192) != hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
                        c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
     return IDF_OK;

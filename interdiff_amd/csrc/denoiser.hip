@@ -406,6 +406,13 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
     }
 }
 
+// self_attn_kernel needs more than 64 KiB of dynamic LDS for long clips: per-device opt-in (common.h)
+int attn_opt_in() {
+    static std::atomic<uint64_t> lds_ok{0};
+    return idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel),
+                          (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float)), lds_ok);
+}
+
 struct Ws {
     float *uA, *uB, *xn, *x2, *ctx, *qkv, *hid;
 };
@@ -530,9 +537,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     const float *lnp_w = nullptr, *lnp_b = nullptr;
     const int TP = (T + 15) & ~15;
     const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(self_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float))) != hipSuccess)
-        return IDF_E_LAUNCH;
+    if (attn_opt_in() != IDF_OK) return IDF_E_LAUNCH;
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->enc_layer[l];
@@ -594,13 +599,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
     const float *lnp_w = nullptr, *lnp_b = nullptr;   // LayerNorm still to be applied to u_in (none for layer 0)
     const int TP = (T + 15) & ~15;
     const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(self_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float))) != hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
+    if (attn_opt_in() != IDF_OK) return IDF_E_LAUNCH;
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];

@@ -35,7 +35,9 @@ struct Args {
     const int64_t *ts;              // E_EMBED: timestep per clip
     const float *temb, *pe;         // E_EMBED: [n_steps][N], [max_T][N]
     int n_steps;
-    long long *probe;               // tools/gemm_probe.hip only: per-workgroup s_memtime stamps (null on the product path)
+#ifdef IDF_GEMM_PROBE
+    long long *probe;               // tools/gemm_probe.hip only (built with -DIDF_GEMM_PROBE): per-workgroup s_memtime stamps
+#endif
 };
 
 // XCD-aware tile order (workgroup b is dispatched to XCD b % 8, each XCD has its own L2): remap the linear
@@ -50,6 +52,13 @@ __device__ __forceinline__ void xcd_tile(int ntn, int &mt, int &nt, int &wg) {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// phase stamps exist only in the probe build of tools/gemm_probe.hip; the product kernels carry no pointer and no branch for them
+#ifdef IDF_GEMM_PROBE
+#define IDF_PROBE_STAMP(g, wg, slot) do { if ((g).probe && threadIdx.x == 0) (g).probe[(wg) * 4 + (slot)] = clock64(); } while (0)
+#else
+#define IDF_PROBE_STAMP(g, wg, slot) do { } while (0)
+#endif
 
 #define IDF_MFMA4(acc, a, b)                                            \
     do {                                                                \
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
         }
     };
 
-    if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
+    IDF_PROBE_STAMP(g, wg, 0);
     load_b(0);
     if constexpr (APRO == A_LN) {
         // whole rows: wave w owns rows w, w+NW, ...; a lane holds 4 consecutive features of the 256-wide row
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     }
     store_b(0);
     __syncthreads();
-    if (g.probe && tid == 0) g.probe[wg * 4 + 1] = clock64();
+    IDF_PROBE_STAMP(g, wg, 1);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
         __syncthreads();
     }
 
-    if (g.probe && tid == 0) g.probe[wg * 4 + 2] = clock64();
+    IDF_PROBE_STAMP(g, wg, 2);
     float rres[TM][TN][4], bvs[TN];
     load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
     if constexpr (EPI == E_RESID) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     } else {
         epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     }
-    if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
+    IDF_PROBE_STAMP(g, wg, 3);
 }
 
 template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     const int li = lane & 15, kq = lane >> 4;
     const int K = g.K, M = g.M, N = g.N;
     const int nk = K / KC;
-    if (g.probe && tid == 0) g.probe[wg * 4 + 0] = clock64();
+    IDF_PROBE_STAMP(g, wg, 0);
 
     // per-wave DMA descriptors: instruction i = wave + NW*j of the IPC that make up one chunk; lane l of it fills
     // the 16-B LDS cell p = 64 i + l, i.e. (row p / CH, position p % CH), from source chunk (p % CH) ^ (row % CH)
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     wait_landed(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (g.probe && tid == 0) g.probe[wg * 4 + 1] = clock64();
+    IDF_PROBE_STAMP(g, wg, 1);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
         __builtin_amdgcn_s_barrier();
         st = st == NS - 1 ? 0 : st + 1;
     }
-    if (g.probe && tid == 0) g.probe[wg * 4 + 2] = clock64();
+    IDF_PROBE_STAMP(g, wg, 2);
 
     if constexpr (KS > 1) {
         // all LDS reads of the k-loop are behind the last barrier: reuse the buffer for the partial tiles
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     } else {
         if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     }
-    if (g.probe && tid == 0) g.probe[wg * 4 + 3] = clock64();
+    IDF_PROBE_STAMP(g, wg, 3);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>

@@ -288,12 +288,8 @@ extern "C" int interdiff_objprojector_sample(const idf_objproj *op, const float 
     for (int l = 0; l < 12; ++l)
         if (op->cin[l] > 32 || op->cout[l] > 32 || op->cin[l] + op->cout[l] > POOL_CH) return IDF_E_INVAL;
     const size_t lds = ((size_t)POOL_CH * PLANE + (size_t)CH * PLANE + 128) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(objproj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(objproj_kernel), (int)lds, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     idf_prof_mark(IDF_K_OBJPROJ, idf_stream(stream));
     hipLaunchKernelGGL(objproj_kernel, dim3(B), dim3(NTHR), lds, idf_stream(stream), *op, obj_angles, obj_trans, markers, contact, B, out);
     idf_prof_mark(-1, idf_stream(stream));

@@ -627,13 +627,8 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
                        st->near);
     hipLaunchKernelGGL(opt_signed_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->pts, P, st->verts, V, st->yidx,
                        c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, st->y2x_signed, st->y2x);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(opt_lossgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
-            hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(opt_lossgrad_kernel), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(opt_lossgrad_kernel, dim3((unsigned)N), dim3(LG_T), (size_t)V * 3 * sizeof(float), s, st->verts, st->verts_gt, V,
                        st->y2x_signed, st->near, st->yidx, st->y2x, st->obj_points, P, T, st->ctl, st->gv, st->grad, st->gtr, st->lossf);
     // A [N][J][12] sits behind the feature rows in the SMPL workspace (smpl.hip: interdiff_smpl_forward)

@@ -211,13 +211,8 @@ extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((unsigned)N), dim3(64), 0, s, *m, pose, betas, trans, feat, A, jtr);
     const size_t lds = std::max((size_t)(m->KB / 4) * AQS, (size_t)FT * STS) * sizeof(float);
     if (lds > 150 * 1024) return IDF_E_INVAL;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(smpl_blend_skin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
-            hipSuccess)
-            return IDF_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (lds > 64 * 1024 && idf_opt_in_lds(reinterpret_cast<const void *>(smpl_blend_skin_kernel), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     idf_prof_mark(IDF_K_SMPL_BLEND_SKIN, s);
     hipLaunchKernelGGL(smpl_blend_skin_kernel, dim3((unsigned)idf_cdiv(N, FT), (unsigned)idf_cdiv(m->V, VT)), dim3(256), lds, s, *m,
                        feat, A, trans, N, verts, v_posed);

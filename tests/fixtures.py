@@ -139,6 +139,19 @@ def eval_inputs():
     return batch, bt['noise'], NoiseStream(7000)
 
 
+FULL_SHAPE = (100, 16, 2048)          # T, B, P : BASELINE config #2 itself (eval_smpl_short.py, correction mode), full 1000 steps
+FULL_STEPS = 1000
+FULL_DUMPS = [0, 499, 500, 549, 749, 949, 999]      # loop indices (it): 499 = the first corrected step (t = 500), 999 = the sample
+
+
+def full_inputs():
+    """Clip batch + x_T + per-step noise stream of the full-size end-to-end golden (tests/golden/full.npz)."""
+    T, B, P = FULL_SHAPE
+    bt = _clip(31, B, T, P)
+    batch = dict(gt=bt['gt'], cond=bt['cond'], hand_pose=bt['hand_pose'], beta=bt['beta'], obj_points=bt['obj_points'])
+    return batch, bt['noise'], NoiseStream(8000)
+
+
 EMB_SHAPE = (35, 3, 2048)              # T, B, P : MDM._get_embeddings (encoder side, "next" row N1)
 
 

@@ -24,6 +24,9 @@ What each fixture pins (reference file:line in brackets):
   optim.npz        optimization.optimize (physics post-optimisation, "next" row N4) on one synthetic clip, restricted to the
                    iteration numbers fx.OPT_ITERS: its printed losses, the parameters and gradients its Adam sees at each of
                    them, the parameters after the last, and the record it returns [optimization.py:19-173]
+  full.npz         BASELINE config #2 end to end (B=16, T=100, P=2048, 1000 steps, correction mode): the reference's own
+                   sample_once_proj / get_gt / metrics with injected noise, the sampler state at fx.FULL_DUMPS and the hook's
+                   per-call decisions; generated separately (`make_golden.py full`, ~35 min) [eval_smpl_short.py:84-177]
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
@@ -150,9 +153,87 @@ def gen_optim():
     save('optim.npz', **res)
 
 
+def gen_full():
+    """BASELINE config #2 end to end on the reference's own code: eval_smpl_short.sample_once_proj (1000-step p_sample_loop with the
+    reference MDM and the reference denoised_fn, injected x_T and per-step noise) at B=16, T=100, P=2048, then get_gt and metrics.
+    Recorded besides the outputs: the sampler state at fx.FULL_DUMPS and, for each of the 11 correction calls, which clips the hook
+    rewrote (``condition``) and the contact counts it handed to ObjProjector.sample (whose argmax picks the reference marker).
+    ~35 min on 8 cores; `python tests/golden/make_golden.py full`."""
+    import time
+    ev = refshim.load('eval_smpl_short')
+    gd = refshim.load('diffusion.gaussian_diffusion')
+    net = ref_mdm()
+    L = ref_smpl(fx.smpl_model())
+    T, B, P = fx.FULL_SHAPE
+    past = fx.PAST
+    batch, noise, stream = fx.full_inputs()
+    ev.args = Namespace(smpl_dim=132, past_len=past, future_len=T - past)
+    ev.idx_pad = list(range(past)) + [past - 1] * (T - past)
+    ev.device = torch.device('cpu')
+
+    class Holder:
+        pass
+    om = Holder()
+    om.model = ref_objproj(T)
+    ev.obj_model = om
+    net._get_embeddings = lambda b, device: (batch['cond'], batch['gt'].squeeze(1).permute(2, 0, 1).contiguous())
+    lit = Holder()
+    diff = ref_diffusion(fx.FULL_STEPS)
+    lit.model, lit.diffusion, lit.body_model = net, diff, {'male': L}
+    ev.model = lit
+    rec = dict(t=[], condition=[], contact=[])
+    real_sample = om.model.sample
+
+    def sample_spy(obj_angles, obj_trans, human_verts, contact, *a, **k):
+        rec['contact'].append(np_(contact).astype(np.int32))
+        return real_sample(obj_angles, obj_trans, human_verts, contact, *a, **k)
+    om.model.sample = sample_spy
+    real_hook = ev.denoised_fn
+    t0 = time.time()
+
+    def hook_spy(x, t, model_kwargs):
+        gated = not (t[0] > 500 or t[0] % 50 != 0)
+        before = x.clone() if gated else None
+        out = real_hook(x, t, model_kwargs)
+        if gated:
+            rec['t'].append(int(t[0]))
+            rec['condition'].append(np_((out != before).flatten(1).any(dim=1)))
+            print('  correction at t=%d: %d/%d clips rewritten (%.0f s)' % (int(t[0]), int(rec['condition'][-1].sum()), B, time.time() - t0), flush=True)
+        return out
+    ev.denoised_fn = hook_spy
+    real_loop = diff.p_sample_loop
+    dumps = {}
+
+    def loop_spy(model, shape, **kw):
+        out = real_loop(model, shape, dump_steps=fx.FULL_DUMPS, **kw)
+        dumps.update({s: v for s, v in zip(fx.FULL_DUMPS, out)})
+        return out[-1]
+    diff.p_sample_loop = loop_spy
+    pose_full = torch.cat([torch.zeros(T, B, 66), batch['hand_pose']], dim=2)     # only [:, 66:] is read (:146)
+    rb = {'frames': [{'smplfit_params': {'pose': pose_full[t], 'betas': batch['beta'][t]}} for t in range(T)],
+          'obj_points': torch.cat([batch['obj_points'], torch.zeros(B, P, 3)], dim=2)}
+    real_randn, real_randn_like = torch.randn, gd.th.randn_like
+    gd.th.randn_like = lambda x: stream.next_like(x)
+    torch.randn = lambda *shape, **kw: noise.clone()
+    try:
+        obj, body, verts, jtrs, pelvis = ev.sample_once_proj(rb)
+    finally:
+        torch.randn, gd.th.randn_like = real_randn, real_randn_like
+    print('sampled in %.0f s' % (time.time() - t0), flush=True)
+    obj_gt, jtr_gt, body_gt, faces = ev.get_gt(rb)
+    met = ev.metrics(obj[past:], jtrs[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces,
+                     batch['obj_points'])
+    from oracle.correction import MARKERS67
+    save('full.npz', obj=np_(obj), body=np_(body), markers=np_(verts[:, :, MARKERS67]), jtr=np_(jtrs),
+         corr_t=np.array(rec['t']), condition=np.stack(rec['condition']), contact=np.stack(rec['contact']),
+         **{'dump_%d' % s: np_(v) for s, v in dumps.items()}, **{'m_' + k: np_(v) for k, v in met.items()})
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'optim':
         return gen_optim()
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        return gen_full()
     # ---- real correction checkpoint -> plain arrays (must exist before fx.objproj_weights())
     ck = torch.load('/root/reference/interdiff/checkpoints/correction.ckpt', map_location='cpu', weights_only=False)
     save('correction_ckpt.npz', **{k[len('model.'):]: np_(v) for k, v in ck['state_dict'].items()})

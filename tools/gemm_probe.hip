@@ -1,5 +1,5 @@
 // GEMM tile-configuration probe (not product code):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I interdiff_amd/csrc tools/gemm_probe.hip -o build_tools/gemm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIDF_GEMM_PROBE -I interdiff_amd/csrc tools/gemm_probe.hip -o build_tools/gemm_probe
 // Times every tile configuration of gemm.h on the denoiser's shapes (M = 1600) with back-to-back launches and
 // prints the per-workgroup phase breakdown (prologue / k-loop / epilogue, in shader-clock ticks) from the probe stamps.
 #include "gemm.h"

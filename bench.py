@@ -2,14 +2,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one DDPM reverse step (p_sample: denoiser forward + x0-inpainting + [gated correction] +
-posterior update with in-kernel noise) over one batch of B=16 BEHAVE-shaped synthetic clips of T=100
-frames per GPU (BASELINE config #2: eval_smpl_short.py, B=16, T=100, 1000-step DDPM, correction mode).
-The timed region runs the first K iterations of the 1000-step loop (t = 999 .. 1000-K); the default
-K=1000 is one complete sample: 989 plain steps + the 11 correction steps (t in {500,450,..,0}) and the
-once-per-sample memory folding.  Inputs are resident in HBM before the clock starts.
+A "step" is one DDPM reverse step (p_sample: denoiser forward + x0-inpainting + [gated correction] + posterior update with
+in-kernel noise) over one batch of B=16 BEHAVE-shaped synthetic clips of T=100 frames per GPU (BASELINE config #2:
+eval_smpl_short.py, B=16, T=100, 1000-step DDPM, correction mode).
 
-value = frame-steps/s = K * B_total * T / wall  (whole job, all ranks; weak scaling: B=16 per GPU).
+The timed region is ALWAYS made of whole samples: ceil(K / 1000) complete 1000-step samples, each with its 989 plain steps, its
+11 gated correction steps (t in {500,450,..,0}: SMPL-H FK + LBS, normals, signed nearest neighbours, contact-frame predictor) and
+the once-per-sample memory folding -- whatever --steps says (the default and every K <= 1000 time exactly one sample), so that the
+headline is the rate of the workload eval_smpl_short.py runs, never a window of plain steps.  `steps` in the JSON line is the number
+of steps really timed, `steps_requested` echoes --steps.  Inputs are resident in HBM before the clock starts.
+
+value = frame-steps/s = steps * B_total * T / wall  (whole job, all ranks; weak scaling: B=16 per GPU).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself as N ranks (torch.distributed.run, one per GPU).
+After the timed region every rank scores its clips and the six per-clip metric vectors are collated with the path's one collective
+(RCCL all-gather); rank 0 then measures, outside the clock: the same sample in no_correction mode, BASELINE config #3 (B=32),
+a K-step window of plain steps, the per-kernel profile + roofline kernel, the conditioning path, the post-optimisation row and the
+CPU baseline.
 """
 import argparse
 import ctypes as C
@@ -36,6 +45,7 @@ B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
 FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_GEMM_FLOP_PER_TOKEN = 2 * 256 * 1024                    # one of the two FFN GEMMs
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
+DOMINANT_KERNEL_ID = 'gemm_glds_kernel<32,32,2,2,2,64,A_PLAIN,E_RESID>'      # the build the roofline block (and traffic.json) speaks about
 
 
 def tt(d, dev=None):
@@ -66,20 +76,8 @@ def build_world(dev, rank):
     return model, corr, bt, y, (sd, smpl_np, osd)
 
 
-def step_window(K):
-    """Timesteps a K-step timed region covers.  K = 1000: the whole sample.  K < 1000: a window of the schedule holding the same
-    SHARE of gated correction steps as the whole sample (11 per 1000: t <= 500 and t % 50 == 0), so that a shorter run measures
-    the same per-step mix: the window ends on the round(K*11/1000)-th correction step counted from t = 500 (none below 46 steps)."""
-    if K >= STEPS:
-        return STEPS - 1, 11
-    n = int(round(K * 11 / 1000.0))
-    if n == 0:
-        return STEPS - 1, 0
-    last = 500 - 50 * (n - 1)                                  # window = [last + K - 1, last]
-    return last + K - 1, n
-
-
 def run_steps(diff, model, corr, bt, y, n_steps, seed, use_graph=True, first_t=None):
+    """n_steps iterations of the 1000-step loop from t = first_t (default 999); `corr` None = no_correction mode."""
     return diff.p_sample_loop(model, tuple(bt['noise'].shape), noise=bt['noise'], clip_denoised=False, first_t=first_t,
                               model_kwargs={'y': y}, denoised_fn=corr, seed=seed, n_steps=n_steps, use_graph=use_graph)
 
@@ -153,8 +151,10 @@ def usable_cores():
 
 
 def cpu_baseline(assets, bt_cpu, y_cpu):
-    """The oracle (CPU restatement of the reference path), timed on this box's host cores, bounded sample:
-    2 plain denoiser steps at the full B=16,T=100 batch + 1 correction call on 1 of the 16 clips (x16)."""
+    """The oracle (CPU restatement of the reference path), timed on this box's host cores on a bounded sample of the SAME mix the
+    GPU headline times (989 plain + 11 corrected steps per sample): 3 warm-up + 5 timed plain steps at the full B=16,T=100 batch,
+    and 3 timed correction calls (denoised_fn at t = 500, 250, 0), each on one clip of the batch and scaled to 16 clips (the
+    hook is independent per clip; a 16-clip call takes ~80 s)."""
     from oracle import diffusion as odf, denoiser as oden, correction as ocor
     sd, smpl_np, osd = assets
     sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
@@ -168,23 +168,31 @@ def cpu_baseline(assets, bt_cpu, y_cpu):
         x0 = oden.mdm_forward(sd_t, x, ts, y_cpu['cond'])
         x0 = x0 * (~y_cpu['inpainting_mask']) + y_cpu['inpainted_motion'] * y_cpu['inpainting_mask']
         return float(sched['posterior_mean_coef1'][999]) * x0 + float(sched['posterior_mean_coef2'][999]) * x + 0.1 * torch.randn_like(x)
-    plain()
-    t0 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(3):
         plain()
-    t_plain = (time.perf_counter() - t0) / 2
-    nb = 1
-    ysub = {k: (v[:, :nb] if k in ('cond', 'hand_pose', 'beta') else v[:nb]) if isinstance(v, torch.Tensor) else v
-            for k, v in y_cpu.items()}
-    ysub.update(smpl={k: torch.from_numpy(v) for k, v in smpl_np.items()}, obj_model={k: torch.from_numpy(v) for k, v in osd.items()})
+    n_plain = 5
     t0 = time.perf_counter()
-    ocor.denoised_fn(bt_cpu['gt'][:nb].clone(), torch.full((nb,), 500, dtype=torch.int64), {'y': ysub}, past_len=PAST)
-    t_corr = (time.perf_counter() - t0) * (B_PER_GPU / nb)
+    for _ in range(n_plain):
+        plain()
+    t_plain = (time.perf_counter() - t0) / n_plain
+    smpl_t = {k: torch.from_numpy(v) for k, v in smpl_np.items()}
+    osd_t = {k: torch.from_numpy(v) for k, v in osd.items()}
+    t_calls = []
+    for clip, tval in ((0, 500), (1, 250), (2, 0)):
+        sl = slice(clip, clip + 1)
+        ysub = {k: (v[:, sl] if k in ('cond', 'hand_pose', 'beta') else v[sl]) if isinstance(v, torch.Tensor) else v
+                for k, v in y_cpu.items()}
+        ysub.update(smpl=smpl_t, obj_model=osd_t)
+        t0 = time.perf_counter()
+        ocor.denoised_fn(bt_cpu['gt'][sl].clone(), torch.full((1,), tval, dtype=torch.int64), {'y': ysub}, past_len=PAST)
+        t_calls.append(time.perf_counter() - t0)
+    t_corr = sum(t_calls) / len(t_calls) * B_PER_GPU
     steps_per_s = STEPS / ((STEPS - 11) * t_plain + 11 * (t_plain + t_corr))
     return dict(value=steps_per_s * B_PER_GPU * T, unit='frame-steps/s', cores=cores, kind='port',
-                sample='2 plain steps at B=16,T=100 (%.2f s/step) + 1 correction call on 1 of 16 clips scaled x16 (%.1f s/call); '
-                       'blended over 989 plain + 11 corrected steps; torch CPU fp32, %d threads' % (t_plain, t_corr, cores),
-                steps_per_sec=steps_per_s)
+                sample='3 warm-up + %d timed plain steps at B=16,T=100 (%.3f s/step) + 3 correction calls (t=500,250,0) on one clip '
+                       'each, scaled x16 (%.1f s per 16-clip call); blended over the 989 plain + 11 corrected steps of one sample = '
+                       'the mix the GPU headline times; torch CPU fp32, %d threads' % (n_plain, t_plain, t_corr, cores),
+                steps_per_sec=steps_per_s, plain_step_s=t_plain, correction_call_s=t_corr)
 
 
 def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
@@ -219,6 +227,32 @@ def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
     return out
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI)."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < args.gpus:
+        print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('no WORLD_SIZE in the environment: launching %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')))
+
+
+def timed_samples(diff, model, corr, bt, y, n, seed0=233):
+    """n complete 1000-step samples back to back on the current stream; returns (wall seconds, last sample)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_i in range(n):
+        out = run_steps(diff, model, corr, bt, y, STEPS, seed=seed0 + s_i)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
 def main():
     global B_PER_GPU
     ap = argparse.ArgumentParser()
@@ -228,16 +262,21 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-postopt', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the no_correction / B=32 / plain-window legs')
     ap.add_argument('--clips-per-gpu', type=int, default=B_PER_GPU,
                     help='NOT the BASELINE configuration unless 16: batch-scaling experiments only (DESIGN.md §4.1)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_spawn(args))
     B_PER_GPU = args.clips_per_gpu
     torch.set_grad_enabled(False)
     rank, world, local = idist.init_from_env('nccl' if args.gpus > 1 else None)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    K = max(1, args.steps)                    # more than 1000 steps = whole samples back to back, then a window for the rest
+    K = max(1, args.steps)
+    n_samples = (K + STEPS - 1) // STEPS              # whole samples only: the headline always contains the correction path
     log('building world (weights, SMPL-H stand-in, clips) on %s' % dev)
     model, corr, bt, y, assets = build_world(dev, rank)
     log('world ready')
@@ -251,74 +290,110 @@ def main():
     log('warm-up done')
 
     idist.barrier()
+    # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
+    wall_local, out = timed_samples(diff, model, corr, bt, y, n_samples)
+    idist.barrier()
+    wall = idist.max_over_ranks(wall_local, dev)
+    assert torch.isfinite(out).all()
+    n_timed = n_samples * STEPS
+    log('timed region: %d whole sample(s) = %d steps (incl. %d correction steps) in %.3f s' % (n_samples, n_timed, 11 * n_samples, wall))
+
+    # ---- eval leg, all ranks: every rank scores its clips, ONE all-gather (RCCL over xGMI) collates the six per-clip metric vectors
+    from interdiff_amd import eval as ev
+    clip_batch = dict(gt=bt['gt'], cond=bt['cond'], hand_pose=bt['hand_pose'], beta=bt['beta'], obj_points=bt['obj_points'])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
-    n_full, rem = divmod(K, STEPS)
-    t_first, n_corr = (STEPS - 1, 11 * n_full) if n_full else step_window(rem)
-    for s_i in range(n_full):
-        out = run_steps(diff, model, corr, bt, y, STEPS, seed=233 + s_i)
-    if rem:
-        t_rem, n_rem = step_window(rem)
-        out = run_steps(diff, model, corr, bt, y, rem, seed=233 + n_full, first_t=t_rem)
-        if n_full:
-            n_corr += n_rem
+    per_clip, means = ev.evaluate_sharded(model, diff, corr, clip_batch, PAST, mode='correction', diverse_samples=1, seed=1000,
+                                          presharded=True)
     torch.cuda.synchronize()
-    idist.barrier()
-    wall = idist.max_over_ranks(time.perf_counter() - t0, dev)
-    assert torch.isfinite(out).all()
-    log('timed region: %d steps in %.3f s' % (K, wall))
-    idist.shutdown()              # no collective after this point: rank 0 alone takes the profile / baseline legs below
+    eval_s = time.perf_counter() - t0
+    assert all(v.numel() == B_PER_GPU * world for v in per_clip.values())
+    idist.shutdown()              # no collective after this point: rank 0 alone takes the extra legs below
+    if rank != 0:
+        return
 
+    extra = {}
+    if not args.no_extra_configs:
+        w_nc, o_nc = timed_samples(diff, model, None, bt, y, 1)
+        extra['no_correction'] = dict(workload='the same clips, eval_smpl_short.py --mode no_correction (1000 plain steps)', steps=STEPS,
+                                      ms_per_step=1e3 * w_nc / STEPS, value=STEPS * B_PER_GPU * T / w_nc, unit='frame-steps/s')
+        # K-step window of plain steps from t = 999 (what --steps K alone would have timed): secondary, never the headline
+        kw = min(K, 450)
+        run_steps(diff, model, corr, bt, y, kw, seed=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(diff, model, corr, bt, y, kw, seed=3)
+        torch.cuda.synchronize()
+        w_win = time.perf_counter() - t0
+        extra['plain_step_window'] = dict(timesteps='999..%d' % (STEPS - kw), steps=kw, correction_steps_in_window=0,
+                                          ms_per_step=1e3 * w_win / kw, value=kw * B_PER_GPU * T / w_win, unit='frame-steps/s')
+        if B_PER_GPU == 16:
+            # BASELINE config #3: eval_smpl_short.py + correction predictor, B=32 (the reference's own default batch), same T
+            B_PER_GPU = 32
+            m3, c3, bt3, y3, _ = build_world(dev, rank)
+            run_steps(diff, m3, c3, bt3, y3, 57, seed=7)
+            c3.apply(bt3['noise'].clone(), 500, y3)
+            w3, o3 = timed_samples(diff, m3, c3, bt3, y3, 1)
+            assert torch.isfinite(o3).all()
+            extra['config3_B32_correction'] = dict(workload='eval_smpl_short.py correction mode, B=32, T=%d, one whole sample' % T, steps=STEPS,
+                                                   ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s')
+            del m3, c3, bt3, y3
+            B_PER_GPU = 16
+        log('extra configurations done')
     prof = None
-    if rank == 0 and not args.no_kernel_profile:
+    if not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
         dom_us = time_dominant_kernel(model, dev)
         log('kernel profile done')
-    enc_ms = None
-    if rank == 0:
-        # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
-        ei = tt(syn.make_embedding_inputs(seed=77, B=B_PER_GPU, T=T, n_points=P), dev)
-        args_e = (ei['body_pose'], ei['body_trans'], ei['obj_angles'], ei['obj_trans'], ei['obj_points'], PAST)
+    # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
+    ei = tt(syn.make_embedding_inputs(seed=77, B=B_PER_GPU, T=T, n_points=P), dev)
+    args_e = (ei['body_pose'], ei['body_trans'], ei['obj_angles'], ei['obj_trans'], ei['obj_points'], PAST)
+    model._get_embeddings(*args_e)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
         model._get_embeddings(*args_e)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            model._get_embeddings(*args_e)
-        e1.record()
-        e1.synchronize()
-        enc_ms = e0.elapsed_time(e1) / 5
+    e1.record()
+    e1.synchronize()
+    enc_ms = e0.elapsed_time(e1) / 5
     post = None
-    if rank == 0 and not args.no_postopt:
+    if not args.no_postopt:
         post = postopt_bench(corr.smpl, assets[1], dev, with_cpu=(world == 1 and not args.no_cpu_baseline))
         log('post-optimisation bench done')
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(assets, tt({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in bt.items()}),
                            {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in y.items()})
     log('cpu baseline done' if cpu else 'cpu baseline skipped')
-    if rank != 0:
-        return
     Btot = B_PER_GPU * world
-    line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=K * Btot * T / wall,
-                unit='frame-steps/s', n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=1e3 * wall / K,
+    line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=n_timed * Btot * T / wall,
+                unit='frame-steps/s', n_gpus=world, steps=n_timed, steps_requested=K, warmup=args.warmup, ms_per_step=1e3 * wall / n_timed,
                 higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                steps_per_sec=K / wall,
+                steps_per_sec=n_timed / wall,
                 config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
                                      '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
                                      'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
-                            global_batch=Btot, seq_len=T, correction_steps_in_region=n_corr, timesteps=('%d..%d' % (t_first, t_first - K + 1)) if not n_full else ('%d whole sample(s)' % n_full + (' + %d..%d' % (t_rem, t_rem - rem + 1) if rem else '')), parallelism='clips sharded x%d' % world))
+                            global_batch=Btot, seq_len=T, samples_in_region=n_samples, correction_steps_in_region=11 * n_samples,
+                            plain_steps_in_region=989 * n_samples, timesteps='%d whole sample(s): t = 999..0' % n_samples,
+                            parallelism='clips sharded x%d' % world))
+    line['eval_collation'] = dict(collective='all_gather of [6, B_local] fp32 (%s), %d ranks' % ('RCCL' if world > 1 else 'degenerate: 1 rank', world),
+                                  seconds_sample_plus_metrics=eval_s, clips=Btot, means=means,
+                                  note='random-init denoiser: the metric values only serve as parity evidence against the oracle')
+    line.update(extra)
     if prof:
         dom = 'gemm_ffn2'
         us = dom_us
         flops = FFN_GEMM_FLOP_PER_TOKEN * B_PER_GPU * T
         ach = flops / (us * 1e-6) / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom)
+            tj = json.load(open(tf))
+            if tj.get('kernel_id') == DOMINANT_KERNEL_ID:          # a PMC figure is only valid for the kernel build it was taken on
+                traffic, traffic_src = tj.get(dom), tj.get('_how')
         line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
-                                traffic=traffic, us_per_launch=us, algorithmic_flop_per_launch=flops,
+                                traffic=traffic, us_per_launch=us, algorithmic_flop_per_launch=flops, kernel_id=DOMINANT_KERNEL_ID,
+                                traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
                                 note='16 of the 32 launches of a denoiser forward are this GEMM shape (FFN); duration = HIP events around 200 '
                                      'back-to-back launches replayed from a hipGraph on the launch stream (rocprofv3 in-situ average: profiles/)')
         dn = sum(v['ms_total'] for k, v in prof.items() if k.startswith(('embed', 'gemm', 'self_attn', 'rowblock')))
@@ -326,8 +401,7 @@ def main():
         line['denoiser_forward'] = dict(us=1e3 * dn / nfw, achieved_tflops=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12,
                                         frac_of_f32_mfma_peak=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12 / PEAK_F32_MFMA_TFLOPS)
         line['kernels_us_event_to_event'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}    # includes the launch gap + event records
-    if enc_ms is not None:
-        line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)
+    line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)
     if post:
         line['post_optimisation'] = post                    # "next" row N4 (optimization.py), outside the timed region
     if cpu:

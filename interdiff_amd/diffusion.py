@@ -18,6 +18,7 @@ Host-side design (not a translation of the reference loop):
 Only the configuration the eval path uses is implemented (ModelMeanType.START_X, ModelVarType.FIXED_SMALL,
 clip_denoised=False, identity timestep map); anything else raises NotImplementedError.
 """
+import itertools
 import math
 import os
 from types import SimpleNamespace
@@ -39,6 +40,15 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
 
 
 GRAPH_BLOCKS = (49, 7, 1)          # plain steps per captured hipGraph (49 = the gap between two correction steps)
+MAX_GRAPH_SHAPES = 8               # captured (shape, mask, cond) entries kept per denoiser before the cache is dropped wholesale
+_UID = itertools.count(1)
+
+
+def fresh_seed():
+    """A 62-bit seed from torch's global CPU generator: what a caller who passes no ``seed`` gets, so that every sampling call
+    draws its own per-step noise stream (the reference calls ``randn_like`` afresh in every step of every call,
+    gaussian_diffusion.py:532) while ``torch.manual_seed`` still makes a whole run reproducible."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 class GaussianDiffusion:
@@ -61,7 +71,8 @@ class GaussianDiffusion:
         self._c2 = self.posterior_mean_coef2.astype(np.float32)
         self._sigma = np.exp(np.float32(0.5) * self.posterior_log_variance_clipped.astype(np.float32)).astype(np.float32)
         self._t_cache = {}
-        self._tables, self._graphs = {}, {}
+        self._tables = {}
+        self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
     # ------------------------------------------------------------------ helpers
     def _timesteps(self, B, device):
@@ -95,17 +106,23 @@ class GaussianDiffusion:
         # The captured graphs read the sample's inputs from buffers this cache entry OWNS (x, gt, mask, cond): one capture per
         # (denoiser, shape) then serves every sample -- an eval loop or an autoregressive rollout feeds a new cond / gt per sample
         # and must not pay a re-capture (57 denoiser forwards) each time.
-        key = (id(model), tuple(img.shape), has_mask, tuple(cond.shape))
-        st = self._graphs.get(key)
+        # The cache lives ON the denoiser object: the captured graphs bake in the addresses of its arena, workspace and memory
+        # context, so they must die with it (a cache keyed by id(model) would replay freed memory once the id is recycled).
+        cache = model.__dict__.setdefault('_graph_cache', {})
+        key = (self._uid, tuple(img.shape), has_mask, tuple(cond.shape))
+        st = cache.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),
                                  state=torch.zeros(4, dtype=torch.int64, device=dev), cond=torch.empty_like(cond, memory_format=torch.contiguous_format),
                                  gt=torch.empty_like(img) if has_mask else None,
                                  mask=torch.empty(img.shape, dtype=torch.uint8, device=dev) if has_mask else None, graphs={})
             st.kwargs = {'y': {'cond': st.cond}}              # what the captured denoiser calls see
-            if len(self._graphs) > 8:
-                self._graphs.clear()
-            self._graphs[key] = st
+            if len(cache) >= MAX_GRAPH_SHAPES:
+                cache.clear()                        # graphs first, then the buffers whose addresses they held
+                release = getattr(model, 'release_shape_buffers', None)
+                if release is not None:
+                    release()
+            cache[key] = st
             fresh = True
         else:
             fresh = False
@@ -186,10 +203,11 @@ class GaussianDiffusion:
     # ------------------------------------------------------------------ public surface
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
-                      cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None, seed=0, n_steps=None,
+                      cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None, seed=None, n_steps=None,
                       use_graph=True, first_t=None):
         """Same keyword surface as the reference (:598-614).  Extra: ``step_noise`` (tensor [n,...] or callable
-        (loop_index, x) -> tensor) for deterministic parity, ``seed`` for the in-kernel generator, ``n_steps`` to
+        (loop_index, x) -> tensor) for deterministic parity, ``seed`` for the in-kernel generator (None: a fresh one per call
+        from torch's global generator, see ``fresh_seed``), ``n_steps`` to
         run only the first n iterations (t = T-1 .. T-n) -- used by the bench / short-chain parity tests, ``use_graph=False``
         to force the eager route, ``first_t`` to enter the schedule at that timestep with ``noise`` taken as x_{first_t}
         (a window of the loop for measurements; default T-1)."""
@@ -199,6 +217,8 @@ class GaussianDiffusion:
             raise NotImplementedError('only noise=, denoised_fn=, model_kwargs=, dump_steps= are live (SURVEY.md §8(b))')
         if model_kwargs is None:
             model_kwargs = {}
+        if seed is None:
+            seed = fresh_seed()
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))

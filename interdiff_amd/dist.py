@@ -23,6 +23,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def get_rank_world():
+    """(rank, world) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def shard_slice(n_items, rank, world):
     """Contiguous, balanced shard of n_items for this rank."""
     base, rem = divmod(n_items, world)
@@ -95,3 +102,46 @@ def _selftest_worker(rank, world, port):
     barrier()
     shutdown()
     assert not dist.is_initialized()
+
+
+def _selftest_eval_worker(rank, world, port):
+    """evaluate_sharded on CPU ranks (gloo): the sampler + metrics of ``evaluate_batch`` need the GPU, so a stand-in scores every
+    clip with numbers that identify the clip, the seed it was handed and the rank -- what is under test is the shard, the seed
+    offsets, the ONE all-gather and the per-clip order of the collated vectors."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from . import eval as ev
+    r, w, _ = init_from_env('gloo')
+    B, T, P, div = 5, 12, 8, 3                                       # uneven shards on purpose
+    batch = dict(gt=torch.arange(B, dtype=torch.float32)[:, None, None, None].expand(B, 1, 144, T).contiguous(),
+                 cond=torch.zeros(10, B, 256), hand_pose=torch.zeros(T, B, 90), beta=torch.zeros(T, B, 10), obj_points=torch.zeros(B, P, 3))
+    calls = []
+
+    def fake_evaluate_batch(model, diffusion, correction, local, past_len, mode, diverse_samples, seed=None, **kw):
+        calls.append((local['gt'].shape[0], seed, diverse_samples))
+        assert local['cond'].shape[1] == local['hand_pose'].shape[1] == local['beta'].shape[1] == local['obj_points'].shape[0] == local['gt'].shape[0]
+        clip = local['gt'][:, 0, 0, 0]
+        return {k: clip * 10 + i + (0.001 * seed if k == 'penetrate' else 0.0) for i, k in enumerate(METRIC_KEYS)}
+    real, ev.evaluate_batch = ev.evaluate_batch, fake_evaluate_batch
+    try:
+        full, means = ev.evaluate_sharded(None, None, None, batch, 10, 'correction', div, seed=100)
+    finally:
+        ev.evaluate_batch = real
+    sl = shard_slice(B, r, w)
+    assert calls == [(sl.stop - sl.start, 100 + sl.start * div, div)], calls
+    clip = torch.arange(B, dtype=torch.float32)
+    seeds = torch.tensor([100 + shard_slice(B, q, w).start * div for q in range(w) for _ in range(shard_slice(B, q, w).stop - shard_slice(B, q, w).start)],
+                         dtype=torch.float32)
+    for i, k in enumerate(METRIC_KEYS):
+        want = clip * 10 + i + (0.001 * seeds if k == 'penetrate' else 0.0)
+        assert torch.allclose(full[k], want), (k, full[k], want)
+        assert abs(means[k] - float(want.mean())) < 1e-5
+    # a pre-sharded batch (bench.py builds its clips per rank) goes through the same collective
+    mine = shard_batch(batch, r, 1, {})                             # whole batch as "this rank's clips"
+    ev.evaluate_batch = fake_evaluate_batch
+    try:
+        full2, _ = ev.evaluate_sharded(None, None, None, mine, 10, 'correction', 1, seed=7, presharded=True)
+    finally:
+        ev.evaluate_batch = real
+    assert full2['global_mpjpe'].numel() == B * w
+    barrier()
+    shutdown()

@@ -13,7 +13,7 @@ elementwise adds outside it: the rendering-only ``smooth`` and the translation r
 """
 import ctypes as C
 import torch
-from . import _lib, transforms as tr
+from . import _lib, dist, transforms as tr
 from .dist import METRIC_KEYS
 
 SMPL_DIM = 132          # 22 joints x rot6d (eval_smpl_short.py:416)
@@ -60,12 +60,19 @@ def finalize(sample, batch, smpl, past_len):
     return obj_pred, body_pred, verts, jtr, jtr[:, :, 0, :]
 
 
+def _x_T(gt, seed):
+    """x_T ~ N(0, I) (:153 ``torch.randn``): from torch's global generator, or from ``seed`` when the caller wants a reproducible draw."""
+    if seed is None:
+        return torch.randn(*gt.shape, device=gt.device)
+    return torch.randn(*gt.shape, device=gt.device, generator=torch.Generator(device=gt.device).manual_seed(int(seed)))
+
+
 def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=None, **loop_kw):
     """Full InterDiff: diffusion + correction hook.  Returns (obj_pred [T,B,6], body_pred [T,B,159], verts [T,B,V,3],
     jtr [T,B,J,3], pelvis [T,B,3]) like the reference (:177).  ``noise`` / ``step_noise`` / ``seed`` make it deterministic."""
     gt = batch['gt']
     if noise is None:
-        noise = torch.randn(*gt.shape, device=gt.device)
+        noise = _x_T(gt, loop_kw.get('seed'))
     sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise,
                                      model_kwargs={'y': model_kwargs_for(batch, past_len)}, denoised_fn=correction, **loop_kw)
     return finalize(sample, batch, correction.smpl if correction is not None else loop_kw['smpl'], past_len)
@@ -75,7 +82,7 @@ def sample_once(model, diffusion, smpl, batch, past_len=10, noise=None, **loop_k
     """Diffusion only (mode no_correction, :179-215)."""
     gt = batch['gt']
     if noise is None:
-        noise = torch.randn(*gt.shape, device=gt.device)
+        noise = _x_T(gt, loop_kw.get('seed'))
     y = model_kwargs_for(batch, past_len)
     sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise, model_kwargs={'y': y}, **loop_kw)
     return finalize(sample, batch, smpl, past_len)
@@ -107,7 +114,7 @@ def batch_from_raw(model, raw, past_len=10):
                 beta=raw['beta'].contiguous(), obj_points=raw['obj_points'].contiguous())
 
 
-def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=0, **loop_kw):
+def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=0, x_T=None, step_noise=None, **loop_kw):
     """Autoregressive long-horizon forecasting (eval_smpl_long.py:26-84,273-285; BASELINE config #4).
 
     Upstream this path is unreleased/broken (``denormalize`` / ``correct`` are undefined, ``get_batch`` copies clip 0 into
@@ -116,23 +123,27 @@ def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='c
     past, translated so that the pelvis of their first frame is the origin (orientation untouched: rotation = I upstream),
     future frames padded with the last past frame, new conditioning through ``_get_embeddings``, sample, translate back,
     append the window's future frames.  Every clip keeps its chain on its own GPU: no exchange between ranks.
+    ``x_T(k)`` / ``step_noise(k)`` (optional callables) inject window k's initial noise / per-step noise callable for deterministic
+    parity with oracle/long_horizon.py; by default window k draws both from ``seed + k``.
     Returns (obj [T+K*F,B,6], body [T+K*F,B,159], verts, jtr, pelvis) in the first window's coordinate frame."""
     smpl = correction.smpl
     T = raw['body_pose'].shape[0]
     fut = T - past_len
-    def run(bt, sd):
-        nz = torch.randn(bt['gt'].shape, device=bt['gt'].device, generator=torch.Generator(device=bt['gt'].device).manual_seed(sd))
+    def run(bt, k):
+        sd = seed + k
+        nz = x_T(k) if x_T is not None else _x_T(bt['gt'], sd)
+        kw = dict(loop_kw, step_noise=step_noise(k)) if step_noise is not None else loop_kw
         if mode == 'correction':
-            return sample_once_proj(model, diffusion, correction, bt, past_len, noise=nz, seed=sd, **loop_kw)
-        return sample_once(model, diffusion, smpl, bt, past_len, noise=nz, seed=sd, **loop_kw)
-    obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len), seed)
+            return sample_once_proj(model, diffusion, correction, bt, past_len, noise=nz, seed=sd, **kw)
+        return sample_once(model, diffusion, smpl, bt, past_len, noise=nz, seed=sd, **kw)
+    obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len), 0)
     for k in range(windows):
         pb, po = body[-past_len:], obj[-past_len:]
         centroid = pelvis[-past_len].clone()                                        # [B,3] origin of the next window
         pad = lambda a: torch.cat([a, a[-1:].expand(fut, *a.shape[1:])], dim=0).contiguous()
         nxt = dict(body_pose=pad(pb[..., :66]), hand_pose=pad(pb[..., 66:156]), body_trans=pad(pb[..., -3:] - centroid),
                    obj_angles=pad(po[..., :3]), obj_trans=pad(po[..., 3:] - centroid), beta=raw['beta'], obj_points=raw['obj_points'])
-        o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len), seed + 1 + k)
+        o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len), 1 + k)
         o, b_ = o.clone(), b_.clone()
         o[..., 3:] += centroid
         b_[..., -3:] += centroid
@@ -168,20 +179,55 @@ class Metrics:
         return {k: out[i] for i, k in enumerate(METRIC_KEYS)}
 
 
-def evaluate_batch(model, diffusion, correction, batch, past_len=10, mode='correction', diverse_samples=1, noise=None, **loop_kw):
+def evaluate_batch(model, diffusion, correction, batch, past_len=10, mode='correction', diverse_samples=1, noise=None, seed=None,
+                   **loop_kw):
     """One iteration of the reference's outer eval loop (:252-296) for a clip batch: sample ``diverse_samples`` times,
     score each against the ground truth on the future frames, keep the per-clip minimum (:291-296).  Returns the six
-    [B] metric vectors (ready for dist.gather_metrics)."""
+    [B] metric vectors (ready for dist.gather_metrics).
+
+    Every draw is an independent ancestral sample like upstream's fresh ``randn_like`` per step (:275-279,
+    gaussian_diffusion.py:532): draw j runs the in-kernel noise generator under its own seed -- ``seed + j`` when a base seed is
+    given (reproducible), otherwise one fresh 63-bit seed per draw from torch's global generator.  A fixed ``noise`` (x_T) with
+    ``diverse_samples > 1`` therefore still gives different samples."""
     smpl = correction.smpl
     obj_gt, jtr_gt, body_gt, faces = get_gt(batch, smpl)
     met = Metrics(correction)
     best = None
-    for _ in range(diverse_samples):
+    for j in range(diverse_samples):
+        sd = None if seed is None else int(seed) + j
         if mode == 'correction':
-            obj, body, verts, jtr, _ = sample_once_proj(model, diffusion, correction, batch, past_len, noise=noise, **loop_kw)
+            obj, body, verts, jtr, _ = sample_once_proj(model, diffusion, correction, batch, past_len, noise=noise, seed=sd, **loop_kw)
         else:
-            obj, body, verts, jtr, _ = sample_once(model, diffusion, smpl, batch, past_len, noise=noise, **loop_kw)
+            obj, body, verts, jtr, _ = sample_once(model, diffusion, smpl, batch, past_len, noise=noise, seed=sd, **loop_kw)
         m = met(obj[past_len:], jtr[past_len:], body[past_len:], obj_gt[past_len:], jtr_gt[past_len:], body_gt[past_len:],
                 verts[past_len:], faces, batch['obj_points'])
         best = m if best is None else {k: torch.minimum(best[k], m[k]) for k in m}
     return best
+
+
+BATCH_DIMS = dict(gt=0, cond=1, hand_pose=1, beta=1, obj_points=0)        # clip dimension of every tensor of a clip batch
+
+
+def evaluate_sharded(model, diffusion, correction, batch, past_len=10, mode='correction', diverse_samples=1, seed=None,
+                     presharded=False, **loop_kw):
+    """One eval batch of the reference's outer loop (:265-296) over ALL ranks: every rank takes a contiguous shard of the clips
+    (they are independent through the whole path), runs ``evaluate_batch`` on it and the six per-clip metric vectors are
+    collated with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) -- the only collective of the path.
+    Returns (per-clip metrics {name: [B_total]} in clip order on every rank, their means {name: float} = the numbers upstream
+    accumulates at :291-296).  ``seed``: base seed; a rank's draws use ``seed + first_clip * diverse_samples + j`` so that ranks
+    never share a noise stream and a given (clip shard, draw) is reproducible whatever the world size of an even split.
+    ``presharded``: ``batch`` is this rank's shard already (bench.py builds its clips per rank)."""
+    rank, world = dist.get_rank_world()
+    if presharded:                                                  # `batch` already is this rank's shard (equal sizes assumed for the seeds)
+        B = batch['gt'].shape[0]
+        sl, local = slice(rank * B, (rank + 1) * B), batch
+    else:
+        sl = dist.shard_slice(batch['gt'].shape[0], rank, world)
+        local = dist.shard_batch(batch, rank, world, BATCH_DIMS)
+    if sl.stop > sl.start:
+        sd = None if seed is None else int(seed) + sl.start * diverse_samples
+        m = evaluate_batch(model, diffusion, correction, local, past_len, mode, diverse_samples, seed=sd, **loop_kw)
+    else:                                                           # more ranks than clips: contribute an empty shard
+        m = {k: torch.empty(0, device=batch['gt'].device) for k in METRIC_KEYS}
+    full = dist.gather_metrics(m, world)
+    return full, {k: float(v.mean()) for k, v in full.items()}

@@ -206,6 +206,13 @@ class MDM:
         self._ws, self._ws_shape = ws, (B, T)
         return ws
 
+    def release_shape_buffers(self):
+        """Drop the per-shape workspaces and memory contexts.  Only the owner of the hipGraphs that captured their addresses may
+        call this, after destroying those graphs (diffusion.py does when its per-denoiser cache overflows)."""
+        self._ws_pool.clear()
+        self._memctx_pool.clear()
+        self._ws = self._ws_shape = self._memctx = self._mem_key = self._mem_cond = None
+
     def prepare_memory(self, cond):
         """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands."""
         if cond.shape[0] != MEM or cond.shape[2] != D:

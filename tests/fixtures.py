@@ -152,6 +152,36 @@ def full_inputs():
     return batch, bt['noise'], NoiseStream(8000)
 
 
+CORR32_SHAPE = (100, 32, 2048)        # T, B, P : one corrected step at BASELINE config #3's size (tests/golden/corr32.npz)
+CORR32_T = 250
+
+
+def corr32_inputs():
+    T, B, P = CORR32_SHAPE
+    bt = _clip(132, B, T, P)
+    rs = np.random.RandomState(5032)
+    x = bt['gt'] + 0.05 * _randn(rs, *bt['gt'].shape)
+    x[0, 0, 141:144, :] += 3.0          # clip 0: object far away -> no contact, condition still true
+    return x, model_kwargs_y(bt, T)
+
+
+PARITY_LOG = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r02.json')
+
+
+def record_parity(name, **values):
+    """Measured errors of the chain / end-to-end parity tests -> gpurun_out/parity_r02.json (merged back from the GPU box; the
+    copy that is judged lives in profiles/).  Never fails a test."""
+    import json
+    try:
+        path = os.path.abspath(PARITY_LOG)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+        json.dump(data, open(path, 'w'), indent=1, sort_keys=True)
+    except Exception as e:                                        # pragma: no cover
+        print('record_parity(%s): %r' % (name, e))
+
+
 EMB_SHAPE = (35, 3, 2048)              # T, B, P : MDM._get_embeddings (encoder side, "next" row N1)
 
 

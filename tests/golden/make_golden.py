@@ -27,6 +27,9 @@ What each fixture pins (reference file:line in brackets):
   full.npz         BASELINE config #2 end to end (B=16, T=100, P=2048, 1000 steps, correction mode): the reference's own
                    sample_once_proj / get_gt / metrics with injected noise, the sampler state at fx.FULL_DUMPS and the hook's
                    per-call decisions; generated separately (`make_golden.py full`, ~35 min) [eval_smpl_short.py:84-177]
+  full64.npz       the fp64 twin of full.npz (the ORACLE in float64 on the same inputs / noise; `make_golden.py full64`, ~1 h):
+                   not a reference output -- the yardstick that says how far fp32 itself is from exact arithmetic on this chain
+  corr32.npz       eval_smpl_short.denoised_fn, one corrected step (t = 250) at B=32, T=100, P=2048 (`make_golden.py corr32`)
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
 """
@@ -229,7 +232,69 @@ def gen_full():
          **{'dump_%d' % s: np_(v) for s, v in dumps.items()}, **{'m_' + k: np_(v) for k, v in met.items()})
 
 
+def gen_full64():
+    """The fp64 twin of full.npz: the ORACLE's restatement of the same path (sampler + denoiser + hook) run in float64 on the same
+    inputs and the same injected noise.  It is the yardstick for the end-to-end tolerance: the reference's fp32 run and the HIP
+    fp32 run are both compared with it (which side is closer, and how far fp32 itself is from the exact arithmetic after 1000
+    steps and 11 discrete decisions).  ~1 h on 8 cores; `python tests/golden/make_golden.py full64`."""
+    import time
+    from oracle import diffusion as odf, denoiser as oden, correction as ocor
+    T, B, P = fx.FULL_SHAPE
+    past = fx.PAST
+    batch, noise, stream = fx.full_inputs()
+    d = lambda v: v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v
+    sd = {k: d(v) for k, v in fx.mdm_weights().items()}
+    y = {k: d(v) for k, v in fx.model_kwargs_y(dict(batch, noise=noise), T).items()}
+    y.update(smpl={k: d(v) for k, v in fx.smpl_model().items()}, obj_model={k: d(v) for k, v in fx.objproj_weights().items()})
+    rec = dict(t=[], condition=[], contact=[])
+    t0 = time.time()
+
+    def hook(x, t, model_kwargs):
+        if not ocor.correction_gate(int(t[0])):
+            return x
+        terms = ocor.correction_terms(x.clone(), model_kwargs['y'], past)
+        rec['t'].append(int(t[0]))
+        rec['condition'].append(np_(terms['condition']))
+        rec['contact'].append(np_(terms['contact']).astype(np.int32))
+        print('  fp64 correction at t=%d: %d/%d clips rewritten (%.0f s)' % (int(t[0]), int(terms['condition'].sum()), B, time.time() - t0), flush=True)
+        return ocor.denoised_fn(x, t, model_kwargs, past_len=past)
+    dumps = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond']), tuple(noise.shape), odf.make_schedule(fx.FULL_STEPS),
+                              noise.double(), lambda i, x: stream.next_like(x).double(), {'y': y}, denoised_fn=hook, dump_steps=fx.FULL_DUMPS)
+    print('fp64 twin sampled in %.0f s' % (time.time() - t0), flush=True)
+    save('full64.npz', corr_t=np.array(rec['t']), condition=np.stack(rec['condition']), contact=np.stack(rec['contact']),
+         **{'dump_%d' % s: np_(v).astype(np.float32) for s, v in zip(fx.FULL_DUMPS, dumps)})
+
+
+def gen_corr32():
+    """One corrected step (the reference's own denoised_fn, t = 250) at BASELINE config #3's size B=32, T=100, P=2048: the per-clip
+    reductions over 90 future frames and the 32-clip ObjProjector batch at the benchmark shape.  ~5 min, ~6 GB."""
+    ev = refshim.load('eval_smpl_short')
+    T, B, P = fx.CORR32_SHAPE
+    ev.args = Namespace(smpl_dim=132, past_len=fx.PAST)
+    L = ref_smpl(fx.smpl_model())
+
+    class Holder:
+        pass
+    om = Holder()
+    om.model = ref_objproj(T)
+    seen = {}
+    real_sample = om.model.sample
+
+    def spy(obj_angles, obj_trans, human_verts, contact, *a, **k):
+        seen['contact'] = np_(contact).astype(np.int32)
+        return real_sample(obj_angles, obj_trans, human_verts, contact, *a, **k)
+    om.model.sample = spy
+    x, y = fx.corr32_inputs()
+    yref = dict(y, smpl=L, obj_model=om)
+    out = ev.denoised_fn(x.clone(), torch.full((B,), fx.CORR32_T, dtype=torch.int64), {'y': yref})
+    save('corr32.npz', out=np_(out), condition=np_((out != x).flatten(1).any(dim=1)), contact=seen['contact'])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'full64':
+        return gen_full64()
+    if len(sys.argv) > 1 and sys.argv[1] == 'corr32':
+        return gen_corr32()
     if len(sys.argv) > 1 and sys.argv[1] == 'optim':
         return gen_optim()
     if len(sys.argv) > 1 and sys.argv[1] == 'full':

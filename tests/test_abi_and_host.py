@@ -102,6 +102,14 @@ def test_gloo_sharding_world2():
     mp.spawn(idist._selftest_worker, args=(2, 29517), nprocs=2, join=True)
 
 
+def test_gloo_evaluate_sharded_world2():
+    """The eval entry that issues the path's one collective (interdiff_amd/eval.py: evaluate_sharded, eval_smpl_short.py:265-296):
+    uneven clip shards, per-rank seed offsets, all-gather, clip order of the collated per-clip metric vectors -- 2 gloo ranks."""
+    import torch.multiprocessing as mp
+    from interdiff_amd import dist as idist
+    mp.spawn(idist._selftest_eval_worker, args=(2, 29531), nprocs=2, join=True)
+
+
 def test_behave_etl_matches_reference_dataset(tmp_path):
     """"Next" row N2: clip canonicalisation + file formats + windows of interdiff_amd/data.py against the reference's own
     Dataset.__getitem__ on three windows of the shipped BEHAVE sequence (tests/golden/etl.npz holds the raw frames and the

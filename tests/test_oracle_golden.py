@@ -214,3 +214,51 @@ def test_optimization_golden():
             ref = g['grad_' + n][k]
             assert np.abs(grads[n].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, n
             assert ((grads[n].numpy() == 0) == (ref == 0)).all(), n                             # exact-zero pattern (Adam leaves those untouched)
+
+
+def test_long_horizon_restatement_properties():
+    """oracle/long_horizon.py ("next" row N3; upstream eval_smpl_long.py is broken, parity unpinned): what can be pinned without a
+    reference run -- ``next_window_raw`` IS get_batch's arithmetic for clip 0 (origin = first pelvis, rotation = I, scipy-canonical
+    rotation vectors, future = copies of the last past frame), window 0 of a rollout is the short-horizon sample, and the appended
+    frames are translated back by exactly the window's centroid."""
+    from scipy.spatial.transform import Rotation
+    from oracle import long_horizon as olh
+    from interdiff_amd import synthetic as syn
+    T, B, P, past, steps, K = 12, 2, 64, fx.PAST, 4, 1
+    ei = {k: torch.from_numpy(v) for k, v in syn.make_embedding_inputs(seed=5, B=B, T=T, n_points=P).items()}
+    g = torch.Generator().manual_seed(2)
+    raw = dict(ei, hand_pose=0.1 * torch.randn(T, B, 90, generator=g), beta=torch.randn(1, B, 10, generator=g).expand(T, B, 10).contiguous())
+    body = torch.randn(past, B, 159, generator=g)
+    body[0, 0, :3] = torch.tensor([4.0, 0.3, -0.2])                 # angle > pi: scipy re-expresses it, the rotation is unchanged
+    obj, pelvis = torch.randn(past, B, 6, generator=g), torch.randn(past, B, 3, generator=g)
+    nxt, centroid = olh.next_window_raw(body, obj, pelvis, raw, past, T - past)
+    assert torch.equal(centroid, pelvis[0])
+    # get_batch's own lines for clip 0, frame i (eval_smpl_long.py:40-63 with rotation = I)
+    for i in (0, past - 1):
+        c0 = pelvis[0, 0].numpy()
+        trans = body[i, 0, -3:].numpy() - c0
+        pel = pelvis[i, 0].numpy() - c0
+        pel_orig = pel - trans
+        np.testing.assert_allclose(nxt['body_trans'][i, 0].numpy(), np.dot(trans + pel_orig, np.eye(3)) - pel_orig, atol=1e-6)
+        np.testing.assert_allclose(nxt['body_pose'][i, 0, :3].numpy(), Rotation.from_rotvec(body[i, 0, :3].numpy()).as_rotvec(), atol=1e-6)
+        np.testing.assert_allclose(nxt['obj_trans'][i, 0].numpy(), obj[i, 0, 3:6].numpy() - c0, atol=1e-6)
+        assert torch.equal(nxt['body_pose'][i, :, 3:], body[i, :, 3:66]) and torch.equal(nxt['hand_pose'][i], body[i, :, 66:156])
+    close(R.axis_angle_to_matrix(nxt['body_pose'][0, 0, :3]), R.axis_angle_to_matrix(body[0, 0, :3]), 1e-5, 'same rotation')
+    assert float(nxt['body_pose'][0, 0, :3].norm()) <= np.pi + 1e-6
+    for k in ('body_pose', 'hand_pose', 'body_trans', 'obj_angles', 'obj_trans'):
+        assert nxt[k].shape[0] == T and all(torch.equal(nxt[k][t], nxt[k][past - 1]) for t in range(past, T))
+    # rollout: window 0 = the short-horizon sample; appended frames = the second window's future, moved back by its centroid
+    sched = odf.make_schedule(steps)
+    xT = lambda k: torch.from_numpy(np.random.RandomState(50 + k).standard_normal((B, 1, 144, T)).astype(np.float32))
+    sn = lambda k: (lambda i, x: torch.from_numpy(np.random.RandomState(60 + 10 * k + i).standard_normal(tuple(x.shape)).astype(np.float32)))
+    args = (fx.mdm_weights(), fx.smpl_model(), fx.objproj_weights())
+    o, b, v, j, p = olh.rollout(*args, raw, K, past, sched, xT, sn)
+    o0, b0, v0, j0, p0 = olh.sample_window(*args, raw, past, sched, xT(0), sn(0))
+    F = T - past
+    assert o.shape == (T + K * F, B, 6) and v.shape[0] == T + K * F
+    assert torch.equal(o[:T], o0) and torch.equal(v[:T], v0) and torch.equal(p, j[:, :, 0])
+    nxt, c = olh.next_window_raw(b0[-past:], o0[-past:], p0[-past:], raw, past, F)
+    o1, b1, v1, j1, p1 = olh.sample_window(*args, nxt, past, sched, xT(1), sn(1))
+    close(o[T:, :, 3:], o1[past:, :, 3:] + c, 1e-6, 'appended object translation')
+    close(v[T:], v1[past:] + c[None, :, None, :], 1e-6, 'appended vertices')
+    assert torch.equal(o[T:, :, :3], o1[past:, :, :3])

@@ -43,9 +43,9 @@ from interdiff_amd.diffusion import create_gaussian_diffusion      # noqa: E402
 B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
 # algorithmic FLOP per token of one denoiser step and of the kernels bench reports on
 FLOP_PER_TOKEN = 11978752 + 2048 * T
-FFN_GEMM_FLOP_PER_TOKEN = 2 * 256 * 1024                    # one of the two FFN GEMMs
+FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
-DOMINANT_KERNEL_ID = 'gemm_glds_kernel<32,32,2,2,2,64,A_PLAIN,E_RESID>'      # the build the roofline block (and traffic.json) speaks about
+DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r02a'       # the build the roofline block (and profiles/traffic.json) speaks about
 
 
 def tt(d, dev=None):
@@ -97,20 +97,17 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
 
 
 def time_dominant_kernel(model, dev, reps=200):
-    """The roofline kernel (FFN second GEMM: [1600,1024] x [256,1024]^T + bias + residual), timed live with HIP events on the
-    launch stream around `reps` back-to-back launches on the model's own weights (layer 1).  The launches are replayed from a
-    hipGraph so that the figure is the GPU's, whatever the host is doing (an earlier version launched from Python and measured a
-    busy host instead: 380 us per "launch" once the CPU-baseline threads were still spinning)."""
-    from interdiff_amd.mdm import linear
+    """The roofline kernel: the fused feed-forward block of one layer (csrc/ffn.h: [1600,256] -> linear1 -> gelu -> linear2 as five
+    partial slabs; 8 of the 24 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
+    stream around `reps` back-to-back launches on the model's own weights (layer 1).  The launches are replayed from a hipGraph so
+    that the figure is the GPU's, whatever the host is doing.  Returns the MEAN of three bursts (and the best, for reference)."""
+    from interdiff_amd.mdm import ffn_parts
     N = B_PER_GPU * T
     g = torch.Generator().manual_seed(5)
-    hid, x2 = torch.randn(N, 1024, generator=g).to(dev), torch.randn(N, 256, generator=g).to(dev)
-    ly = model.w.layer[1]
-    W = model.arena[ly.ff2_w:ly.ff2_w + 256 * 1024].view(256, 1024)
-    bias = model.arena[ly.ff2_b:ly.ff2_b + 256]
-    out = torch.empty(N, 256, device=dev)
+    x2 = torch.randn(N, 256, generator=g).to(dev)
+    parts = torch.empty(_lib.FFN_SLICES, N, 256, device=dev)
     for _ in range(20):
-        linear(hid, W, bias, residual=x2, out=out)
+        ffn_parts(model, x2, 1, out=parts)
     torch.cuda.synchronize()
     per_graph = 50
     side = torch.cuda.Stream(device=dev)
@@ -118,19 +115,19 @@ def time_dominant_kernel(model, dev, reps=200):
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             for _ in range(per_graph):
-                linear(hid, W, bias, residual=x2, out=out)
+                ffn_parts(model, x2, 1, out=parts)
         graph.replay()
         side.synchronize()
-        best = float('inf')
-        for _ in range(3):                                       # best of three bursts of `reps` launches
+        ts = []
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(side)
             for _ in range(reps // per_graph):
                 graph.replay()
             e1.record(side)
             e1.synchronize()
-            best = min(best, 1e3 * e0.elapsed_time(e1) / (reps // per_graph * per_graph))
-    return best
+            ts.append(1e3 * e0.elapsed_time(e1) / (reps // per_graph * per_graph))
+    return sum(ts) / len(ts), min(ts)
 
 
 def log(msg):
@@ -343,7 +340,7 @@ def main():
     prof = None
     if not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
-        dom_us = time_dominant_kernel(model, dev)
+        dom_us, dom_best = time_dominant_kernel(model, dev)
         log('kernel profile done')
     # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
     ei = tt(syn.make_embedding_inputs(seed=77, B=B_PER_GPU, T=T, n_points=P), dev)
@@ -381,9 +378,9 @@ def main():
                                   note='random-init denoiser: the metric values only serve as parity evidence against the oracle')
     line.update(extra)
     if prof:
-        dom = 'gemm_ffn2'
+        dom = 'ffn_fused'
         us = dom_us
-        flops = FFN_GEMM_FLOP_PER_TOKEN * B_PER_GPU * T
+        flops = FFN_FLOP_PER_TOKEN * B_PER_GPU * T
         ach = flops / (us * 1e-6) / 1e12
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -392,10 +389,12 @@ def main():
             if tj.get('kernel_id') == DOMINANT_KERNEL_ID:          # a PMC figure is only valid for the kernel build it was taken on
                 traffic, traffic_src = tj.get(dom), tj.get('_how')
         line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
-                                traffic=traffic, us_per_launch=us, algorithmic_flop_per_launch=flops, kernel_id=DOMINANT_KERNEL_ID,
+                                traffic=traffic, us_per_launch=us, us_per_launch_best_burst=dom_best, algorithmic_flop_per_launch=flops,
+                                kernel_id=DOMINANT_KERNEL_ID,
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
-                                note='16 of the 32 launches of a denoiser forward are this GEMM shape (FFN); duration = HIP events around 200 '
-                                     'back-to-back launches replayed from a hipGraph on the launch stream (rocprofv3 in-situ average: profiles/)')
+                                note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 24 launches '
+                                     'of a denoiser forward; duration = mean of three bursts of 200 back-to-back launches replayed from a hipGraph, HIP '
+                                     'events on the launch stream (rocprofv3 in-situ average: profiles/)' % (B_PER_GPU * T))
         dn = sum(v['ms_total'] for k, v in prof.items() if k.startswith(('embed', 'gemm', 'self_attn', 'rowblock')))
         nfw = prof['embed']['launches']
         line['denoiser_forward'] = dict(us=1e3 * dn / nfw, achieved_tflops=FLOP_PER_TOKEN * B_PER_GPU * T / (1e-3 * dn / nfw) / 1e12,

@@ -13,7 +13,8 @@
  *    enqueued asynchronously on it, nothing synchronises, nothing allocates: scratch comes
  *    from the caller (`ws`, sized by the matching *_workspace_bytes function);
  *  - return value: 0 on success, a negative code on error (IDF_E_*); no exceptions, no
- *    callbacks, no global state => safe to capture in a hipGraph;
+ *    callbacks, no mutable process state (the only statics are idempotent per-device caches of a
+ *    kernel attribute, see csrc/common.h idf_opt_in_lds) => safe to capture in a hipGraph;
  *  - inputs are borrowed; outputs are caller-allocated.
  */
 #ifndef INTERDIFF_HIP_H
@@ -114,6 +115,7 @@ int interdiff_point2point_signed(const float *x, int32_t P1, const float *y, int
 #define IDF_MDM_HEADS  4
 #define IDF_MDM_NQ     10      /* learned queries per QaN layer                          */
 #define IDF_MDM_MEM    10      /* memory (past) tokens                                   */
+#define IDF_FFN_SLICES 5       /* hidden-unit slices of the fused FFN = partial output slabs (csrc/ffn.h) */
 
 typedef struct {
     int64_t is_qan;            /* 0: torch TransformerDecoderLayer, 1: QaN               */
@@ -123,6 +125,7 @@ typedef struct {
     int64_t ca_kv_w, ca_kv_b;  /* cross-attn key|value proj [512,256],[512]              */
     int64_t ca_out_w, ca_out_b;
     int64_t ff1_w, ff1_b, ff2_w, ff2_b;             /* [1024,256],[1024],[256,1024],[256] */
+    int64_t ffn_pack;          /* linear1 + linear2 weights in the fused FFN kernel's stream order (2*256*1024 floats, mdm.py pack_ffn) */
     int64_t ln_w[3], ln_b[3];
 } idf_mdm_layer;
 
@@ -139,6 +142,9 @@ typedef struct {
     /* encoder side ("next" row, MDM._get_embeddings): [std, QaN x6, std] without cross-attention; uses sa_*, qc, wk,
      * ff*, ln_w/ln_b[0..1] (= norm1, norm2); valid when has_encoder != 0 */
     idf_mdm_layer enc_layer[IDF_MDM_LAYERS];
+    /* tile-configuration overrides for A/B measurements (tools/kbench.py), indexed by IDF_TUNE_*; all zero = the shipped
+     * configuration.  A field of the handle, not process state: two models in one process never see each other's overrides. */
+    int32_t tune[8];
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
@@ -153,6 +159,11 @@ int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float 
  *   VWT [L][B][256][48]  (out = P . VW + out_bias, stored output-column-major, 40 padded to 48)
  *   g0  [L][B][40]
  * cond [MEM,B,256] (reference layout).  `memctx` must hold interdiff_mdm_memctx_floats(B). */
+/* The feed-forward block of one layer as a standalone op (what bench.py times for its roofline block; the denoiser launches the
+ * same kernel): x2 [M,256] -> parts [IDF_FFN_SLICES][M][256] whose sum over the slabs is x2 + linear2(gelu(linear1(x2)))
+ * (torch.nn.TransformerDecoderLayer._ff_block + residual; sublayers.py:331-341).  encoder != 0 selects enc_layer[layer]. */
+int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts, void *stream);
+
 size_t interdiff_mdm_memctx_floats(int32_t B);
 size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T);
 int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B,
@@ -346,7 +357,7 @@ int interdiff_debug_joint_map_vjp(const float *R, const float *g_out, float *g_i
  * ---------------------------------------------------------------------------------- */
 enum {
     IDF_K_EMBED = 0, IDF_K_GEMM_QKV, IDF_K_SELF_ATTN, IDF_K_GEMM_OUTPROJ, IDF_K_ROWBLOCK_QAN,
-    IDF_K_ROWBLOCK_STD, IDF_K_GEMM_FFN1, IDF_K_GEMM_FFN2, IDF_K_GEMM_HEADS, IDF_K_MEM_PREP,
+    IDF_K_ROWBLOCK_STD, IDF_K_FFN_FUSED, IDF_K_RESERVED7, IDF_K_GEMM_HEADS, IDF_K_MEM_PREP,
     IDF_K_INPAINT, IDF_K_POSTERIOR, IDF_K_CORR_PREPARE, IDF_K_SMPL_POSE, IDF_K_SMPL_BLEND_SKIN,
     IDF_K_CORR_CONTACT, IDF_K_CORR_REDUCE, IDF_K_OBJPROJ, IDF_K_CORR_BLEND, IDF_K_OTHER,
     IDF_K_COUNT
@@ -354,13 +365,11 @@ enum {
 int interdiff_profile_begin(int32_t capacity);
 int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kind);
 
-/* Tile-configuration override for A/B measurements (tools/kbench.py); value 0 = the shipped default.
- * Not on the product path: nothing in interdiff_amd/ calls it. */
+/* indices into idf_mdm_weights.tune (value 0 = the shipped default) */
 enum {
-    IDF_TUNE_GEMM_EMBED = 0, IDF_TUNE_GEMM_QKV, IDF_TUNE_GEMM_OUTPROJ, IDF_TUNE_GEMM_FFN1, IDF_TUNE_GEMM_FFN2,
+    IDF_TUNE_GEMM_EMBED = 0, IDF_TUNE_GEMM_QKV, IDF_TUNE_GEMM_OUTPROJ, IDF_TUNE_FFN, IDF_TUNE_RESERVED,
     IDF_TUNE_GEMM_HEADS, IDF_TUNE_CONTACT, IDF_TUNE_MISC, IDF_TUNE_COUNT
 };
-int interdiff_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -9,11 +9,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
 MDM_LAYERS = 8
+FFN_SLICES = 5              # IDF_FFN_SLICES: partial output slabs of the fused feed-forward kernel
+TUNE = dict(embed=0, qkv=1, outproj=2, ffn=3, heads=5, contact=6, misc=7)      # indices into MdmWeights.tune (IDF_TUNE_*)
 
 
 class SmplModel(C.Structure):
@@ -27,7 +29,7 @@ class MdmLayer(C.Structure):
                 ('qc', i64), ('wk', i64),
                 ('ca_q_w', i64), ('ca_q_b', i64), ('ca_kv_w', i64), ('ca_kv_b', i64),
                 ('ca_out_w', i64), ('ca_out_b', i64),
-                ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64),
+                ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64),
                 ('ln_w', i64 * 3), ('ln_b', i64 * 3)]
 
 
@@ -35,7 +37,7 @@ class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
                 ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
-                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS)]
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8)]
 
 
 class PnMlp(C.Structure):
@@ -90,6 +92,7 @@ _SIGS = {
     'interdiff_pointnet2_encode': (C.c_int, [C.POINTER(PointNet2), vp, i32, i32, vp, vp]),
     'interdiff_mdm_encode_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_encode': (C.c_int, [C.POINTER(MdmWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
+    'interdiff_mdm_ffn': (C.c_int, [C.POINTER(MdmWeights), i32, i32, vp, i32, vp, vp]),
     'interdiff_mdm_memctx_floats': (sz, [i32]),
     'interdiff_mdm_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),
@@ -113,10 +116,9 @@ _SIGS = {
     'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    'interdiff_tune': (C.c_int, [i32, i32]),
 }
 
-KERNEL_KINDS = ('embed', 'gemm_qkv', 'self_attn', 'gemm_outproj', 'rowblock_qan', 'rowblock_std', 'gemm_ffn1', 'gemm_ffn2',
+KERNEL_KINDS = ('embed', 'gemm_qkv', 'self_attn', 'gemm_outproj', 'rowblock_qan', 'rowblock_std', 'ffn_fused', 'reserved7',
                 'gemm_heads', 'mem_prep', 'inpaint', 'posterior', 'corr_prepare', 'smpl_pose', 'smpl_blend_skin',
                 'corr_contact', 'corr_reduce', 'objproj', 'corr_blend', 'other')
 

@@ -34,12 +34,37 @@ static inline int idf_opt_in_lds(const void *fn, int bytes, std::atomic<uint64_t
     return IDF_OK;
 }
 
+// ---- LDS-DMA (global -> LDS without a VGPR round trip) as INLINE ASM ----------------------------------------------------------
+// hipcc's waitcnt pass cannot tell which LDS bytes a `global_load_lds` writes, so with the builtin it drains vmcnt to 0 before the
+// first ds_read that follows ANY pending DMA -- a software pipeline that keeps chunks in flight across iterations silently degrades
+// to "issue, wait for everything, compute" (round 1's GEMMs did: their ISA shows `s_waitcnt vmcnt(0)` right after the issue).
+// Inline asm is invisible to that pass: the kernel owns the bookkeeping and must cover every DMA with its own counted
+// `s_waitcnt vmcnt(N)` (+ an s_barrier before other waves read the bytes).  The compiler's waits for ITS OWN loads stay correct:
+// memory returns in issue order, so a DMA it does not know about can only make its waits stricter, never looser.
+// Every wave instruction moves 64 lanes x 16 B to LDS bytes [lds_base + 16*lane); lds_base (and gbase) must be wave-uniform.
+typedef __attribute__((address_space(3))) float idf_lds_float;
+__device__ __forceinline__ uint32_t idf_lds_addr(const float *p) {       // LDS byte address of a pointer into __shared__ memory
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(idf_lds_float *)p);
+}
+__device__ __forceinline__ const float *idf_uniform_ptr(const float *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float *>(((uint64_t)hi << 32) | lo);
+}
+// global address = gbase (SGPR pair) + voff_bytes (per lane)
+__device__ __forceinline__ void idf_dma16_s(const float *gbase, uint32_t voff_bytes, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(gbase), "s"(lds_base) : "memory", "m0");
+}
+// global address = gptr (per lane, 64-bit)
+__device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory", "m0");
+}
+
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
 extern bool g_idf_prof_on;
 void idf_prof_mark_slow(int kind, hipStream_t s);
 static inline void idf_prof_mark(int kind, hipStream_t s) { if (g_idf_prof_on) idf_prof_mark_slow(kind, s); }
 
-extern int g_idf_tune[];          // denoiser.hip: tile-configuration overrides (interdiff_tune)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -121,6 +146,28 @@ __device__ __forceinline__ void ln_row16(Row16 &r, const float *__restrict__ w, 
 __device__ __forceinline__ void row16_load(Row16 &r, const float *__restrict__ row, int l16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * 16 + l16) * 4);
+}
+// A layer output is either one [N,256] matrix or the IDF_FFN_SLICES partial slabs the fused FFN leaves behind (ffn.h): element =
+// ((((s0 + s1) + s2) + s3) + s4), slabs `stride` floats apart.  Summed in this fixed order by every reader: deterministic.
+__device__ __forceinline__ float4 ld4_sum(const float *__restrict__ p, int np, size_t stride) {
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    if (np == IDF_FFN_SLICES) {                       // all loads in flight before the first add
+        float4 t[IDF_FFN_SLICES - 1];
+#pragma unroll
+        for (int s = 1; s < IDF_FFN_SLICES; ++s) t[s - 1] = *reinterpret_cast<const float4 *>(p + s * stride);
+#pragma unroll
+        for (int s = 1; s < IDF_FFN_SLICES; ++s) { v.x += t[s - 1].x; v.y += t[s - 1].y; v.z += t[s - 1].z; v.w += t[s - 1].w; }
+    } else {
+        for (int s = 1; s < np; ++s) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + s * stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ void row16_load_sum(Row16 &r, const float *__restrict__ row, int l16, int np, size_t stride) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.c[i] = ld4_sum(row + (i * 16 + l16) * 4, np, stride);
 }
 __device__ __forceinline__ void row16_store(const Row16 &r, float *__restrict__ row, int l16) {
 #pragma unroll

@@ -15,19 +15,19 @@
 //     scores = x.G^T + g0 and out = P.VW (interdiff_mdm_prepare_memory),
 //   * LayerNorm never gets its own launch: the row-block kernel owns whole rows (LN_prev on load,
 //     LN1, LN2 in place) and the QKV / heads GEMMs normalise on load.
-// Per step: 1 embed GEMM + 2 x 6 (standard layers) + 6 x 3 (QaN layers) + 1 heads GEMM = 32 launches.
+//   * the feed-forward block is ONE launch (ffn.h): linear1 -> gelu -> linear2 per (32-row tile, hidden slice), the hidden
+//     activations never leave the CU; it leaves IDF_FFN_SLICES partial slabs that the next reader sums on load.
+// Per step: 1 embed GEMM + 2 x 5 (standard layers) + 6 x 2 (QaN layers) + 1 heads GEMM = 24 launches.
 #include "common.h"
 #include "gemm.h"
+#include "ffn.h"
 #include <float.h>
-
-int g_idf_tune[IDF_TUNE_COUNT] = {0};
 
 namespace {
 
 using namespace idf_gemm;
 
 constexpr int D = IDF_MDM_D;          // 256
-constexpr int FF = IDF_MDM_FF;        // 1024
 constexpr int H = IDF_MDM_HEADS;      // 4
 constexpr int HD = D / H;             // 64
 constexpr int NQ = IDF_MDM_NQ;        // 10
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        const float *__restrict__ g0, const float *__restrict__ VWT,
                                                        const float *__restrict__ bout, const float *__restrict__ ln2_w,
                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
-                                                       int out_frame_major /* encoder output: row = t*B + b */) {
+                                                       int out_frame_major /* encoder output: row = t*B + b */,
+                                                       int u_np /* partial slabs of u_in (1 = plain) */, size_t u_pstride) {
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + NQ * TR * 4 + TR * 4 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         Row16 ra, rb;
         row16_zero(ra);
         row16_zero(rb);
-        if (va) row16_load(ra, u_in + (rowbase + ta) * D, li);
-        if (vb) row16_load(rb, u_in + (rowbase + tb) * D, li);
+        if (va) row16_load_sum(ra, u_in + (rowbase + ta) * D, li, u_np, u_pstride);
+        if (vb) row16_load_sum(rb, u_in + (rowbase + tb) * D, li, u_np, u_pstride);
         float4 q[4][3];
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         const int t = t0 + rown;
         Row16 ra;
         row16_zero(ra);
-        if (t < T) row16_load(ra, u_in + (rowbase + t) * D, li);
+        if (t < T) row16_load_sum(ra, u_in + (rowbase + t) * D, li, u_np, u_pstride);
         prefetch_g();
         ln_row16(ra, ln1_w, ln1_b, li);
         if constexpr (CROSS) row16_store(ra, x1s + rown * RS, li);
@@ -414,8 +415,10 @@ int attn_opt_in() {
 }
 
 struct Ws {
-    float *uA, *uB, *xn, *x2, *ctx, *qkv, *hid;
+    float *uA, *uB, *xn, *x2, *ctx, *qkv, *parts;
 };
+constexpr int NSL = IDF_FFN_SLICES;
+constexpr size_t WS_ROW_FLOATS = (size_t)(5 + 3 + NSL) * D;      // uA uB xn x2 ctx | qkv | FFN partial slabs
 Ws carve(void *ws, int64_t N) {
     float *p = reinterpret_cast<float *>(ws);
     Ws r;
@@ -425,7 +428,7 @@ Ws carve(void *ws, int64_t N) {
     r.x2 = p; p += N * D;
     r.ctx = p; p += N * D;
     r.qkv = p; p += N * 3 * D;
-    r.hid = p;
+    r.parts = p;
     return r;
 }
 
@@ -452,9 +455,13 @@ inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 
 }  // namespace
 
-extern "C" int interdiff_tune(int32_t key, int32_t value) {
-    if (key < 0 || key >= IDF_TUNE_COUNT) return IDF_E_INVAL;
-    g_idf_tune[key] = value;
+extern "C" int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts,
+                                 void *stream) {
+    if (!w || !x2 || !parts || M <= 0 || layer < 0 || layer >= L || (encoder && !w->has_encoder)) return IDF_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(x2) & 15) || (reinterpret_cast<uintptr_t>(parts) & 15)) return IDF_E_INVAL;
+    const idf_mdm_layer &ly = encoder ? w->enc_layer[layer] : w->layer[layer];
+    idf_ffn::launch_ffn(idf_stream(stream), x2, M, w->arena + ly.ffn_pack, w->arena + ly.ff1_b, w->arena + ly.ff2_b, parts);
+    IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
 
@@ -481,7 +488,7 @@ extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) {
 
 extern "C" size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T) {
     const size_t N = (size_t)B * T;
-    const size_t fwd = N * (5 * D + 3 * D + FF) * sizeof(float);
+    const size_t fwd = N * WS_ROW_FLOATS * sizeof(float);
     const size_t prep = (size_t)L * MEM * B * 512 * sizeof(float);
     return idf_align(fwd > prep ? fwd : prep);
 }
@@ -510,7 +517,7 @@ __global__ void iota_kernel(int64_t *p, int n) {
 
 extern "C" size_t interdiff_mdm_encode_workspace_bytes(int32_t B, int32_t Tp) {
     const size_t N = (size_t)B * Tp;
-    return idf_align(N * (5 * D + 3 * D + FF) * sizeof(float)) + idf_align((size_t)B * sizeof(int64_t));
+    return idf_align(N * WS_ROW_FLOATS * sizeof(float)) + idf_align((size_t)B * sizeof(int64_t));
 }
 
 // Encoder side: u0 = [body | obj].W_in^T + b_in + pc[b] + pe[t] over the Tp past frames, then the 8 encoder layers
@@ -525,7 +532,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     const float *ar = w->arena;
     const int N = B * Tp, C = w->C, T = Tp;
     Ws k = carve(ws, N);
-    int64_t *iota = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * (5 * D + 3 * D + FF) * sizeof(float)));
+    int64_t *iota = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * WS_ROW_FLOATS * sizeof(float)));
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)idf_cdiv(B, 256)), dim3(256), 0, s, iota, B);
     {
         Args g{};
@@ -533,7 +540,10 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
         g.ts = iota; g.temb = pc; g.pe = ar + w->pe; g.n_steps = B;            // "+ temb[ts[b]]" adds pc[b]
         launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
     }
-    float *u_in = k.uA, *u_tmp = k.uB;
+    const float *u_in = k.uA;                  // layer input: plain [N,256] for layer 0, then the FFN's partial slabs
+    int u_np = 1;
+    const size_t pstride = (size_t)N * D;
+    float *u_tmp = k.uB;
     const float *lnp_w = nullptr, *lnp_b = nullptr;
     const int TP = (T + 15) & ~15;
     const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
@@ -543,11 +553,11 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
         const idf_mdm_layer &ly = w->enc_layer[l];
         if (ly.is_qan) {
             hipLaunchKernelGGL((rowblock_kernel<true, false>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0);
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, u_np, pstride);
         } else {
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
-            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T;
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
             run_gemm<A_LN, E_BIAS>(CFG_QKV, s, g);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             Args o{};
@@ -555,22 +565,17 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
             o.N = D; o.resid = k.xn; o.T = T;
             run_gemm<A_PLAIN, E_RESID>(CFG_OUTPROJ, s, o);
             hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0);
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, 1, (size_t)0);
         }
-        Args f1{};
-        f1.A = k.x2; f1.lda = D; f1.K = D; f1.W = ar + ly.ff1_w; f1.bias = ar + ly.ff1_b; f1.C = k.hid; f1.ldc = FF; f1.M = N;
-        f1.N = FF; f1.T = T;
-        run_gemm<A_PLAIN, E_GELU>(CFG_FFN1, s, f1);
-        Args f2{};
-        f2.A = k.hid; f2.lda = FF; f2.K = FF; f2.W = ar + ly.ff2_w; f2.bias = ar + ly.ff2_b; f2.C = u_in; f2.ldc = D; f2.M = N;
-        f2.N = D; f2.resid = k.x2; f2.T = T;
-        run_gemm<A_PLAIN, E_RESID>(CFG_FFN2, s, f2);
+        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ff1_b, ar + ly.ff2_b, k.parts);
+        u_in = k.parts;
+        u_np = NSL;
         lnp_w = ar + ly.ln_w[1];
         lnp_b = ar + ly.ln_b[1];
     }
     // cond[t][b][:] = LN2_last(u[b*T + t])
     hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1);
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, u_np, pstride);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -585,7 +590,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
     const int N = B * T, C = w->C;
     Ws k = carve(ws, N);
     const float *G = memctx, *VWT = memctx + (size_t)L * B * HM * D, *g0 = VWT + (size_t)L * B * D * HMP;
-    const int *tune = g_idf_tune;
+    const int32_t *tune = w->tune;
 
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
         Args g{};
@@ -595,7 +600,10 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         if (tune[IDF_TUNE_GEMM_EMBED] == 1) launch<64, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
         else launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
     }
-    float *u_in = k.uA, *u_tmp = k.uB;         // layer input (pre-norm sum of the previous layer) / scratch
+    const float *u_in = k.uA;                  // layer input (pre-norm sum of the previous layer): plain for layer 0, then FFN partial slabs
+    int u_np = 1;
+    const size_t pstride = (size_t)N * D;
+    float *u_tmp = k.uB;
     const float *lnp_w = nullptr, *lnp_b = nullptr;   // LayerNorm still to be applied to u_in (none for layer 0)
     const int TP = (T + 15) & ~15;
     const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
@@ -608,12 +616,12 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
             hipLaunchKernelGGL((rowblock_kernel<true>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T, 0);
+                               ar + ly.ln_b[1], k.x2, T, 0, u_np, pstride);
         } else {
             // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
-            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T;
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
             run_gemm<A_LN, E_BIAS>(pick(tune[IDF_TUNE_GEMM_QKV], CFG_QKV), s, g);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
@@ -627,26 +635,20 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
             hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T, 0);
+                               ar + ly.ln_b[1], k.x2, T, 0, 1, (size_t)0);
         }
-        // hid = gelu(x2.W1^T + b1) ; u3 = x2 + hid.W2^T + b2  (into the dead layer-input buffer)
-        Args f1{};
-        f1.A = k.x2; f1.lda = D; f1.K = D; f1.W = ar + ly.ff1_w; f1.bias = ar + ly.ff1_b; f1.C = k.hid; f1.ldc = FF; f1.M = N;
-        f1.N = FF; f1.T = T;
-        idf_prof_mark(IDF_K_GEMM_FFN1, s);
-        run_gemm<A_PLAIN, E_GELU>(pick(tune[IDF_TUNE_GEMM_FFN1], CFG_FFN1), s, f1);
-        Args f2{};
-        f2.A = k.hid; f2.lda = FF; f2.K = FF; f2.W = ar + ly.ff2_w; f2.bias = ar + ly.ff2_b; f2.C = u_in; f2.ldc = D; f2.M = N;
-        f2.N = D; f2.resid = k.x2; f2.T = T;
-        idf_prof_mark(IDF_K_GEMM_FFN2, s);
-        run_gemm<A_PLAIN, E_RESID>(pick(tune[IDF_TUNE_GEMM_FFN2], CFG_FFN2), s, f2);
+        // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
+        idf_prof_mark(IDF_K_FFN_FUSED, s);
+        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ff1_b, ar + ly.ff2_b, k.parts);
+        u_in = k.parts;
+        u_np = NSL;
         lnp_w = ar + ly.ln_w[2];
         lnp_b = ar + ly.ln_b[2];
     }
     {   // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
         Args g{};
         g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + w->out_w; g.bias = ar + w->out_b; g.C = x0;
-        g.ldc = C; g.M = N; g.N = C; g.T = T;
+        g.ldc = C; g.M = N; g.N = C; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
         idf_prof_mark(IDF_K_GEMM_HEADS, s);
         run_gemm<A_LN, E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g);
     }

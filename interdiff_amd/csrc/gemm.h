@@ -25,6 +25,8 @@ struct Args {
     const float *A;
     int lda, K;
     const float *lnw, *lnb;         // A_LN (null lnw: rows copied unnormalised)
+    int a_np;                       // A_LN: A is a_np (>= 1; 0 means 1) partial slabs a_pstride floats apart, summed on load (common.h ld4_sum)
+    size_t a_pstride;
     const float *W;                 // [N][K]
     const float *bias;              // [N] or null
     float *C;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4(g.A + (size_t)m * g.lda + lane * 4) : zero4();
+            float4 v = m < M ? ld4_sum(g.A + (size_t)m * g.lda + lane * 4, g.a_np > 1 ? g.a_np : 1, g.a_pstride) : zero4();
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);
@@ -346,7 +348,8 @@ inline void launch(hipStream_t s, const Args &g) {
 //    row i: k = 16s + 4kq + {0..3});
 //  * NS (3..6) LDS stages: chunks k+1 .. k+NS-1 are in flight while chunk k is on the MFMAs; the only wait in the loop
 //    is a COUNTED s_waitcnt vmcnt((NS-2)*LPC) (chunk k+1 landed, the later ones still flying) followed by ONE raw
-//    s_barrier per chunk -- the lookahead has to cover ~1 us of loaded global->LDS latency;
+//    s_barrier per chunk -- the lookahead has to cover ~1 us of loaded global->LDS latency.  The DMA instruction is issued from
+//    inline asm (common.h): only then does the counted wait really keep chunks in flight;
 //  * KS = 2 / 4 splits the 16-wide k-groups of every chunk over that many wave sets (2 / 4 waves per SIMD at one
 //    workgroup per CU), reduced through LDS at the end -- for the GEMMs whose grid cannot fill the chip twice.
 // ------------------------------------------------------------------------------------------------------------
@@ -359,8 +362,6 @@ __device__ __forceinline__ void wait_vmcnt() {
     IDF_VMCNT_CASE(13) IDF_VMCNT_CASE(14) IDF_VMCNT_CASE(15) IDF_VMCNT_CASE(16)
 #undef IDF_VMCNT_CASE
 }
-
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>
 __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g) {
@@ -416,10 +417,12 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
         else if (ahead == 3) { if constexpr (NS >= 5) wait_vmcnt<3 * LPC>(); }
         else { if constexpr (NS >= 6) wait_vmcnt<4 * LPC>(); }
     };
+    // asm DMA (common.h idf_dma16_v): with the builtin, hipcc drains vmcnt to 0 before the first ds_read after every issue and
+    // the counted waits below never get to keep a chunk in flight
+    const uint32_t stages_lds = idf_lds_addr(stages);
     auto issue = [&](int kc, int st) {
 #pragma unroll
-        for (int j = 0; j < LPC; ++j)
-            __builtin_amdgcn_global_load_lds((const void *)(src[j] + kc * KC), (lds_ptr_t)(stages + st * STAGE + dst[j]), 16, 0, 0);
+        for (int j = 0; j < LPC; ++j) idf_dma16_v(src[j] + kc * KC, stages_lds + (uint32_t)((st * STAGE + dst[j]) * 4));
     };
 
 #pragma unroll
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4(g.A + (size_t)m * g.lda + lane * 4) : zero4();
+            float4 v = m < M ? ld4_sum(g.A + (size_t)m * g.lda + lane * 4, g.a_np > 1 ? g.a_np : 1, g.a_pstride) : zero4();
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);

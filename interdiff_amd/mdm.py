@@ -60,6 +60,42 @@ def _np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
+FFN_SLICE_H = 208           # hidden units per slice of the fused FFN kernel (13 MFMA column tiles; the last slice takes the rest)
+_G4 = np.array([0, 3, 2, 1])
+
+
+def ffn_slices(ff=FF, n=_lib.FFN_SLICES):
+    """(first hidden unit, count) of every slice -- csrc/ffn.h slice_h0 / slice_hs."""
+    return [(FFN_SLICE_H * s, FFN_SLICE_H if s < n - 1 else ff - FFN_SLICE_H * (n - 1)) for s in range(n)]
+
+
+def _swizzle16(block):
+    """[rows][16] floats -> the LDS image the kernel reads with conflict-free ds_read_b128: the four 16-byte cells of a row are
+    stored at position (cell ^ g4[(row >> 2) & 3]) (an involution, applied again by the reader)."""
+    rows = block.shape[0]
+    cells = block.reshape(rows, 4, 4)
+    pos = np.arange(4)[None, :] ^ _G4[(np.arange(rows) >> 2) & 3][:, None]          # cell stored at position p is cell p ^ key
+    return np.take_along_axis(cells, pos[:, :, None], axis=1).reshape(rows, 16)
+
+
+def pack_ffn(w1, w2):
+    """linear1.weight [1024,256], linear2.weight [256,1024] -> the fused FFN kernel's weight stream (csrc/ffn.h): per hidden slice
+    the 16 k-group chunks of W1 ([HS rows][16 k]) followed by the HS/16 k-group chunks of W2 ([256 rows][16 k]), every chunk
+    already in its swizzled LDS image, so that a workgroup's LDS-DMA is a linear copy of a contiguous 2*256*HS-float run."""
+    w1, w2 = np.asarray(w1, np.float32), np.asarray(w2, np.float32)
+    assert w1.shape == (FF, D) and w2.shape == (D, FF)
+    out = []
+    for h0, hs in ffn_slices():
+        assert hs % 16 == 0 and hs > 0
+        for g in range(D // 16):
+            out.append(_swizzle16(w1[h0:h0 + hs, 16 * g:16 * g + 16]).ravel())
+        for q in range(hs // 16):
+            out.append(_swizzle16(w2[:, h0 + 16 * q:h0 + 16 * q + 16]).ravel())
+    out = np.concatenate(out)
+    assert out.size == 2 * D * FF
+    return out
+
+
 class _Arena:
     def __init__(self):
         self.parts, self.n = [], 0
@@ -119,6 +155,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         ly.ca_out_b = ar.add(g(p + 'multihead_attn.out_proj.bias'))
         ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
         ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
+        ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
         for k in range(3):
             ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
             ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
@@ -138,6 +175,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
                 ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
             ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
             ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
+            ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
             for k in range(2):
                 ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
                 ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
@@ -281,6 +319,19 @@ class MDM:
         return out
 
     __call__ = forward
+
+
+def ffn_parts(model, x2, layer, encoder=False, out=None):
+    """The fused feed-forward block of one layer on ``model``'s weights: x2 [M,256] -> partial slabs [FFN_SLICES, M, 256] whose
+    sum is x2 + linear2(gelu(linear1(x2))) (interdiff_mdm_ffn)."""
+    lib = _lib.load()
+    M = x2.shape[0]
+    x2 = x2.contiguous()
+    if out is None:
+        out = torch.empty(_lib.FFN_SLICES, M, D, dtype=torch.float32, device=x2.device)
+    _lib.check(lib.interdiff_mdm_ffn(C.byref(model.w), layer, 1 if encoder else 0, _lib.dptr(x2, torch.float32), M, _lib.dptr(out),
+                                     _lib.stream()), 'mdm_ffn')
+    return out
 
 
 def linear(x, weight, bias=None, residual=None, gelu=False, out=None, cfg=0):

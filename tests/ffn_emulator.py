@@ -1,0 +1,167 @@
+"""Lane-level CPU emulation of csrc/ffn.h (the fused feed-forward kernel) for ONE workgroup: the packed weight stream
+(interdiff_amd/mdm.py: pack_ffn), the LDS images (XOR-swizzled x2 / hid rows, swizzled [rows][16] chunks in a 6-slot ring), the
+order in which chunk pairs are issued and consumed, the MFMA fragment <-> lane maps and both epilogues are restated here in numpy,
+so that the host-side packing and the kernel's addressing can be checked against a plain matmul WITHOUT a GPU.  The DMA is applied
+either at issue time ("early") or at the wait that covers it ("late"): a slot that is overwritten before its last read, or read
+before its data is guaranteed, gives a wrong answer in one of the two.  TEST INFRASTRUCTURE (not product code)."""
+import numpy as np
+
+D, FF, BM, NSL, NW, SLOT, NSLOT = 256, 1024, 32, 5, 8, 4096, 6
+
+
+def _gelu(x):
+    from math import erf
+    return 0.5 * x * (1.0 + np.vectorize(erf)(x / np.sqrt(2.0)))
+
+
+def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
+    M = x2.shape[0]
+    m0 = mt * BM
+    h0, HS = 208 * sl, (208 if sl < NSL - 1 else FF - 208 * (NSL - 1))
+    nt = HS // 16
+    stream = pack[2 * D * h0:]
+    w1sz = HS * 16
+    nch, npairs = 16 + nt, (16 + nt + 1) // 2
+    Xs, ring, Bs = np.zeros(BM * D), np.full(NSLOT * SLOT, np.nan), np.zeros(256)
+    lane = np.arange(64)
+    li, kq = lane & 15, lane >> 4
+    key = (4 - (li >> 2)) & 3
+    ch_off = lambda c: c * w1sz if c < 16 else 16 * w1sz + (c - 16) * SLOT
+    ch_ins = lambda c: 0 if c >= nch else (nt if c < 16 else 16)
+    pending = {}
+
+    def issue_pair(P):
+        ops = []
+        ca = 2 * P
+        na, ntot = ch_ins(ca), ch_ins(ca) + ch_ins(ca + 1)
+        for wave in range(NW):
+            for i in range(wave, ntot, NW):
+                c, loc = (ca, i) if i < na else (ca + 1, i - na)
+                src = ch_off(c) + loc * 256
+                ops.append(((c % NSLOT) * SLOT + loc * 256, stream[src:src + 256].copy()))
+        if late and ops:
+            pending[P] = ops
+        else:
+            for dst, data in ops:
+                ring[dst:dst + 256] = data
+
+    def land(P):
+        for dst, data in pending.pop(P, []):
+            ring[dst:dst + 256] = data
+
+    # prologue
+    Bs[:256] = np.resize(b1[h0:h0 + 256], 256) if h0 + 256 <= b1.size else np.concatenate([b1[h0:], np.zeros(256 - (b1.size - h0))])
+    for i in range(BM):
+        row = x2[min(m0 + i, M - 1)]
+        for l in range(64):
+            Xs[i * D + l * 4:i * D + l * 4 + 4] = row[(l ^ (i & 15)) * 4:(l ^ (i & 15)) * 4 + 4]
+    issue_pair(0)
+    issue_pair(1)
+    land(0)
+    # ---- phase 1
+    hid_acc = {}                                      # (wave, j) -> [16 rows][16 cols] accumulator tile in D layout
+
+    def mfma_group(acc, a, b):                        # a [64,4], b [64,4]: four 16x16x4 MFMAs
+        for comp in range(4):
+            A = np.zeros((16, 4))
+            Bm = np.zeros((4, 16))
+            A[li, kq] = a[:, comp]
+            Bm[kq, li] = b[:, comp]
+            acc += A @ Bm
+    maps = []
+    for wave in range(NW):
+        r1, half, hi = (wave >> 1) & 1, wave & 1, wave >> 2
+        left = (nt + 1) >> 1
+        hcnt = nt - left if half else left
+        n_a = (hcnt + 1) >> 1
+        c0 = (left if half else 0) + (n_a if hi else 0)
+        nct = hcnt - n_a if hi else n_a
+        maps.append((r1, c0, nct))
+        for j in range(nct):
+            hid_acc[(wave, j)] = np.zeros((16, 16))
+
+    def read1(wave, c):
+        r1, c0, nct = maps[wave]
+        rows = r1 * 16 + li
+        a = np.stack([Xs[rows * D + (((4 * c + kq) ^ li) << 2) + t] for t in range(4)], axis=1)
+        bs = []
+        for j in range(nct):
+            base = (c % NSLOT) * SLOT + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
+            bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
+        return a, bs
+    frag0 = [read1(w, 0) for w in range(NW)]
+    for P in range(8):
+        issue_pair(P + 2)
+        frag1 = [read1(w, 2 * P + 1) for w in range(NW)]
+        for w in range(NW):
+            a, bs = frag0[w]
+            for j, b in enumerate(bs):
+                mfma_group(hid_acc[(w, j)], a, b)
+        land(P + 1)                                   # the wait + barrier: pair P+1 has landed
+        if P + 1 < 8:
+            frag0 = [read1(w, 2 * P + 2) for w in range(NW)]
+        for w in range(NW):
+            a, bs = frag1[w]
+            for j, b in enumerate(bs):
+                mfma_group(hid_acc[(w, j)], a, b)
+    # epilogue 1: gelu(acc + b1) -> Xs (swizzled), D layout: lane (li, kq), reg rr -> row kq*4+rr, col li
+    for w in range(NW):
+        r1, c0, nct = maps[w]
+        for j in range(nct):
+            t = hid_acc[(w, j)]
+            for rr in range(16):
+                for cc in range(16):
+                    row, col = r1 * 16 + rr, (c0 + j) * 16 + cc
+                    Xs[row * D + (((col >> 2) ^ (row & 15)) << 2) + (col & 3)] = _gelu(t[rr, cc] + Bs[col])
+    # ---- phase 2
+    out_acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(4)}
+
+    def read2(wave, q):
+        r2, nb = wave & 1, (wave >> 1) * 4
+        rows = r2 * 16 + li
+        a = np.stack([Xs[rows * D + (((4 * q + kq) ^ li) << 2) + t] for t in range(4)], axis=1)
+        bs = []
+        for j in range(4):
+            base = ((16 + q) % NSLOT) * SLOT + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
+            bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
+        return a, bs
+    frag0 = [read2(w, 0) for w in range(NW)]
+    for P in range(8, npairs):
+        q = 2 * (P - 8)
+        two = q + 1 < nt
+        issue_pair(P + 2)
+        if two:
+            frag1 = [read2(w, q + 1) for w in range(NW)]
+        for w in range(NW):
+            a, bs = frag0[w]
+            for j, b in enumerate(bs):
+                mfma_group(out_acc[(w, j)], a, b)
+        land(P + 1)
+        if q + 2 < nt:
+            frag0 = [read2(w, q + 2) for w in range(NW)]
+        if two:
+            for w in range(NW):
+                a, bs = frag1[w]
+                for j, b in enumerate(bs):
+                    mfma_group(out_acc[(w, j)], a, b)
+    assert not pending
+    part = np.zeros((BM, D))
+    for w in range(NW):
+        r2, nb = w & 1, (w >> 1) * 4
+        for j in range(4):
+            part[r2 * 16:r2 * 16 + 16, (nb + j) * 16:(nb + j) * 16 + 16] = out_acc[(w, j)]
+    rows = np.minimum(m0 + np.arange(BM), M - 1)
+    if sl == 0:
+        part = part + x2[rows] + b2[None, :]
+    return part[:max(0, min(BM, M - m0))]
+
+
+def emulate_ffn(x2, pack, b1, b2, late):
+    """All workgroups -> parts [NSL][M][256] (float64 arithmetic)."""
+    M = x2.shape[0]
+    parts = np.zeros((NSL, M, D))
+    for mt in range((M + BM - 1) // BM):
+        for sl in range(NSL):
+            p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1.astype(np.float64), b2.astype(np.float64), mt, sl, late)
+            parts[sl, mt * BM:mt * BM + p.shape[0]] = p
+    return parts

@@ -178,3 +178,25 @@ def test_joint_map_vjp_host_matches_autograd():
     assert lib.interdiff_debug_joint_map_vjp(Rn.ctypes.data, gn.ctypes.data, out.ctypes.data, n) == 0
     assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
     assert ((out == 0) == (ref == 0)).all()
+
+
+def test_ffn_pack_and_kernel_addressing_by_emulation():
+    """The fused feed-forward kernel (csrc/ffn.h) restated lane by lane in numpy (tests/ffn_emulator.py) on the weight stream
+    pack_ffn builds: sum of the five partial slabs == x2 + linear2(gelu(linear1(x2))) for a ragged row count, with the DMA applied
+    at issue time and at the covering wait (ring-slot reuse hazards show up as a wrong answer in one of the two)."""
+    import numpy as np
+    from interdiff_amd.mdm import pack_ffn, ffn_slices
+    from tests.ffn_emulator import emulate_ffn, _gelu
+    rs = np.random.RandomState(0)
+    M = 37                                                 # two M tiles, the second ragged
+    x2 = rs.standard_normal((M, 256)).astype(np.float32)
+    w1 = (rs.standard_normal((1024, 256)) / 16).astype(np.float32)
+    w2 = (rs.standard_normal((256, 1024)) / 32).astype(np.float32)
+    b1, b2 = rs.standard_normal(1024).astype(np.float32), rs.standard_normal(256).astype(np.float32)
+    pack = pack_ffn(w1, w2)
+    assert [s for s in ffn_slices()] == [(0, 208), (208, 208), (416, 208), (624, 208), (832, 192)]
+    ref = x2.astype(np.float64) + _gelu(x2.astype(np.float64) @ w1.T.astype(np.float64) + b1) @ w2.T.astype(np.float64) + b2
+    for late in (False, True):
+        parts = emulate_ffn(x2, pack, b1, b2, late)
+        err = np.abs(parts.sum(0) - ref).max()
+        assert err < 1e-9, (late, err)

@@ -454,6 +454,27 @@ def test_gemm_f32_epilogues_vs_torch_fp32(lib):
         linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0
 
 
+@pytest.mark.parametrize('M', [1, 31, 33, 160, 1600, 3200])
+def test_fused_ffn_vs_torch_fp64(mdm, M):
+    """interdiff_mdm_ffn (csrc/ffn.h: linear1 -> gelu -> linear2 in one launch, five partial slabs summed by the reader) against
+    torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts."""
+    from interdiff_amd.mdm import ffn_parts
+    g = torch.Generator().manual_seed(100 + M)
+    x2 = torch.randn(M, 256, generator=g)
+    sd = fx.mdm_weights()
+    for enc, layer, pre in ((False, 1, 'decoder.layers.1.'), (False, 7, 'decoder.layers.7.'), (True, 3, 'encoder.layers.3.')):
+        parts = ffn_parts(mdm, x2.to(DEV), layer, encoder=enc)
+        assert parts.shape == (5, M, 256)
+        got = (((parts[0] + parts[1]) + parts[2]) + parts[3]) + parts[4]
+        w1, b1 = sd[pre + 'linear1.weight'].double(), sd[pre + 'linear1.bias'].double()
+        w2, b2 = sd[pre + 'linear2.weight'].double(), sd[pre + 'linear2.bias'].double()
+        xd = x2.double()
+        ref = xd + torch.nn.functional.gelu(xd @ w1.T + b1) @ w2.T + b2
+        close(got, ref, 2e-6, 'fused FFN M=%d %s' % (M, pre))
+    again = ffn_parts(mdm, x2.to(DEV), 1)
+    assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1)), 'deterministic: no atomics, fixed summation order'
+
+
 # ------------------------------------------------------------------------------------------ other BASELINE configurations
 @pytest.mark.parametrize('B,T', [(32, 100), (32, 35), (1, 30)])
 def test_other_configs_run_and_match_oracle_step(smpl, B, T):

@@ -125,7 +125,8 @@ typedef struct {
     int64_t ca_kv_w, ca_kv_b;  /* cross-attn key|value proj [512,256],[512]              */
     int64_t ca_out_w, ca_out_b;
     int64_t ff1_w, ff1_b, ff2_w, ff2_b;             /* [1024,256],[1024],[256,1024],[256] */
-    int64_t ffn_pack;          /* linear1 + linear2 weights in the fused FFN kernel's stream order (2*256*1024 floats, mdm.py pack_ffn) */
+    int64_t ffn_pack;          /* linear1 + linear2 weights in the fused FFN kernel's stream order (5 x 106496 floats, mdm.py pack_ffn) */
+    int64_t ffn_b1p;           /* linear1 bias zero-padded to 5 x 208 (+ 256 spare floats)                                      */
     int64_t ln_w[3], ln_b[3];
 } idf_mdm_layer;
 

@@ -64,9 +64,10 @@ FFN_SLICE_H = 208           # hidden units per slice of the fused FFN kernel (13
 _G4 = np.array([0, 3, 2, 1])
 
 
-def ffn_slices(ff=FF, n=_lib.FFN_SLICES):
-    """(first hidden unit, count) of every slice -- csrc/ffn.h slice_h0 / slice_hs."""
-    return [(FFN_SLICE_H * s, FFN_SLICE_H if s < n - 1 else ff - FFN_SLICE_H * (n - 1)) for s in range(n)]
+def ffn_slices(n=_lib.FFN_SLICES):
+    """(first hidden unit, count) of every slice -- csrc/ffn.h: all slices are FFN_SLICE_H wide, 5 x 208 = 1040 >= 1024, the
+    units past 1023 are zero weights / zero bias (gelu(0) = 0 times zero columns: they contribute exactly nothing)."""
+    return [(FFN_SLICE_H * s, FFN_SLICE_H) for s in range(n)]
 
 
 def _swizzle16(block):
@@ -80,19 +81,28 @@ def _swizzle16(block):
 
 def pack_ffn(w1, w2):
     """linear1.weight [1024,256], linear2.weight [256,1024] -> the fused FFN kernel's weight stream (csrc/ffn.h): per hidden slice
-    the 16 k-group chunks of W1 ([HS rows][16 k]) followed by the HS/16 k-group chunks of W2 ([256 rows][16 k]), every chunk
-    already in its swizzled LDS image, so that a workgroup's LDS-DMA is a linear copy of a contiguous 2*256*HS-float run."""
+    the 16 k-group chunks of W1 ([208 rows][16 k]) followed by the 13 k-group chunks of W2 ([256 rows][16 k]), every chunk
+    already in its swizzled LDS image, so that a workgroup's LDS-DMA is a linear copy of a contiguous 416-KiB run."""
     w1, w2 = np.asarray(w1, np.float32), np.asarray(w2, np.float32)
     assert w1.shape == (FF, D) and w2.shape == (D, FF)
+    hp = FFN_SLICE_H * _lib.FFN_SLICES
+    w1p, w2p = np.zeros((hp, D), np.float32), np.zeros((D, hp), np.float32)
+    w1p[:FF], w2p[:, :FF] = w1, w2
     out = []
     for h0, hs in ffn_slices():
-        assert hs % 16 == 0 and hs > 0
         for g in range(D // 16):
-            out.append(_swizzle16(w1[h0:h0 + hs, 16 * g:16 * g + 16]).ravel())
+            out.append(_swizzle16(w1p[h0:h0 + hs, 16 * g:16 * g + 16]).ravel())
         for q in range(hs // 16):
-            out.append(_swizzle16(w2[:, h0 + 16 * q:h0 + 16 * q + 16]).ravel())
+            out.append(_swizzle16(w2p[:, h0 + 16 * q:h0 + 16 * q + 16]).ravel())
     out = np.concatenate(out)
-    assert out.size == 2 * D * FF
+    assert out.size == _lib.FFN_SLICES * (16 * FFN_SLICE_H * 16 + (FFN_SLICE_H // 16) * D * 16)
+    return out
+
+
+def pad_ffn_bias(b1):
+    """linear1.bias [1024] -> [5 * 208] zero-padded + one spare KiB (the kernel fetches a slice's bias with one 1-KiB DMA)."""
+    out = np.zeros(FFN_SLICE_H * _lib.FFN_SLICES + 256, np.float32)
+    out[:FF] = np.asarray(b1, np.float32)
     return out
 
 
@@ -156,6 +166,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
         ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
         ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
+        ly.ffn_b1p = ar.add(pad_ffn_bias(g(p + 'linear1.bias')))
         for k in range(3):
             ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
             ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
@@ -176,6 +187,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
             ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
             ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
+            ly.ffn_b1p = ar.add(pad_ffn_bias(g(p + 'linear1.bias')))
             for k in range(2):
                 ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
                 ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))

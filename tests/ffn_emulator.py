@@ -6,7 +6,13 @@ either at issue time ("early") or at the wait that covers it ("late"): a slot th
 before its data is guaranteed, gives a wrong answer in one of the two.  TEST INFRASTRUCTURE (not product code)."""
 import numpy as np
 
-D, FF, BM, NSL, NW, SLOT, NSLOT = 256, 1024, 32, 5, 8, 4096, 6
+D, FF, BM, NSL, NW = 256, 1024, 32, 5, 8
+HS, NTILE = 208, 13
+W1C, W2C = HS * 16, D * 16
+NP1, NP2 = 8, 7
+NPAIR = NP1 + NP2
+SLICE_FLOATS = 16 * W1C + NTILE * W2C
+PSLOT = 2 * W2C
 
 
 def _gelu(x):
@@ -14,31 +20,37 @@ def _gelu(x):
     return 0.5 * x * (1.0 + np.vectorize(erf)(x / np.sqrt(2.0)))
 
 
-def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
+def pair_off(P):
+    return P * 2 * W1C if P < NP1 else 16 * W1C + (P - NP1) * 2 * W2C
+
+
+def pair_ins(P):
+    if P >= NPAIR:
+        return 0
+    return 2 * W1C // 256 if P < NP1 else (2 * W2C // 256 if P < NPAIR - 1 else W2C // 256)
+
+
+def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
     M = x2.shape[0]
     m0 = mt * BM
-    h0, HS = 208 * sl, (208 if sl < NSL - 1 else FF - 208 * (NSL - 1))
-    nt = HS // 16
-    stream = pack[2 * D * h0:]
-    w1sz = HS * 16
-    nch, npairs = 16 + nt, (16 + nt + 1) // 2
-    Xs, ring, Bs = np.zeros(BM * D), np.full(NSLOT * SLOT, np.nan), np.zeros(256)
+    nt = NTILE
+    stream = pack[sl * SLICE_FLOATS:(sl + 1) * SLICE_FLOATS]
+    Xs, ring, Bs = np.zeros(BM * D), np.full(3 * PSLOT, np.nan), np.zeros(256)
     lane = np.arange(64)
     li, kq = lane & 15, lane >> 4
     key = (4 - (li >> 2)) & 3
-    ch_off = lambda c: c * w1sz if c < 16 else 16 * w1sz + (c - 16) * SLOT
-    ch_ins = lambda c: 0 if c >= nch else (nt if c < 16 else 16)
     pending = {}
 
     def issue_pair(P):
         ops = []
-        ca = 2 * P
-        na, ntot = ch_ins(ca), ch_ins(ca) + ch_ins(ca + 1)
+        nins = pair_ins(P)
         for wave in range(NW):
-            for i in range(wave, ntot, NW):
-                c, loc = (ca, i) if i < na else (ca + 1, i - na)
-                src = ch_off(c) + loc * 256
-                ops.append(((c % NSLOT) * SLOT + loc * 256, stream[src:src + 256].copy()))
+            for j in range(4):
+                i = wave + 8 * j
+                if i < nins:                              # 8j+7 < nins for every wave, or the ragged tail for waves 0, 1
+                    assert (8 * j + 7 < nins) or (8 * j < nins and wave < 2)
+                    src = pair_off(P) + i * 256
+                    ops.append(((P % 3) * PSLOT + i * 256, stream[src:src + 256].copy()))
         if late and ops:
             pending[P] = ops
         else:
@@ -50,7 +62,7 @@ def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
             ring[dst:dst + 256] = data
 
     # prologue
-    Bs[:256] = np.resize(b1[h0:h0 + 256], 256) if h0 + 256 <= b1.size else np.concatenate([b1[h0:], np.zeros(256 - (b1.size - h0))])
+    Bs[:256] = b1p[sl * HS:sl * HS + 256]
     for i in range(BM):
         row = x2[min(m0 + i, M - 1)]
         for l in range(64):
@@ -70,12 +82,9 @@ def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
             acc += A @ Bm
     maps = []
     for wave in range(NW):
-        r1, half, hi = (wave >> 1) & 1, wave & 1, wave >> 2
-        left = (nt + 1) >> 1
-        hcnt = nt - left if half else left
-        n_a = (hcnt + 1) >> 1
-        c0 = (left if half else 0) + (n_a if hi else 0)
-        nct = hcnt - n_a if hi else n_a
+        r1 = (wave >> 1) & 1
+        c0 = ((7 if wave < 4 else 10) if wave & 1 else (0 if wave < 4 else 4))
+        nct = 4 if wave in (0, 2) else 3
         maps.append((r1, c0, nct))
         for j in range(nct):
             hid_acc[(wave, j)] = np.zeros((16, 16))
@@ -83,10 +92,10 @@ def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
     def read1(wave, c):
         r1, c0, nct = maps[wave]
         rows = r1 * 16 + li
-        a = np.stack([Xs[rows * D + (((4 * c + kq) ^ li) << 2) + t] for t in range(4)], axis=1)
+        a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
         bs = []
         for j in range(nct):
-            base = (c % NSLOT) * SLOT + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
+            base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
     frag0 = [read1(w, 0) for w in range(NW)]
@@ -119,15 +128,15 @@ def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
     def read2(wave, q):
         r2, nb = wave & 1, (wave >> 1) * 4
         rows = r2 * 16 + li
-        a = np.stack([Xs[rows * D + (((4 * q + kq) ^ li) << 2) + t] for t in range(4)], axis=1)
+        a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (q & 3))) << 2) + 64 * (q >> 2) + t] for t in range(4)], axis=1)
         bs = []
         for j in range(4):
-            base = ((16 + q) % NSLOT) * SLOT + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
+            base = ((NP1 + (q >> 1)) % 3) * PSLOT + (q & 1) * W2C + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
     frag0 = [read2(w, 0) for w in range(NW)]
-    for P in range(8, npairs):
-        q = 2 * (P - 8)
+    for P in range(NP1, NPAIR):
+        q = 2 * (P - NP1)
         two = q + 1 < nt
         issue_pair(P + 2)
         if two:
@@ -156,12 +165,12 @@ def emulate_workgroup(x2, pack, b1, b2, mt, sl, late):
     return part[:max(0, min(BM, M - m0))]
 
 
-def emulate_ffn(x2, pack, b1, b2, late):
+def emulate_ffn(x2, pack, b1p, b2, late):
     """All workgroups -> parts [NSL][M][256] (float64 arithmetic)."""
     M = x2.shape[0]
     parts = np.zeros((NSL, M, D))
     for mt in range((M + BM - 1) // BM):
         for sl in range(NSL):
-            p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1.astype(np.float64), b2.astype(np.float64), mt, sl, late)
+            p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1p.astype(np.float64), b2.astype(np.float64), mt, sl, late)
             parts[sl, mt * BM:mt * BM + p.shape[0]] = p
     return parts

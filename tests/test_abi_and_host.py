@@ -185,7 +185,7 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
     pack_ffn builds: sum of the five partial slabs == x2 + linear2(gelu(linear1(x2))) for a ragged row count, with the DMA applied
     at issue time and at the covering wait (ring-slot reuse hazards show up as a wrong answer in one of the two)."""
     import numpy as np
-    from interdiff_amd.mdm import pack_ffn, ffn_slices
+    from interdiff_amd.mdm import pack_ffn, pad_ffn_bias, ffn_slices
     from tests.ffn_emulator import emulate_ffn, _gelu
     rs = np.random.RandomState(0)
     M = 37                                                 # two M tiles, the second ragged
@@ -194,9 +194,9 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
     w2 = (rs.standard_normal((256, 1024)) / 32).astype(np.float32)
     b1, b2 = rs.standard_normal(1024).astype(np.float32), rs.standard_normal(256).astype(np.float32)
     pack = pack_ffn(w1, w2)
-    assert [s for s in ffn_slices()] == [(0, 208), (208, 208), (416, 208), (624, 208), (832, 192)]
+    assert [s for s in ffn_slices()] == [(0, 208), (208, 208), (416, 208), (624, 208), (832, 208)] and pack.size == 5 * 106496
     ref = x2.astype(np.float64) + _gelu(x2.astype(np.float64) @ w1.T.astype(np.float64) + b1) @ w2.T.astype(np.float64) + b2
     for late in (False, True):
-        parts = emulate_ffn(x2, pack, b1, b2, late)
+        parts = emulate_ffn(x2, pack, pad_ffn_bias(b1), b2, late)
         err = np.abs(parts.sum(0) - ref).max()
         assert err < 1e-9, (late, err)

@@ -260,7 +260,8 @@ typedef struct {
     const int32_t *faces;      /* [F][3] */
     const int32_t *adj_ptr, *adj_face, *adj_corner;
     const int32_t *markers_idx;
-    int32_t n_markers, n_points, past_len, _pad;
+    int32_t n_markers, n_points, past_len;
+    int32_t tune;              /* 0 = shipped configuration of the contact scan; tools may set 1 (8 waves x 4 points per thread) */
 } idf_correction_ctx;
 
 size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);

@@ -57,7 +57,7 @@ class ObjProj(C.Structure):
 class CorrectionCtx(C.Structure):
     _fields_ = [('smpl', C.POINTER(SmplModel)), ('objproj', C.POINTER(ObjProj)),
                 ('faces', vp), ('adj_ptr', vp), ('adj_face', vp), ('adj_corner', vp), ('markers_idx', vp),
-                ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('_pad', i32)]
+                ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('tune', i32)]
 
 
 class OptCtx(C.Structure):

@@ -77,15 +77,19 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 }
 
 // ---- K4: per-frame contact analysis -------------------------------------------------------------------
-// One workgroup (CT threads = 16 waves, four per SIMD) per frame; every thread owns QP object points as QP/2 PACKED
-// pairs: the exact-arithmetic distance (dx*dx + dy*dy) + dz*dz of a pair against the LDS-broadcast vertex is
-// 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add (no FMA contraction, so the argmin is bit-identical to geometry.hip
-// and to the oracle), then compare + 2 selects per point.
-constexpr int CT = 1024;               // threads per workgroup
-constexpr int QP = 2;                  // object points per thread (P <= CT*QP = 2048)
+// One workgroup (CT threads) per frame; every thread owns QP object points as QP/2 PACKED pairs: the exact-arithmetic
+// distance (dx*dx + dy*dy) + dz*dz of a pair against the LDS-broadcast vertex is 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add
+// (no FMA contraction, so the argmin is bit-identical to geometry.hip and to the oracle).
+// The scan itself only keeps the running MINIMUM (v_min3_f32 over vertex pairs); which vertex it was is settled per block of
+// VB vertices -- one compare + two selects per point per BLOCK instead of per vertex -- and resolved afterwards by re-scoring
+// the one winning block: the first vertex of the first block whose distance equals the minimum, i.e. exactly the
+// lowest-index-wins rule of the brute force.  11 -> ~8.6 VALU lane-ops per (point, vertex) pair.
+constexpr int MAXP = 2048;             // object points per frame handled by one workgroup (CT * QP)
 constexpr int MAXM = 128;
+constexpr int VB = 8;                  // vertices per index-bookkeeping block
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+template <int CT, int QP>
 __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restrict__ verts, int V,
                                                           const float *__restrict__ obj_points, int P,
                                                           const float *__restrict__ objR, const float *__restrict__ objT,
@@ -97,16 +101,16 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                                                           float *__restrict__ min_dist, int32_t *__restrict__ label,
                                                           float *__restrict__ o2h_out /* nullable [N][P] */,
                                                           int64_t nn_from /* frames below it skip the NN scan */) {
-    extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V rounded up to 4] then markers [MAXM]
-    const int V4 = (V + 3) & ~3;
-    float4 *ms = vs + V4;
+    extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V rounded up to VB, + one far-away block] then markers [MAXM]
+    const int V4 = (V + VB - 1) / VB * VB;                                 // records are (x, y, z, z): {z, z} is a ready-made packed operand
+    float4 *ms = vs + V4 + VB;
     __shared__ int flags[MAXM];
     __shared__ float red[CT];
     const int64_t n = blockIdx.x;
     const int b = (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
-    for (int v = tid; v < V4; v += CT)
-        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], __int_as_float(v)) : make_float4(3e18f, 3e18f, 3e18f, 0.f);
+    for (int v = tid; v < V4 + VB; v += CT)                                // the extra block lets the scan prefetch one block past the end
+        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], vf[3 * v + 2]) : make_float4(3e18f, 3e18f, 3e18f, 3e18f);
     if (tid < MAXM) flags[tid] = 0;
     __syncthreads();
     if (tid < M) {
@@ -148,29 +152,53 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     const bool do_nn = n >= nn_from;
     if (do_nn) {
 #pragma clang fp contract(off)
-        // software pipeline: the LDS records of the NEXT four vertices are in flight while the current four are scored
-        float4 cur[4], nxt[4];
+        int bblk[QP];                                    // first vertex of the block that last lowered the minimum
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = vs[u];
-        for (int v0 = 0; v0 < V4; v0 += 4) {
-            const int vn = v0 + 4 < V4 ? v0 + 4 : v0;
+        for (int k = 0; k < QP; ++k) bblk[k] = 0;
+        // software pipeline: the LDS records of the NEXT block are in flight while the current one is scored
+        float4 cur[VB], nxt[VB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = vs[vn + u];
+        for (int u = 0; u < VB; ++u) cur[u] = vs[u];
+        for (int v0 = 0; v0 < V4; v0 += VB) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 p = cur[u];
-                const v2f PX = v2f{p.x, p.x}, PY = v2f{p.y, p.y}, PZ = v2f{p.z, p.z};
+            for (int u = 0; u < VB; ++u) nxt[u] = vs[v0 + VB + u];
+            v2f bm[QP / 2];
+#pragma unroll
+            for (int k = 0; k < QP / 2; ++k) bm[k] = v2f{FLT_MAX, FLT_MAX};
+#pragma unroll
+            for (int u = 0; u < VB; u += 2) {
+                const float4 p = cur[u], r = cur[u + 1];
+                const v2f PX = v2f{p.x, p.x}, PY = v2f{p.y, p.y}, PZ = v2f{p.z, p.w};
+                const v2f RX = v2f{r.x, r.x}, RY = v2f{r.y, r.y}, RZ = v2f{r.z, r.w};
 #pragma unroll
                 for (int k = 0; k < QP / 2; ++k) {
                     const v2f dx = QX[k] - PX, dy = QY[k] - PY, dz = QZ[k] - PZ;
                     const v2f d2 = (dx * dx + dy * dy) + dz * dz;
-                    // the vertex id rides in .w of the LDS record (one 16-B broadcast read per vertex)
-                    if (d2.x < best[k].x) { best[k].x = d2.x; bi[2 * k] = __float_as_int(p.w); }
-                    if (d2.y < best[k].y) { best[k].y = d2.y; bi[2 * k + 1] = __float_as_int(p.w); }
+                    const v2f ex = QX[k] - RX, ey = QY[k] - RY, ez = QZ[k] - RZ;
+                    const v2f e2 = (ex * ex + ey * ey) + ez * ez;
+                    bm[k].x = fminf(fminf(bm[k].x, d2.x), e2.x);          // v_min3_f32
+                    bm[k].y = fminf(fminf(bm[k].y, d2.y), e2.y);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            for (int k = 0; k < QP / 2; ++k) {
+                if (bm[k].x < best[k].x) { best[k].x = bm[k].x; bblk[2 * k] = v0; }
+                if (bm[k].y < best[k].y) { best[k].y = bm[k].y; bblk[2 * k + 1] = v0; }
+            }
+#pragma unroll
+            for (int u = 0; u < VB; ++u) cur[u] = nxt[u];
+        }
+        // resolve the index inside the winning block: lowest vertex whose (bit-identical) distance equals the minimum
+#pragma unroll
+        for (int k = 0; k < QP; ++k) {
+            const float bk = (k & 1) ? best[k >> 1].y : best[k >> 1].x;
+            int idx = bblk[k];
+#pragma unroll
+            for (int u = VB - 1; u >= 0; --u) {
+                const float4 p = vs[bblk[k] + u];
+                if (dist2_exact(qx[k], qy[k], qz[k], p.x, p.y, p.z) == bk) idx = bblk[k] + u;
+            }
+            bi[k] = idx;
         }
     }
     float loss = 0.f, mind = FLT_MAX;
@@ -235,12 +263,20 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
                    const float *objT, const idf_correction_ctx *c, int B, float *markers, float *loss_sum, float *min_dist,
                    int32_t *label, float *o2h, int64_t nn_from) {
     const int M = c->n_markers;
-    const size_t lds = ((size_t)((V + 3) & ~3) + MAXM) * sizeof(float4);
-    if (lds > 160 * 1024 - 8192) return IDF_E_INVAL;
-    static std::atomic<uint64_t> lds_ok{0};
-    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
-    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
-                       c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
+    const size_t lds = ((size_t)((V + VB - 1) / VB * VB) + VB + MAXM) * sizeof(float4);
+    if (lds > 160 * 1024 - 8192 || P > MAXP) return IDF_E_INVAL;
+    // two shapes of the same scan: 16 waves x 2 points per thread (default) or 8 waves x 4 points (tune = 1: half the LDS broadcasts)
+    if (c->tune == 1) {
+        static std::atomic<uint64_t> lds_ok{0};
+        if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<512, 4>), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+        hipLaunchKernelGGL((corr_contact_kernel<512, 4>), dim3((unsigned)N), dim3(512), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
+                           c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
+    } else {
+        static std::atomic<uint64_t> lds_ok{0};
+        if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<1024, 2>), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+        hipLaunchKernelGGL((corr_contact_kernel<1024, 2>), dim3((unsigned)N), dim3(1024), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
+                           c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
+    }
     return IDF_OK;
 }
 
@@ -327,7 +363,7 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
                                     size_t ws_bytes, void *stream) {
     if (!c || !c->smpl || !c->objproj || !x0 || !gt || !hand_pose || !beta || !obj_points || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
     const int V = c->smpl->V, M = c->n_markers, P = c->n_points;
-    if (c->smpl->J != 52 || c->smpl->n_betas != 10 || M > MAXM || M != c->objproj->P || P > CT * QP || T != c->objproj->T ||
+    if (c->smpl->J != 52 || c->smpl->n_betas != 10 || M > MAXM || M != c->objproj->P || P > MAXP || T != c->objproj->T ||
         c->past_len != c->objproj->past_len || c->past_len >= T)
         return IDF_E_INVAL;
     CorrWs w = carve(c, B, T, ws);
@@ -475,7 +511,7 @@ extern "C" int interdiff_metrics(const idf_correction_ctx *c, const float *obj_p
         !ws || B <= 0 || T <= 0 || J <= 0)
         return IDF_E_INVAL;
     const int V = c->smpl->V, M = c->n_markers, P = c->n_points;
-    if (M > MAXM || P > CT * QP) return IDF_E_INVAL;
+    if (M > MAXM || P > MAXP) return IDF_E_INVAL;
     MetWs w = carve_metrics(c, B, T, ws);
     if (ws_bytes < w.total) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);

@@ -244,11 +244,22 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         for (int j = 0; j < 4; ++j) b[j] = ldsv4(sb + j * 256);
     };
     read2(0, a0, b0);
+    // slab 0 carries the residual and the output bias: its workgroups fetch them two pairs before the end (plain loads, younger than
+    // every DMA, consumed after the loop) instead of serialising them behind the last barrier -- they are the launch's slowest workgroups
+    float4 xres[BM * (D / 4) / NT], bres[BM * (D / 4) / NT];
 #pragma unroll
     for (int P = NP1; P < NPAIR; ++P) {
         const int q = 2 * (P - NP1);
         const bool two = q + 1 < NTILE;
         issue_pair(P + 2);
+        if (P == NPAIR - 2 && sl == 0) {
+#pragma unroll
+            for (int it = 0; it < BM * (D / 4) / NT; ++it) {
+                const int idx = tid + it * NT, row = idx >> 6, c4 = (idx & 63) << 2;
+                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + row, M - 1) * D + c4);
+                bres[it] = *reinterpret_cast<const float4 *>(b2 + c4);
+            }
+        }
         if (two) read2(q + 1, a1, b1f);
         mma_group4<MODE>(acc, a0, b0);
         wait_pair_before(P + 2);
@@ -272,8 +283,8 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         const int idx = tid + it * NT, row = idx >> 6, c4 = (idx & 63) << 2, gr = m0 + row;
         if (gr >= M) continue;
         float4 v = ldsv4(Cs + row * CSS + c4);
-        if (sl == 0) {                                    // slab 0 carries the residual and the output bias
-            const float4 x = *reinterpret_cast<const float4 *>(x2 + (size_t)gr * D + c4), bb = *reinterpret_cast<const float4 *>(b2 + c4);
+        if (sl == 0) {
+            const float4 x = xres[it], bb = bres[it];
             v.x += x.x + bb.x; v.y += x.y + bb.y; v.z += x.z + bb.z; v.w += x.w + bb.w;
         }
         *reinterpret_cast<float4 *>(out + (size_t)gr * D + c4) = v;

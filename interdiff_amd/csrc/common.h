@@ -34,6 +34,8 @@ static inline int idf_opt_in_lds(const void *fn, int bytes, std::atomic<uint64_t
     return IDF_OK;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---- LDS-DMA (global -> LDS without a VGPR round trip) as INLINE ASM ----------------------------------------------------------
 // hipcc's waitcnt pass cannot tell which LDS bytes a `global_load_lds` writes, so with the builtin it drains vmcnt to 0 before the
 // first ds_read that follows ANY pending DMA -- a software pipeline that keeps chunks in flight across iterations silently degrades
@@ -60,13 +62,22 @@ __device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory", "m0");
 }
 
+// 16-byte WRITE-THROUGH store (sc0 sc1): the line goes to the memory side right away instead of sitting dirty in this XCD's L2
+// until the end-of-kernel write-back.  For tensors that the NEXT kernel reads from other XCDs (every layer output here) this takes
+// the flush off the kernel boundary (MI355X_MICROARCH.md: a boundary costs + bytes-left-dirty / 6 TB/s) and overlaps it with the
+// rest of the launch.  Invisible to the compiler's vmcnt bookkeeping like every asm memory op: only for data this kernel never
+// reads back.
+__device__ __forceinline__ void idf_store16_wt(float *p, const float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+}
+
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
 extern bool g_idf_prof_on;
 void idf_prof_mark_slow(int kind, hipStream_t s);
 static inline void idf_prof_mark(int kind, hipStream_t s) { if (g_idf_prof_on) idf_prof_mark_slow(kind, s); }
 
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- cross-lane reductions on the DPP path (no LDS-crossbar permutes) --------------------------------------
@@ -147,27 +158,45 @@ __device__ __forceinline__ void row16_load(Row16 &r, const float *__restrict__ r
 #pragma unroll
     for (int i = 0; i < 4; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * 16 + l16) * 4);
 }
-// A layer output is either one [N,256] matrix or the IDF_FFN_SLICES partial slabs the fused FFN leaves behind (ffn.h): element =
-// ((((s0 + s1) + s2) + s3) + s4), slabs `stride` floats apart.  Summed in this fixed order by every reader: deterministic.
-__device__ __forceinline__ float4 ld4_sum(const float *__restrict__ p, int np, size_t stride) {
-    float4 v = *reinterpret_cast<const float4 *>(p);
-    if (np == IDF_FFN_SLICES) {                       // all loads in flight before the first add
-        float4 t[IDF_FFN_SLICES - 1];
+// A layer output is either one [N,256] matrix (NP = 1) or the IDF_FFN_SLICES partial slabs the fused FFN leaves behind (ffn.h):
+// element = ((((s0 + s1) + s2) + s3) + s4), slabs `stride` floats apart.  Summed in this fixed order by every reader: deterministic.
+// NP is a COMPILE-TIME constant on purpose: with a run-time slab count the compiler parks a `s_waitcnt vmcnt(0)` in front of the
+// branch and every slab of every row becomes its own round trip to memory (a row-block prologue of 16 dependent fetches).
+template <int NP>
+__device__ __forceinline__ float4 ld4_sum(const float *__restrict__ p, size_t stride) {
+    float4 t[NP];
 #pragma unroll
-        for (int s = 1; s < IDF_FFN_SLICES; ++s) t[s - 1] = *reinterpret_cast<const float4 *>(p + s * stride);
+    for (int s = 0; s < NP; ++s) t[s] = *reinterpret_cast<const float4 *>(p + s * stride);      // all loads in flight before the first add
+    float4 v = t[0];
 #pragma unroll
-        for (int s = 1; s < IDF_FFN_SLICES; ++s) { v.x += t[s - 1].x; v.y += t[s - 1].y; v.z += t[s - 1].z; v.w += t[s - 1].w; }
-    } else {
-        for (int s = 1; s < np; ++s) {
-            const float4 t = *reinterpret_cast<const float4 *>(p + s * stride);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-    }
+    for (int s = 1; s < NP; ++s) { v.x += t[s].x; v.y += t[s].y; v.z += t[s].z; v.w += t[s].w; }
     return v;
 }
-__device__ __forceinline__ void row16_load_sum(Row16 &r, const float *__restrict__ row, int l16, int np, size_t stride) {
+// split form: request (all 4*NP loads, nothing consumed) ... reduce later, so that several rows' fetches share one trip to memory
+template <int NP>
+struct Row16Raw {
+    float4 t[4][NP];
+    __device__ __forceinline__ void request(const float *__restrict__ row, int l16, size_t stride) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.c[i] = ld4_sum(row + (i * 16 + l16) * 4, np, stride);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) t[i][s] = *reinterpret_cast<const float4 *>(row + s * stride + (i * 16 + l16) * 4);
+    }
+    __device__ __forceinline__ void reduce(Row16 &r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = t[i][0];
+#pragma unroll
+            for (int s = 1; s < NP; ++s) { v.x += t[i][s].x; v.y += t[i][s].y; v.z += t[i][s].z; v.w += t[i][s].w; }
+            r.c[i] = v;
+        }
+    }
+};
+template <int NP>
+__device__ __forceinline__ void row16_load_sum(Row16 &r, const float *__restrict__ row, int l16, size_t stride) {
+    Row16Raw<NP> raw;
+    raw.request(row, l16, stride);
+    raw.reduce(r);
 }
 __device__ __forceinline__ void row16_store(const Row16 &r, float *__restrict__ row, int l16) {
 #pragma unroll

@@ -23,6 +23,11 @@
 #include "ffn.h"
 #include <float.h>
 
+// phase stamps of the row-block kernel exist only in tools/rowblock_probe.hip (which defines the macro before including this file)
+#ifndef IDF_RB_STAMP
+#define IDF_RB_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 using namespace idf_gemm;
@@ -35,6 +40,18 @@ constexpr int MEM = IDF_MDM_MEM;      // 10
 constexpr int HM = H * MEM;           // 40
 constexpr int HMP = 48;               // HM padded to a multiple of 16 (k-groups of the P.VW contraction)
 constexpr int L = IDF_MDM_LAYERS;
+constexpr int NSL = IDF_FFN_SLICES;   // partial output slabs of the fused FFN (ffn.h)
+
+// XCD-affine workgroup order for the kernels below (speed only; any order is correct): workgroup `id` of a launch runs on XCD
+// id % 8 and every XCD has its own L2, so the LOGICAL index is permuted to make one XCD work through consecutive logical
+// workgroups -- the 7 token tiles of a clip (which all read the clip's folded memory G[b] / VW[b]) or the 4 query tiles of a
+// (clip, head) (which all read its K and V) then fetch those operands into ONE L2 instead of up to eight.  Each XCD reaches
+// HBM / Infinity Cache at only ~1/8 of the chip's rate, and at one workgroup per CU that fetch is most of what these kernels wait for.
+__device__ __forceinline__ int xcd_logical_id() {
+    const int nwg = gridDim.x * gridDim.y * gridDim.z, id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
 
 // four dependent-free rounds of MFMAs over NA accumulators: acc[i] += a[i](k-group) . b[i](k-group)
 template <int NA>
@@ -56,6 +73,30 @@ __device__ __forceinline__ float4 ln_apply(const float4 v, const float4 g, const
                        (v.w - mean) * rstd * g.w + b.w);
 }
 
+// LayerNorm with gamma / beta read from LDS (staged there by DMA at kernel entry; same arithmetic as common.h ln_row16): lane l16
+// of a 16-lane row group handles the chunks {l16, 16+l16, 32+l16, 48+l16} of its row
+__device__ __forceinline__ void ln_row16_lds(Row16 &r, const float *w, const float *b, int l16) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
+    const float mean = row16_sum(sum) * (1.0f / 256.0f);
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
+        qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = 1.0f / sqrtf(row16_sum(qv) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 g = *reinterpret_cast<const float4 *>(w + (i * 16 + l16) * 4), be = *reinterpret_cast<const float4 *>(b + (i * 16 + l16) * 4);
+        r.c[i].x = (r.c[i].x - mean) * rstd * g.x + be.x;
+        r.c[i].y = (r.c[i].y - mean) * rstd * g.y + be.y;
+        r.c[i].z = (r.c[i].z - mean) * rstd * g.z + be.z;
+        r.c[i].w = (r.c[i].w - mean) * rstd * g.w + be.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Row block shared by QaN layers and standard layers, 16 tokens of one clip per workgroup:
 //   [QAN]  x = LN_prev(u_in rows t-1 .. t+16);  logits[t][n][j] = <Qc[n][j], x[t+j-1]>  (MFMA, K split over waves)
@@ -69,7 +110,7 @@ constexpr int TR = 16;
 constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
 constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
-template <bool QAN, bool CROSS = true>
+template <bool QAN, bool CROSS = true, int NP = 1>
 __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
                                                        const float *__restrict__ wk, const float *__restrict__ ln1_w,
@@ -78,8 +119,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        const float *__restrict__ bout, const float *__restrict__ ln2_w,
                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
                                                        int out_frame_major /* encoder output: row = t*B + b */,
-                                                       int u_np /* partial slabs of u_in (1 = plain) */, size_t u_pstride) {
+                                                       size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */) {
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
+    __shared__ __attribute__((aligned(1024))) float prm[7 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias (DMA targets)
     __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + NQ * TR * 4 + TR * 4 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
@@ -88,47 +130,95 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     float *coef = cw + NQ * TR * 4;               // [TR][4]
     float *Ps = coef + TR * 4;                    // [TR][PS]
 
-    const int b = blockIdx.y, t0 = blockIdx.x * TR, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
     const int rown = wave * 4 + kq;
     const float *Gb = CROSS ? G + (size_t)b * HM * D : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
     const float *VWTb = CROSS ? VWT + (size_t)b * D * HMP : nullptr;
+    IDF_RB_STAMP(0);
 
-    float4 gv[4][3];                              // folded-score operand fragments, prefetched one phase ahead
-    auto prefetch_g = [&]() {
-        if constexpr (!CROSS) return;
+    // ---- Operand fetch, organised for memory-level parallelism: everything is requested with clamped (always valid) addresses and
+    // no lane-divergent guard around a load, in three batches that each have whole phases of work to hide behind --
+    //   entry:            token rows (all slabs), the learned-query fragments, and by DMA the small shared vectors (LayerNorm
+    //                     gamma / beta x3, output bias) into LDS;
+    //   after barrier 1:  the folded-score fragments G (used two phases later);
+    //   after barrier 2:  the P.VW fragments (used four phases later).
+    // An earlier version fetched operands "one phase ahead" behind per-lane guards; the compiler parked a full s_waitcnt vmcnt(0)
+    // at every guard and the kernel made ~15 dependent round trips to L2 / Infinity Cache (tools/rowblock_probe.hip: 18 k of its
+    // 26 k cycles).  Rows / columns duplicated by the clamps are never consumed (logit columns >= NQ, score columns >= HM) or are
+    // zeroed below.
+    {
+        const float *srcs[7] = {lnp_w ? lnp_w : ln1_w, lnp_w ? lnp_b : ln1_b, ln1_w, ln1_b, CROSS ? ln2_w : ln1_w, CROSS ? ln2_b : ln1_b,
+                                CROSS ? bout : ln1_b};
+        const uint32_t prm_lds = idf_lds_addr(prm);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if ((i & 3) == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
+    }
+    Row16 ra, rb;
+    float4 q[4][3], gv[4][3], vw[HMP / 16][4];
+    float wk_n = 0.f, g0v[MEM];
+    const int ta = QAN ? t0 - 1 + rown : t0 + rown, tb = t0 + 15 + kq;
+    const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && kq < 2 && tb < T;
+    Row16Raw<NP> raw_a, raw_b;
+    if constexpr (QAN) {
+        if (wave == 0) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16 (wave-uniform branch)
+    }
+    raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, li, u_pstride);
+    if constexpr (QAN) {
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const int m = ct * 16 + li;
-                gv[ss][ct] = m < HM ? ld4(Gb + (size_t)m * D + 16 * (wave * 4 + ss) + 4 * kq) : zero4();
-            }
+            for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (min(li, NQ - 1) * 3 + j) * D + 16 * (wave * 4 + ss) + 4 * kq);
+        wk_n = wk[min(tid >> 4, NQ - 1)];
+    }
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int m = 0; m < MEM; ++m) g0v[m] = g0b[min(tid >> 4, H - 1) * MEM + m];
+    }
+    auto fetch_g = [&]() {
+        if constexpr (CROSS) {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) gv[ss][ct] = ld4(Gb + (size_t)min(ct * 16 + li, HM - 1) * D + 16 * (wave * 4 + ss) + 4 * kq);
+        }
     };
+    auto fetch_vw = [&]() {
+        if constexpr (CROSS) {
+#pragma unroll
+            for (int sidx = 0; sidx < HMP / 16; ++sidx)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vw[sidx][c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + 16 * sidx + 4 * kq);
+        }
+    };
+    // the DMA'd vectors must have landed for every wave before anyone reads them: each wave drains its own queue (its rows come
+    // with it -- they are needed now anyway), then one barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    raw_a.reduce(ra);
+    if constexpr (QAN) {
+        if (wave == 0) raw_b.reduce(rb);
+    }
+    const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
+                *P_bout = prm + 1536;
 
     if constexpr (QAN) {
         // rows t0-1 .. t0+14 by all groups, halo rows t0+15, t0+16 by the first two groups of wave 0
-        const int ta = t0 - 1 + rown, tb = t0 + 15 + kq;
-        const bool va = ta >= 0 && ta < T, vb = wave == 0 && kq < 2 && tb < T;
-        Row16 ra, rb;
-        row16_zero(ra);
-        row16_zero(rb);
-        if (va) row16_load_sum(ra, u_in + (rowbase + ta) * D, li, u_np, u_pstride);
-        if (vb) row16_load_sum(rb, u_in + (rowbase + tb) * D, li, u_np, u_pstride);
-        float4 q[4][3];
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) q[ss][j] = li < NQ ? ld4(Qc + (li * 3 + j) * D + 16 * (wave * 4 + ss) + 4 * kq) : zero4();
         if (lnp_w) {
-            if (va) ln_row16(ra, lnp_w, lnp_b, li);
-            if (vb) ln_row16(rb, lnp_w, lnp_b, li);
+            ln_row16_lds(ra, P_lnp_w, P_lnp_b, li);
+            if (wave == 0) ln_row16_lds(rb, P_lnp_w, P_lnp_b, li);
         }
+        if (!va) row16_zero(ra);
+        if (!vb) row16_zero(rb);
         row16_store(ra, xs + rown * RS, li);
         if (wave == 0 && kq < 2) row16_store(rb, xs + (16 + kq) * RS, li);
+        fetch_g();
         __syncthreads();
+        IDF_RB_STAMP(1);                                 // rows loaded (+ slab sum), LN_prev
         // logits: three 16x16 tiles (j = 0,1,2), each wave contracts a 64-wide slice of K
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -139,12 +229,13 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             for (int j = 0; j < 3; ++j) a[j] = ld4(xs + (li + j) * RS + koff);
             mma_rounds<3>(acc, a, q[ss]);
         }
-        prefetch_g();
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * 256 + (kq * 4 + r) * 16 + li] = acc[j][r];
+        fetch_vw();
         __syncthreads();
+        IDF_RB_STAMP(2);                                 // logits MFMA
         {
             const int t = tid & 15, n = tid >> 4;
             if (n < NQ) {
@@ -158,7 +249,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 if (tg + 1 >= T) l[2] = -FLT_MAX;
                 const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
                 const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
-                const float w = wk[n] / (e0 + e1 + e2);
+                const float w = wk_n / (e0 + e1 + e2);
                 float *o = cw + (n * TR + t) * 4;
                 o[0] = w * e0;
                 o[1] = w * e1;
@@ -175,6 +266,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             coef[tid] = c;
         }
         __syncthreads();
+        IDF_RB_STAMP(3);                                 // tap softmax + coefficient sums
         {   // u1 = x_t + sum_j c_j x_{t+j-1} ;  x1 = LN1(u1)
             Row16 xm, xc, xp;
             row16_load(xm, xs + rown * RS, li);
@@ -188,23 +280,22 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 xc.c[i].z = xc.c[i].z + (c0 * xm.c[i].z + c1 * xc.c[i].z + c2 * xp.c[i].z);
                 xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
             }
-            ln_row16(xc, ln1_w, ln1_b, li);
+            ln_row16_lds(xc, P_ln1_w, P_ln1_b, li);
             if constexpr (CROSS) row16_store(xc, x1s + rown * RS, li);
             else if (t0 + rown < T) row16_store(xc, x2_out + (out_frame_major ? (size_t)(t0 + rown) * gridDim.y + b : rowbase + t0 + rown) * D, li);
         }
     } else {
         const int t = t0 + rown;
-        Row16 ra;
-        row16_zero(ra);
-        if (t < T) row16_load_sum(ra, u_in + (rowbase + t) * D, li, u_np, u_pstride);
-        prefetch_g();
-        ln_row16(ra, ln1_w, ln1_b, li);
+        if (!va) row16_zero(ra);
+        fetch_g();
+        fetch_vw();
+        ln_row16_lds(ra, P_ln1_w, P_ln1_b, li);
         if constexpr (CROSS) row16_store(ra, x1s + rown * RS, li);
         else if (t < T) row16_store(ra, x2_out + (out_frame_major ? (size_t)t * gridDim.y + b : rowbase + t) * D, li);
     }
     if constexpr (!CROSS) return;                  // encoder layers: no memory to attend to, x1 is the FFN input
     __syncthreads();
-    float4 vw[HMP / 16][4];
+    IDF_RB_STAMP(4);                                     // stencil + LN1
     {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -213,17 +304,13 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             float4 a[3] = {av, av, av};
             mma_rounds<3>(acc, a, gv[ss]);
         }
-        // operand fragments of the next contraction (P.VW) fly while the softmax runs
-#pragma unroll
-        for (int s = 0; s < HMP / 16; ++s)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) vw[s][c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + 16 * s + 4 * kq);
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(wave * 3 + ct) * 256 + (kq * 4 + r) * 16 + li] = acc[ct][r];
     }
     __syncthreads();
+    IDF_RB_STAMP(5);                                     // folded scores MFMA
     {
         const int t = tid & 15, h = tid >> 4;
         if (h < H) {
@@ -232,7 +319,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             for (int m = 0; m < MEM; ++m) {
                 const int idx = h * MEM + m, ct = idx >> 4, cl = idx & 15, o = t * 16 + cl;
                 sc[m] = ((part[(0 * 3 + ct) * 256 + o] + part[(1 * 3 + ct) * 256 + o]) +
-                         (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0b[idx];
+                         (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0v[m];
                 mx = fmaxf(mx, sc[m]);
             }
             float sum = 0.f;
@@ -250,6 +337,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         }
     }
     __syncthreads();
+    IDF_RB_STAMP(6);                                     // head softmax
     {   // u2 = x1 + P.VW + b_out : wave w owns output columns [64w, 64w+64)
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -261,19 +349,20 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int col = (wave * 4 + c) * 16 + li;
-            const float bo = bout[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] += acc[c][r] + bo;
+            for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] += acc[c][r] + P_bout[col];
         }
     }
     __syncthreads();
+    IDF_RB_STAMP(7);                                     // P.VW MFMA
     {
         const int t = t0 + rown;
         Row16 r;
         row16_load(r, x1s + rown * RS, li);
-        ln_row16(r, ln2_w, ln2_b, li);
+        ln_row16_lds(r, P_ln2_w, P_ln2_b, li);
         if (t < T) row16_store(r, x2_out + (rowbase + t) * D, li);
     }
+    IDF_RB_STAMP(8);                                     // LN2 + store
 }
 
 // ------------------------------------------------------------------------------------
@@ -287,7 +376,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     extern __shared__ __attribute__((aligned(16))) float smx[];
     const int TP = (T + 15) & ~15, SS = TP + 4;
     float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + 32 * AS;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 32, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     for (int i = tid; i < TP * 16; i += 256) {
@@ -417,7 +506,6 @@ int attn_opt_in() {
 struct Ws {
     float *uA, *uB, *xn, *x2, *ctx, *qkv, *parts;
 };
-constexpr int NSL = IDF_FFN_SLICES;
 constexpr size_t WS_ROW_FLOATS = (size_t)(5 + 3 + NSL) * D;      // uA uB xn x2 ctx | qkv | FFN partial slabs
 Ws carve(void *ws, int64_t N) {
     float *p = reinterpret_cast<float *>(ws);
@@ -435,20 +523,26 @@ Ws carve(void *ws, int64_t N) {
 // tile configurations of the token GEMMs (A_PLAIN / A_LN call sites: the LDS-DMA pipeline of gemm.h).  The default
 // per call site was picked on MI355X with tools/gemm_probe.hip + tools/kbench.py (profiles/); interdiff_tune()
 // overrides it for A/B runs.  Config ids: BM x BN, waves, k-slices per workgroup (ks), chunk depth (kc).
-template <int APRO, int EPI>
+template <int APRO, int EPI, int NP = 1>
 void run_gemm(int cfg, hipStream_t s, const Args &g) {
     switch (cfg) {
-    case 1: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
-    case 2: launch_glds<32, 64, 2, 2, 1, 64, APRO, EPI>(s, g); break;
-    case 3: launch_glds<32, 64, 2, 2, 2, 64, APRO, EPI>(s, g); break;
-    case 4: launch_glds<64, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
-    case 5: launch_glds<32, 32, 2, 2, 1, 64, APRO, EPI>(s, g); break;
-    case 6: launch_glds<32, 32, 2, 2, 2, 64, APRO, EPI>(s, g); break;
-    case 7: launch_glds<64, 32, 2, 2, 1, 32, APRO, EPI>(s, g); break;
-    case 8: launch_glds<64, 32, 2, 2, 2, 64, APRO, EPI>(s, g); break;
-    case 9: launch<32, 64, 2, 2, 32, APRO, EPI>(s, g); break;               // register-staged double buffer
-    default: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI>(s, g); break;
+    case 1: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI, 3, NP>(s, g); break;
+    case 2: launch_glds<32, 64, 2, 2, 1, 64, APRO, EPI, 3, NP>(s, g); break;
+    case 3: launch_glds<32, 64, 2, 2, 2, 64, APRO, EPI, 3, NP>(s, g); break;
+    case 4: launch_glds<64, 64, 2, 2, 1, 32, APRO, EPI, 3, NP>(s, g); break;
+    case 5: launch_glds<32, 32, 2, 2, 1, 64, APRO, EPI, 3, NP>(s, g); break;
+    case 6: launch_glds<32, 32, 2, 2, 2, 64, APRO, EPI, 3, NP>(s, g); break;
+    case 7: launch_glds<64, 32, 2, 2, 1, 32, APRO, EPI, 3, NP>(s, g); break;
+    case 8: launch_glds<64, 32, 2, 2, 2, 64, APRO, EPI, 3, NP>(s, g); break;
+    case 9: launch<32, 64, 2, 2, 32, APRO, EPI, NP>(s, g); break;               // register-staged double buffer
+    default: launch_glds<32, 64, 2, 2, 1, 32, APRO, EPI, 3, NP>(s, g); break;
     }
+}
+// A_LN call sites: the layer input is one matrix (layer 0) or the previous layer's NSL partial slabs
+template <int EPI>
+void run_gemm_ln(int cfg, hipStream_t s, const Args &g, int np) {
+    if (np == NSL) run_gemm<A_LN, EPI, NSL>(cfg, s, g);
+    else run_gemm<A_LN, EPI, 1>(cfg, s, g);
 }
 constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 6;
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
@@ -552,20 +646,24 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->enc_layer[l];
         if (ly.is_qan) {
-            hipLaunchKernelGGL((rowblock_kernel<true, false>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, u_np, pstride);
+            if (u_np == NSL)
+                hipLaunchKernelGGL((rowblock_kernel<true, false, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride);
+            else
+                hipLaunchKernelGGL((rowblock_kernel<true, false, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride);
         } else {
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
-            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
-            run_gemm<A_LN, E_BIAS>(CFG_QKV, s, g);
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
+            run_gemm_ln<E_BIAS>(CFG_QKV, s, g, u_np);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             Args o{};
             o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
             o.N = D; o.resid = k.xn; o.T = T;
             run_gemm<A_PLAIN, E_RESID>(CFG_OUTPROJ, s, o);
             hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, 1, (size_t)0);
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, (size_t)0);
         }
         idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts);
         u_in = k.parts;
@@ -574,8 +672,8 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
         lnp_b = ar + ly.ln_b[1];
     }
     // cond[t][b][:] = LN2_last(u[b*T + t])
-    hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, u_np, pstride);
+    hipLaunchKernelGGL((rowblock_kernel<false, false, NSL>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, pstride);       // after 8 layers u_in is always the slabs
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -614,16 +712,21 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         const float *Gl = G + (size_t)l * B * HM * D, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
-            hipLaunchKernelGGL((rowblock_kernel<true>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T, 0, u_np, pstride);
+            if (u_np == NSL)
+                hipLaunchKernelGGL((rowblock_kernel<true, true, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride);
+            else
+                hipLaunchKernelGGL((rowblock_kernel<true, true, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride);
         } else {
             // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
-            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
+            g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
-            run_gemm<A_LN, E_BIAS>(pick(tune[IDF_TUNE_GEMM_QKV], CFG_QKV), s, g);
+            run_gemm_ln<E_BIAS>(pick(tune[IDF_TUNE_GEMM_QKV], CFG_QKV), s, g, u_np);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             // u1 = xn + ctx.Wo^T + bo
@@ -635,7 +738,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
             hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T, 0, 1, (size_t)0);
+                               ar + ly.ln_b[1], k.x2, T, 0, (size_t)0);
         }
         // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
         idf_prof_mark(IDF_K_FFN_FUSED, s);
@@ -648,9 +751,9 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
     {   // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
         Args g{};
         g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + w->out_w; g.bias = ar + w->out_b; g.C = x0;
-        g.ldc = C; g.M = N; g.N = C; g.T = T; g.a_np = u_np; g.a_pstride = pstride;
+        g.ldc = C; g.M = N; g.N = C; g.T = T; g.a_pstride = pstride;
         idf_prof_mark(IDF_K_GEMM_HEADS, s);
-        run_gemm<A_LN, E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g);
+        run_gemm_ln<E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g, u_np);
     }
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
             const float4 x = xres[it], bb = bres[it];
             v.x += x.x + bb.x; v.y += x.y + bb.y; v.z += x.z + bb.z; v.w += x.w + bb.w;
         }
-        *reinterpret_cast<float4 *>(out + (size_t)gr * D + c4) = v;
+        idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
     }
     stamp();
 }

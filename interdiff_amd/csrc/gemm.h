@@ -25,8 +25,7 @@ struct Args {
     const float *A;
     int lda, K;
     const float *lnw, *lnb;         // A_LN (null lnw: rows copied unnormalised)
-    int a_np;                       // A_LN: A is a_np (>= 1; 0 means 1) partial slabs a_pstride floats apart, summed on load (common.h ld4_sum)
-    size_t a_pstride;
+    size_t a_pstride;               // A_LN with NP > 1 (template parameter): A is NP partial slabs a_pstride floats apart, summed on load (common.h ld4_sum)
     const float *W;                 // [N][K]
     const float *bias;              // [N] or null
     float *C;
@@ -165,7 +164,7 @@ __device__ __forceinline__ void epilogue_rows(const Args &g, float *cs, const f3
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
+template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI, int NP = 1>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4_sum(g.A + (size_t)m * g.lda + lane * 4, g.a_np > 1 ? g.a_np : 1, g.a_pstride) : zero4();
+            float4 v = m < M ? ld4_sum<NP>(g.A + (size_t)m * g.lda + lane * 4, g.a_pstride) : zero4();
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);
@@ -331,10 +330,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     IDF_PROBE_STAMP(g, wg, 3);
 }
 
-template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI>
+template <int BM, int BN, int WM, int WN, int KC, int APRO, int EPI, int NP = 1>
 inline void launch(hipStream_t s, const Args &g) {
     dim3 grid((unsigned)(idf_cdiv(g.M, BM) * idf_cdiv(g.N, BN)));
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KC, APRO, EPI>), grid, dim3(WM * WN * 64), 0, s, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KC, APRO, EPI, NP>), grid, dim3(WM * WN * 64), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -363,7 +362,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef IDF_VMCNT_CASE
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3, int NP = 1>
 __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g) {
     constexpr int NWT = WM * WN, NW = NWT * KS;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4_sum(g.A + (size_t)m * g.lda + lane * 4, g.a_np > 1 ? g.a_np : 1, g.a_pstride) : zero4();
+            float4 v = m < M ? ld4_sum<NP>(g.A + (size_t)m * g.lda + lane * 4, g.a_pstride) : zero4();
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);
@@ -547,10 +546,10 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     IDF_PROBE_STAMP(g, wg, 3);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3>
+template <int BM, int BN, int WM, int WN, int KS, int KC, int APRO, int EPI, int NS = 3, int NP = 1>
 inline void launch_glds(hipStream_t s, const Args &g) {
     dim3 grid((unsigned)(idf_cdiv(g.M, BM) * idf_cdiv(g.N, BN)));
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI, NS>), grid, dim3(WM * WN * KS * 64), 0, s, g);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, KS, KC, APRO, EPI, NS, NP>), grid, dim3(WM * WN * KS * 64), 0, s, g);
 }
 
 }  // namespace idf_gemm

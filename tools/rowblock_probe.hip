@@ -1,0 +1,67 @@
+// Phase stamps of the row-block kernel inside a real denoiser forward (not product code):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -I interdiff_amd/csrc tools/rowblock_probe.hip -o build_tools/rowblock_probe
+// Builds csrc/denoiser.hip as ONE translation unit with IDF_RB_STAMP defined: thread 0 of every workgroup of the QaN row block
+// writes the shader clock at each phase boundary.  Weights / activations are random (timing only).  Prints the mean cycles per
+// phase over the workgroups of the LAST QaN launch of a forward at B x T.
+#include <hip/hip_runtime.h>
+__device__ long long g_rb_stamps[8192 * 16];
+#define IDF_RB_STAMP(i) do { if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
+#include "denoiser.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+bool g_idf_prof_on = false;
+void idf_prof_mark_slow(int, hipStream_t) {}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 100;
+    // a weights struct whose every offset points into one big random arena (layout irrelevant for timing)
+    const size_t arena_floats = (size_t)40 << 20;
+    std::vector<float> h(arena_floats);
+    srand(1);
+    for (auto &v : h) v = (rand() / (float)RAND_MAX - 0.5f) * 0.05f;
+    float *arena;
+    CK(hipMalloc(&arena, arena_floats * 4));
+    CK(hipMemcpy(arena, h.data(), arena_floats * 4, hipMemcpyHostToDevice));
+    idf_mdm_weights w{};
+    w.C = 144; w.n_steps = 1000; w.arena = arena; w.max_T = 512;
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return (int64_t)o; };
+    w.in_w = take(256 * 144); w.in_b = take(256); w.out_w = take(144 * 256); w.out_b = take(144);
+    w.temb_table = take(1000 * 256); w.pe = take(512 * 256);
+    for (int l = 0; l < 8; ++l) {
+        idf_mdm_layer &ly = w.layer[l];
+        ly.is_qan = (l >= 1);                 // the last launch is a QaN row block: its stamps are the ones read back
+        ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256);
+        ly.qc = take(30 * 256); ly.wk = take(64);
+        ly.ca_out_b = take(256);
+        ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
+        for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }
+    }
+    if (off > arena_floats) { printf("arena too small\n"); return 1; }
+    float *memctx, *x, *x0;
+    int64_t *ts;
+    void *ws;
+    const size_t wsb = interdiff_mdm_workspace_bytes(B, T);
+    CK(hipMalloc(&memctx, interdiff_mdm_memctx_floats(B) * 4));
+    CK(hipMemcpy(memctx, h.data(), interdiff_mdm_memctx_floats(B) * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&x, (size_t)B * 144 * T * 4)); CK(hipMalloc(&x0, (size_t)B * 144 * T * 4)); CK(hipMalloc(&ts, B * 8)); CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(x, h.data(), (size_t)B * 144 * T * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(ts, 0, B * 8));
+    for (int i = 0; i < 5; ++i)
+        if (interdiff_mdm_forward(&w, memctx, x, ts, B, T, x0, ws, wsb, nullptr) != 0) { printf("forward failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    const int nwg = ((T + 15) / 16) * B;
+    std::vector<long long> st((size_t)nwg * 16);
+    CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_rb_stamps), st.size() * 8));
+    const char *names[9] = {"", "rows + slab sum + LN_prev (+ Qc requested)", "logits MFMA (waits Qc)", "tap softmax + coefficients", "stencil + LN1",
+                            "folded scores MFMA (waits G)", "head softmax", "P.VW MFMA (waits VW)", "LN2 + store"};
+    double acc[9] = {0}, tot = 0;
+    for (int wgi = 0; wgi < nwg; ++wgi)
+        for (int i = 1; i < 9; ++i) acc[i] += (double)(st[(size_t)wgi * 16 + i] - st[(size_t)wgi * 16 + i - 1]);
+    printf("QaN row block (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", B, T, nwg);
+    for (int i = 1; i < 9; ++i) { printf("  %-46s %8.0f\n", names[i], acc[i] / nwg); tot += acc[i] / nwg; }
+    printf("  total %.0f\n", tot);
+    return 0;
+}

@@ -55,10 +55,13 @@ __device__ __forceinline__ const float *idf_uniform_ptr(const float *p) {
 }
 // global address = gbase (SGPR pair) + voff_bytes (per lane)
 __device__ __forceinline__ void idf_dma16_s(const float *gbase, uint32_t voff_bytes, uint32_t lds_base) {
+    gbase = idf_uniform_ptr(gbase);                                      // both are wave-uniform by contract: pin them to SGPRs
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(gbase), "s"(lds_base) : "memory", "m0");
 }
 // global address = gptr (per lane, 64-bit)
 __device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base) {
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory", "m0");
 }
 

@@ -15,6 +15,11 @@
 #include "rot_math.h"
 #include <algorithm>
 
+// phase stamps exist only in tools/smpl_probe.hip (which defines the macro before including this file)
+#ifndef IDF_SMPL_STAMP
+#define IDF_SMPL_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int MAXJ = 64;
@@ -81,30 +86,77 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const idf_smpl_model m, c
 }
 
 constexpr int FT = 32, VT = 64, NTC = 3 * VT;          // frames / vertices / coordinates per workgroup
-constexpr int FM = FT / 16;                             // 16-frame MFMA tiles per workgroup (each basis fragment is reused FM times)
-constexpr int AQS = FT * 4 + 4;                         // padded quad stride of the feature image
+constexpr int BT = 256;                                 // threads (4 waves x 48 coordinates); two workgroups share a CU (one's skinning phase beside the other's MFMA loop)
+constexpr int FM = FT / 16;                             // 16-frame MFMA tiles per wave (each basis fragment feeds FM*4 MFMAs)
 constexpr int STS = NTC + 1;                            // stage row stride
+constexpr int SF = 16;                                  // frames per skinning sub-step (their joint transforms are staged in LDS)
+constexpr int TBF = 10, TBV = 4;                        // workgroup order: blocks of TBF frame tiles x TBV vertex tiles (L2 working set ~2.9 MiB)
 
-__global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_model m, const float *__restrict__ feat,
+// One workgroup = 32 frames x 64 vertices.  Phase 1: the blend-shape GEMM feat[32,KB] x blend[KB,192] on the fp32 MFMA; the feature
+// tile sits in LDS, each wave streams the basis rows of its 48 output coordinates straight from global memory (three register sets,
+// two k-groups in flight) and uses every fragment for both 16-frame tiles.  Phase 2: v_posed leaves the accumulators through LDS; for 16 frames at a time the 52 joint transforms of each frame are
+// staged in LDS too (one contiguous 39-KiB copy instead of 4 x 3 scattered 16-byte gathers per (frame, vertex) from global memory:
+// 2.1 GB -> 0.43 GB per call), every thread keeps its vertex's <= S skinning weights / bones in registers across all 32 frames,
+// and the skinned vertices go back through LDS so that a frame's 64 vertices leave as one 768-byte run of 16-byte stores.
+template <int NG>                                       // k-groups of 16: KB = 16 NG, a compile-time constant so that the k-loop unrolls
+__global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_model m, const float *__restrict__ feat,
                                                               const float *__restrict__ A, const float *__restrict__ trans,
                                                               int64_t N, float *__restrict__ verts,
                                                               float *__restrict__ v_posed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int KB = m.KB, V = m.V, J = m.J, S = m.S, nq = KB / 4;
+    constexpr int KB = 16 * NG, nq = KB / 4;
+    const int V = m.V, J = m.J, S = m.S;
     float *As = sm, *stage = sm;                       // the stage image reuses the feature image once the contraction is done
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    // frame tiles on blockIdx.x (fast) so that concurrently resident workgroups share one slice of the
-    // blend basis in L2; vertex tiles on blockIdx.y
-    const int64_t f0 = (int64_t)blockIdx.x * FT;
-    const int v0 = blockIdx.y * VT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, fh = tid >> 8, li = lane & 15, kq = lane >> 4;       // fh = 0 (one frame-tile set per workgroup)
+    // Workgroup order, for L2 locality (speed only).  (1) XCD-affine: workgroup id runs on XCD id % 8, each with its own 4-MiB L2,
+    // so the logical index is permuted to give one XCD CONSECUTIVE logical workgroups.  (2) The logical index walks blocks of
+    // TBF frame tiles x TBV vertex tiles: the ~64 workgroups an XCD runs at a time then share TBV basis slices (4 x 368 KiB) and
+    // TBF frame tiles' features + joint transforms (10 x 141 KiB) -- 2.9 MiB, resident -- and every operand reaches the XCD from
+    // the Infinity Cache about once per block.  (Frame-tile-major order cycled each XCD through all 7 MiB of features + transforms
+    // for every vertex tile: an LRU-hostile sweep that missed L2 on nearly every read; round 1 additionally spread each basis
+    // slice over all eight L2s: 657 MB of fabric reads for a 40-MB basis.)
+    const int nft = (int)((N + FT - 1) / FT), nvt = (V + VT - 1) / VT, nfb = (nft + TBF - 1) / TBF;
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int blk = lid / (TBF * TBV), wi = lid - blk * (TBF * TBV);
+    const int ftile = (blk % nfb) * TBF + wi % TBF, vtile = (blk / nfb) * TBV + wi / TBF;
+    if (ftile >= nft || vtile >= nvt) return;          // ragged edge blocks (workgroup-uniform)
+    const int64_t f0 = (int64_t)ftile * FT;
+    const int v0 = vtile * VT;
+    IDF_SMPL_STAMP(0);
 
-    for (int idx = tid; idx < FT * nq; idx += 256) {
-        const int row = idx / nq, q = idx - row * nq;
-        const int64_t n = f0 + row;
-        const float4 v = n < N ? *reinterpret_cast<const float4 *>(feat + n * KB + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(As + q * AQS + row * 4) = v;
+    // feature tile -> LDS by asm DMA (common.h), row-major [FT][KB]: LDS cell p = 64 i + lane of instruction i is 16-byte position
+    // p % nq of row p / nq and receives source chunk pos ^ ((row >> 1) & 7) -- the XOR keeps the MFMA A-fragment reads (16 rows x
+    // one 16-B chunk) free of bank conflicts although the row stride (KB * 4 bytes, KB % 32 == 0) is a multiple of 128 bytes.
+    // All of a wave's instructions are in flight together; rows past the batch end re-read the last frame (never stored).
+    {
+        const uint32_t as_lds = idf_lds_addr(As);
+        const int ncell = FT * nq;
+        for (int i = wave; i * 64 < ncell; i += BT / 64) {
+            const int p = min(i * 64 + lane, ncell - 1), row = p / nq, pos = p - row * nq;
+            idf_dma16_v(feat + (size_t)min(f0 + row, N - 1) * KB + ((pos ^ ((row >> 1) & 7)) << 2), as_lds + (uint32_t)(i * 1024));
+        }
     }
-    __syncthreads();
+    // this thread's vertex (fixed over all frames of the tile): skinning weights and bone offsets into a frame's transform block
+    const int vl = tid & 63, vme = v0 + vl;
+    float sw[4];
+    int so[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // clamped addresses, selects afterwards: eight independent loads, one trip to memory
+        const size_t e = (size_t)min(vme, V - 1) * S + min(k, S - 1);
+        sw[k] = m.skin_w[e];
+        so[k] = m.skin_idx[e] * 12;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = k < S && vme < V;
+        sw[k] = ok ? sw[k] : 0.f;
+        so[k] = ok ? so[k] : 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA (and the loads above) have landed ...
+    __syncthreads();                                   // ... and so has everybody else's
+    IDF_SMPL_STAMP(1);                                 // feature tile in LDS
 
     const float *brow[3];
     bool bval[3];
@@ -119,20 +171,23 @@ __global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_mod
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ng = KB / 16;
     // the basis fragments come straight from global memory (each is used by this wave only): three register sets keep the
-    // loads of groups g+1 and g+2 in flight behind the 8*FM*3 MFMAs of group g
-    float4 b0[3], b1[3], b2[3];
+    // loads of groups g+1 and g+2 in flight behind the 4*FM*3 MFMAs of group g
+    // the basis fragments come straight from global memory (each is used by this wave only) through a ring of PD+1 register sets:
+    // the loads of groups g+1 .. g+PD are in flight behind the MFMAs of group g.  The loop is fully unrolled (NG is a template
+    // parameter): in a rolled loop the compiler's wait-count bookkeeping gives up at the back edge and drains the whole queue
+    // (s_waitcnt vmcnt(0)) every iteration, whatever the prefetch depth.
+    constexpr int PD = 3;
+    float4 bq[PD + 1][3];
     auto ldg = [&](float4 (&dst)[3], int gi) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            dst[t] = (bval[t] && gi < ng) ? *reinterpret_cast<const float4 *>(brow[t] + gi * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < 3; ++t) dst[t] = *reinterpret_cast<const float4 *>(brow[t] + gi * 16);
     };
     auto mac = [&](const float4 (&bc)[3], int gi) {
-        if (gi >= ng) return;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const float4 a = *reinterpret_cast<const float4 *>(As + (gi * 4 + kq) * AQS + (i * 16 + li) * 4);
+            const int row = (fh * FM + i) * 16 + li;
+            const float4 a = *reinterpret_cast<const float4 *>(As + row * KB + (((gi * 4 + kq) ^ ((row >> 1) & 7)) << 2));
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc[t].x, acc[i][t], 0, 0, 0);
 #pragma unroll
@@ -143,50 +198,83 @@ __global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_mod
             for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bc[t].w, acc[i][t], 0, 0, 0);
         }
     };
-    ldg(b0, 0);
-    ldg(b1, 1);
-    for (int g = 0; g < ng; g += 3) {
-        ldg(b2, g + 2);
-        mac(b0, g);
-        ldg(b0, g + 3);
-        mac(b1, g + 1);
-        ldg(b1, g + 4);
-        mac(b2, g + 2);
+#pragma unroll
+    for (int g = 0; g < PD && g < NG; ++g) ldg(bq[g], g);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + PD < NG) ldg(bq[(g + PD) % (PD + 1)], g + PD);
+        __builtin_amdgcn_sched_barrier(0);             // keep the prefetch HERE: left alone, the scheduler sinks every load to just before its use
+        mac(bq[g % (PD + 1)], g);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                   // every wave is done reading As
+    IDF_SMPL_STAMP(2);                                 // blend-shape GEMM
+    // rows of the basis past 3V (the last vertex tile) were read from row 0: their columns are never stored
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(i * 16 + kq * 4 + r) * STS + (wave * 3 + t) * 16 + li] = acc[i][t][r];
-    __syncthreads();
+            for (int r = 0; r < 4; ++r) stage[((fh * FM + i) * 16 + kq * 4 + r) * STS + (wave * 3 + t) * 16 + li] = acc[i][t][r];
 
+    float *Asub = sm + ((FT * STS + 255) & ~255);      // [SF][J*12] joint transforms of the current 16 frames (1-KiB aligned: DMA target)
+    float *ost = Asub + ((SF * J * 12 + 3) & ~3);      // [SF][NTC] skinned vertices of the current 16 frames
+    float *trs = ost + SF * NTC;                       // [FT][3] translations of the tile's frames
+    const int arow = J * 12;
+    if (tid < FT * 3) trs[tid] = trans[min(f0 + tid / 3, N - 1) * 3 + tid % 3];     // consumed after the barriers below
+    for (int sub = 0; sub < FT / SF; ++sub) {
+        const int64_t fs = f0 + sub * SF;
+        if (fs >= N) break;                            // (workgroup-uniform) nothing left to skin: the copy below must not run past A's slack
+        __syncthreads();                               // stage complete (first pass) / previous sub-step's Asub and ost consumed
+        // A is [N][J][12] contiguous: the sub-tile is one run of SF*J*12 floats = 39 x 1 KiB -> a linear DMA copy.  The workspace
+        // carries one sub-tile of slack behind A (interdiff_smpl_workspace_bytes), so a sub-tile that runs past the last frame
+        // stays in bounds (those frames are never stored).
+        {
+            const uint32_t asub_lds = idf_lds_addr(Asub);
+            const float *src = idf_uniform_ptr(A + (size_t)fs * arow);
+            for (int i = wave; i * 256 < SF * arow; i += BT / 64) idf_dma16_s(src + (size_t)i * 256, (uint32_t)(lane << 4), asub_lds + (uint32_t)(i * 1024));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        IDF_SMPL_STAMP(3 + 3 * sub);                   // joint transforms staged
 #pragma unroll
-    for (int k = 0; k < FT * VT / 256; ++k) {
-        const int p = tid + 256 * k, f = p / VT, vl = p - f * VT;
-        const int64_t n = f0 + f;
-        const int v = v0 + vl;
-        if (n >= N || v >= V) continue;
-        const float px = stage[f * STS + 3 * vl], py = stage[f * STS + 3 * vl + 1], pz = stage[f * STS + 3 * vl + 2];
-        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0;
-        const float *An = A + (size_t)n * J * 12;
-        for (int s = 0; s < S; ++s) {
-            const float w = m.skin_w[(size_t)v * S + s];
-            const float4 *a = reinterpret_cast<const float4 *>(An + m.skin_idx[(size_t)v * S + s] * 12);
-            const float4 a0 = a[0], a1 = a[1], a2 = a[2];
-            t0.x += w * a0.x; t0.y += w * a0.y; t0.z += w * a0.z; t0.w += w * a0.w;
-            t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
-            t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
+        for (int k = 0; k < SF * VT / BT; ++k) {
+            const int f = (tid >> 6) + (BT / 64) * k, fr = sub * SF + f;
+            const float px = stage[fr * STS + 3 * vl], py = stage[fr * STS + 3 * vl + 1], pz = stage[fr * STS + 3 * vl + 2];
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0;
+            const float *Af = Asub + f * arow;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < S) {
+                    const float w = sw[b];
+                    const float4 *a = reinterpret_cast<const float4 *>(Af + so[b]);
+                    const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+                    // explicit fmaf everywhere below: with implicit contraction the unrolled copies of this loop body were compiled
+                    // to DIFFERENT fma / mul+add mixes, so a frame's vertices depended (by an ulp) on its position in the batch
+                    t0.x = fmaf(w, a0.x, t0.x); t0.y = fmaf(w, a0.y, t0.y); t0.z = fmaf(w, a0.z, t0.z); t0.w = fmaf(w, a0.w, t0.w);
+                    t1.x = fmaf(w, a1.x, t1.x); t1.y = fmaf(w, a1.y, t1.y); t1.z = fmaf(w, a1.z, t1.z); t1.w = fmaf(w, a1.w, t1.w);
+                    t2.x = fmaf(w, a2.x, t2.x); t2.y = fmaf(w, a2.y, t2.y); t2.z = fmaf(w, a2.z, t2.z); t2.w = fmaf(w, a2.w, t2.w);
+                }
+            }
+            float *o = ost + f * NTC + 3 * vl;
+            o[0] = fmaf(t0.x, px, fmaf(t0.y, py, fmaf(t0.z, pz, t0.w))) + trs[fr * 3 + 0];
+            o[1] = fmaf(t1.x, px, fmaf(t1.y, py, fmaf(t1.z, pz, t1.w))) + trs[fr * 3 + 1];
+            o[2] = fmaf(t2.x, px, fmaf(t2.y, py, fmaf(t2.z, pz, t2.w))) + trs[fr * 3 + 2];
         }
-        float *o = verts + ((size_t)n * V + v) * 3;
-        o[0] = (t0.x * px + t0.y * py + t0.z * pz + t0.w) + trans[n * 3 + 0];
-        o[1] = (t1.x * px + t1.y * py + t1.z * pz + t1.w) + trans[n * 3 + 1];
-        o[2] = (t2.x * px + t2.y * py + t2.z * pz + t2.w) + trans[n * 3 + 2];
-        if (v_posed) {
-            float *q = v_posed + ((size_t)n * V + v) * 3;
-            q[0] = px; q[1] = py; q[2] = pz;
+        __syncthreads();
+        IDF_SMPL_STAMP(4 + 3 * sub);                   // skinning
+        // a frame's 64 vertices are 192 consecutive floats in verts: 16-byte stores (the row start 3*(n*V+v0) is a multiple of 4
+        // floats only when n*V*3 is: handle the general case with 4-byte stores at the tile edge ... V*3 = 20670 is even but not
+        // a multiple of 4, so rows are only 8-byte aligned: use 8-byte stores)
+        const int nvalid = min(VT, V - v0) * 3;
+        for (int idx = tid; idx < SF * (NTC / 2); idx += BT) {
+            const int f = idx / (NTC / 2), c2 = (idx - f * (NTC / 2)) * 2;
+            if (fs + f >= N || c2 >= nvalid) continue;
+            const size_t go = ((size_t)(fs + f) * V + v0) * 3 + c2;
+            *reinterpret_cast<float2 *>(verts + go) = *reinterpret_cast<const float2 *>(ost + f * NTC + c2);
+            if (v_posed) *reinterpret_cast<float2 *>(v_posed + go) = make_float2(stage[(sub * SF + f) * STS + c2], stage[(sub * SF + f) * STS + c2 + 1]);
         }
+        IDF_SMPL_STAMP(5 + 3 * sub);                   // stores issued
     }
 }
 
@@ -194,7 +282,8 @@ __global__ __launch_bounds__(256) void smpl_blend_skin_kernel(const idf_smpl_mod
 
 extern "C" size_t interdiff_smpl_workspace_bytes(const idf_smpl_model *m, int64_t N) {
     if (!m || N < 0) return 0;
-    return idf_align((size_t)N * m->KB * sizeof(float)) + idf_align((size_t)N * m->J * 12 * sizeof(float));
+    // feature rows [N][KB] | joint transforms [N][J][12] + one 16-frame sub-tile of slack (the skinning phase copies whole sub-tiles)
+    return idf_align((size_t)N * m->KB * sizeof(float)) + idf_align(((size_t)N + SF) * m->J * 12 * sizeof(float));
 }
 
 extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose, const float *betas, const float *trans,
@@ -209,12 +298,14 @@ extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose
     float *A = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * m->KB * sizeof(float)));
     idf_prof_mark(IDF_K_SMPL_POSE, s);
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((unsigned)N), dim3(64), 0, s, *m, pose, betas, trans, feat, A, jtr);
-    const size_t lds = std::max((size_t)(m->KB / 4) * AQS, (size_t)FT * STS) * sizeof(float);
-    if (lds > 150 * 1024) return IDF_E_INVAL;
+    const size_t lds = std::max((size_t)FT * m->KB, (size_t)((FT * STS + 255) & ~255) + ((SF * m->J * 12 + 3) & ~3) + (size_t)SF * NTC + FT * 3) * sizeof(float);
+    // KB % 32: the swizzled feature image; J*12*SF % 256: the joint transforms of 16 frames are whole KiB; <= 4 bones per vertex
+    if (lds > 150 * 1024 || m->KB % 32 != 0 || (SF * m->J * 12) % 256 != 0 || (m->V * 3) % 2 != 0 || m->S > 4) return IDF_E_INVAL;     // <= 4 bones per vertex (SMPL / SMPL-H skinning)
+    if (m->KB != 480) return IDF_E_INVAL;              // SMPL-H: 9 * 51 pose + 10 shape + 1 template = 470 -> 480 (the only basis width built)
     static std::atomic<uint64_t> lds_ok{0};
-    if (lds > 64 * 1024 && idf_opt_in_lds(reinterpret_cast<const void *>(smpl_blend_skin_kernel), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+    if (lds > 64 * 1024 && idf_opt_in_lds(reinterpret_cast<const void *>(smpl_blend_skin_kernel<30>), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     idf_prof_mark(IDF_K_SMPL_BLEND_SKIN, s);
-    hipLaunchKernelGGL(smpl_blend_skin_kernel, dim3((unsigned)idf_cdiv(N, FT), (unsigned)idf_cdiv(m->V, VT)), dim3(256), lds, s, *m,
+    hipLaunchKernelGGL(smpl_blend_skin_kernel<30>, dim3((unsigned)(idf_cdiv(idf_cdiv(N, FT), TBF) * idf_cdiv(idf_cdiv(m->V, VT), TBV) * TBF * TBV)), dim3(BT), lds, s, *m,
                        feat, A, trans, N, verts, v_posed);
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();

@@ -169,7 +169,11 @@ size_t interdiff_mdm_memctx_floats(int32_t B);
 size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T);
 int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B,
                                  float *memctx, void *ws, size_t ws_bytes, void *stream);
-/* x [B,1,C,T], ts int64 [B] -> x0 [B,1,C,T] */
+/* x [B,1,C,T], ts int64 [B] -> x0 [B,1,C,T].
+ * Size limits (IDF_E_INVAL beyond them): T <= 208 -- the temporal self-attention of the two standard layers parks K and V of one
+ * (clip, head) in one CU's LDS (2 x T x 68 floats + the score tile = 149 KiB at T = 208); T <= max_T of the packed positional table;
+ * C <= 256 and C % 4 == 0.  The reference itself is bounded only by PositionalEncoding(max_len=5000) (model/layers.py:11); its
+ * datasets use T = 35 (eval_smpl_short.py:376-377) and BASELINE.json T = 100.  B is unbounded (clips are independent). */
 int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x,
                           const int64_t *ts, int32_t B, int32_t T, float *x0,
                           void *ws, size_t ws_bytes, void *stream);

@@ -229,9 +229,9 @@ def test_full_1000_step_loop_golden(mdm, smpl):
                                denoised_fn=corr, dump_steps=fx.LOOP_DUMPS, step_noise=lambda i, x: stream.next_like(x).to(DEV))
     worst = 0.0
     for s, d in zip(fx.LOOP_DUMPS, dumps):
-        worst = max(worst, close(d, z['dump_%d' % s], 5e-4, 'loop index %d' % s))
+        worst = max(worst, close(d, z['dump_%d' % s], 1e-4, 'loop index %d' % s))
     print('full-loop worst rel err %.2e' % worst)
-    fx.record_parity('loop_T12_B2_P64_1000steps_vs_reference', worst_rel_err=worst, asserted=5e-4, dumps=list(fx.LOOP_DUMPS))
+    fx.record_parity('loop_T12_B2_P64_1000steps_vs_reference', worst_rel_err=worst, asserted=1e-4, dumps=list(fx.LOOP_DUMPS))
 
 
 def _pick(contact):
@@ -296,6 +296,16 @@ def test_full_size_end_to_end_golden(mdm, smpl):
                                   R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3))),
                markers=rel(verts[:, :, MARKERS67], z['markers']), joints=rel(jtr, z['jtr']))
     rep['final_outputs_rel_err_vs_reference'] = fin
+    # the same post-processing applied to the REFERENCE's own final sample: separates the error of the conversion / body-model
+    # kernels from the sensitivity of rot6d -> axis-angle -> SMPL to the 6e-5 that the two samples differ by (with a random-init
+    # denoiser some joints' 6-D vectors are close to parallel, where Gram-Schmidt amplifies any input difference)
+    o2, b2, v2, j2, _ = ev.finalize(torch.from_numpy(z['dump_999']).to(DEV), bd, smpl, past)
+    fin_same = dict(obj_translation=rel(o2[..., 3:], z['obj'][..., 3:]),
+                    obj_rotation=rel(R.axis_angle_to_matrix(o2[..., :3].cpu()), R.axis_angle_to_matrix(torch.from_numpy(z['obj'][..., :3]))),
+                    body_rotations=rel(R.axis_angle_to_matrix(b2[..., :66].reshape(T, B, 22, 3).cpu()),
+                                       R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3))),
+                    markers=rel(v2[:, :, MARKERS67], z['markers']), joints=rel(j2, z['jtr']))
+    rep['final_outputs_rel_err_on_the_reference_sample'] = fin_same
     obj_gt, jtr_gt, body_gt, faces = ev.get_gt(bd, smpl)
     m = ev.Metrics(corr)(obj[past:], jtr[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces, bd['obj_points'])
     rep['metrics_rel_err_vs_reference'] = {k: rel(m[k], z['m_' + k]) for k in m}
@@ -303,16 +313,17 @@ def test_full_size_end_to_end_golden(mdm, smpl):
     rep['metrics_mean_reference'] = {k: float(z['m_' + k].mean()) for k in m}
     fx.record_parity('full_size_end_to_end', **rep)
     print(rep)
-    # Gates.  Before the first decision acts (loop index 0 .. 499) both runs are smooth functions of the same inputs: north_star's 1e-4.
-    for s_ in ('0', '499'):
-        assert per_dump[s_]['hip_vs_reference'] <= 1e-4, (s_, per_dump[s_])
-    # Afterwards a flipped decision moves a clip by far more than rounding, so the bound is the yardstick itself: the HIP run may be
-    # at most as far from the reference as twice what separates the reference's own fp32 run from exact (fp64) arithmetic, and
-    # never looser than 5e-4 where that yardstick is small.
+    # Gates: north_star's 1e-4 on the sampler state at EVERY dump, the final sample included (measured on MI355X: <= 1.2e-6 up to
+    # loop index 949, 6.1e-5 after the last correction, where the reference's own fp32 run is 2.1e-5 from the fp64 twin), no decision
+    # of the hook may differ, the conversion / body-model kernels within 1e-4 on identical input, the metrics within 2e-4
+    # (penetration ratio: a count of sign decisions over 2048 x 90 points per clip, 2e-3).
     for s_, e in per_dump.items():
-        assert e['hip_vs_reference'] <= max(5e-4, 2.0 * e['reference_vs_fp64']), (s_, e)
+        assert e['hip_vs_reference'] <= 1e-4, (s_, e)
+    assert rep['condition_flips_vs_reference'] == 0 and rep['contact_marker_flips_vs_reference'] == 0
+    for k, e in fin_same.items():
+        assert e <= 1e-4, (k, e)
     for k, e in rep['metrics_rel_err_vs_reference'].items():
-        assert e <= (2e-2 if k == 'penetrate' else max(5e-4, 2.0 * per_dump['999']['reference_vs_fp64'])), (k, e)
+        assert e <= (2e-3 if k == 'penetrate' else 2e-4), (k, e)
 
 
 def test_evaluate_batch_and_sample_once(mdm, smpl):
@@ -586,11 +597,11 @@ def test_long_horizon_rollout(mdm, smpl):
         if n in ('obj', 'body'):                         # axis-angle blocks: compare the rotations, not their representation
             nr = 3 if n == 'obj' else 66
             errs[n + '_rot'] = close(R.axis_angle_to_matrix(a[..., :nr].reshape(*a.shape[:2], -1, 3).cpu()),
-                                     R.axis_angle_to_matrix(b[..., :nr].reshape(*b.shape[:2], -1, 3)), 5e-4, 'long-horizon %s rotations' % n)
-            errs[n + '_rest'] = close(a[..., nr:], b[..., nr:], 5e-4, 'long-horizon %s' % n)
+                                     R.axis_angle_to_matrix(b[..., :nr].reshape(*b.shape[:2], -1, 3)), 1e-4, 'long-horizon %s rotations' % n)
+            errs[n + '_rest'] = close(a[..., nr:], b[..., nr:], 1e-4, 'long-horizon %s' % n)
         else:
-            errs[n] = close(a, b, 5e-4, 'long-horizon %s vs oracle/long_horizon.py' % n)
-    fx.record_parity('long_horizon_K2_T14_B2_vs_oracle', asserted=5e-4, **errs)
+            errs[n] = close(a, b, 1e-4, 'long-horizon %s vs oracle/long_horizon.py' % n)
+    fx.record_parity('long_horizon_K2_T14_B2_vs_oracle', asserted=1e-4, **errs)
 
 
 def test_real_behave_clips_end_to_end(mdm, smpl):

@@ -29,7 +29,7 @@ class MdmLayer(C.Structure):
                 ('qc', i64), ('wk', i64),
                 ('ca_q_w', i64), ('ca_q_b', i64), ('ca_kv_w', i64), ('ca_kv_b', i64),
                 ('ca_out_w', i64), ('ca_out_b', i64),
-                ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64), ('ffn_b1p', i64),
+                ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64), ('ffn_b1p', i64), ('sa_in_pack', i64),
                 ('ln_w', i64 * 3), ('ln_b', i64 * 3)]
 
 

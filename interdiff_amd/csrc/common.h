@@ -72,7 +72,10 @@ __device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base
 // reads back.
 __device__ __forceinline__ void idf_store16_wt(float *p, const float4 v) {
     const f32x4 t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+    // s_nop: a store of more than 64 bits reads its data registers AFTER issue -- a VALU write to them needs wait states in
+    // between.  The compiler's hazard recognizer pads its own stores; it cannot see into this asm (tools/lnlin_probe.hip caught
+    // the next loop iteration's index landing in .x of ~0.1 % of the stores).
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it

@@ -544,8 +544,14 @@ void run_gemm_ln(int cfg, hipStream_t s, const Args &g, int np) {
     if (np == NSL) run_gemm<A_LN, EPI, NSL>(cfg, s, g);
     else run_gemm<A_LN, EPI, 1>(cfg, s, g);
 }
-constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_QKV = 9, CFG_HEADS = 6;
+constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_HEADS = 6;          // (the QKV projection has its own kernel: run_qkv)
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
+// QKV projection: the LayerNorm+linear kernel of ffn.h (tune 0) or, for A/B runs, one of the generic GEMM configurations
+void run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np) {
+    if (tuned) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return; }
+    if (np == NSL) idf_ffn::launch_ln_linear<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out);
+    else idf_ffn::launch_ln_linear<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out);
+}
 
 }  // namespace
 
@@ -656,7 +662,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
-            run_gemm_ln<E_BIAS>(CFG_QKV, s, g, u_np);
+            run_qkv(0, s, g, ar + ly.sa_in_pack, u_np);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             Args o{};
             o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
@@ -726,7 +732,7 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
-            run_gemm_ln<E_BIAS>(pick(tune[IDF_TUNE_GEMM_QKV], CFG_QKV), s, g, u_np);
+            run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             // u1 = xn + ctx.Wo^T + bo

@@ -292,6 +292,132 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
     stamp();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm + linear for the QKV projection of the two standard layers, on the same skeleton as phase 1 above:
+//     C[M, N] = LN(sum of NP slabs of A)[M,256] . W[N,256]^T + bias            (nn.MultiheadAttention in_proj after the previous
+//                                                                               layer's norm3; torch TransformerDecoderLayer)
+// grid = ceil(M/32) x (N / 192) workgroups of 512 threads: a workgroup normalises its 32 rows ONCE (wave w: rows w, w+8, w+16, w+24;
+// the slab sum of common.h ld4_sum, all loads in flight together), parks them in the swizzled LDS image and streams its 192 weight
+// rows as 16 pre-packed k-group chunks ([192 rows][16 k] = 12 KiB, two per ring slot, two slots ahead).  The generic GEMM it
+// replaces tiled N by 64, so every row block was fetched (five slabs) and normalised by TWELVE workgroups instead of four.
+// The slice-0 workgroups also write the normalised rows (the residual of the attention block) to xn_out.
+constexpr int LCT = 12, LHS = LCT * 16;                 // column tiles / columns per workgroup
+constexpr int LW1C = LHS * 16;                          // floats per k-group chunk
+constexpr int LPSLOT = 2 * LW1C;                        // floats per ring slot (24 KiB)
+static_assert(2 * LW1C / 256 == 3 * NW, "three DMA instructions per wave per pair");
+
+template <int NP>
+__global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__ A, size_t a_pstride, const float *__restrict__ lnw,
+                                                        const float *__restrict__ lnb, int M, const float *__restrict__ pack,
+                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                        float *__restrict__ xn_out) {
+    __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * LPSLOT];
+    float *Xs = smem, *ring = smem + XS;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsl = gridDim.y, mt = blockIdx.x, sl = blockIdx.y, m0 = mt * BM, n0 = sl * LHS;
+    const float *stream = idf_uniform_ptr(pack + (size_t)sl * (16 * LW1C));
+    const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
+    const int key = (4 - (li >> 2)) & 3;
+    (void)nsl;
+    auto issue_pair = [&](int P) {                        // pair P = chunks 2P, 2P+1: 24 KiB contiguous in the stream and in slot P % 3
+        if (P >= 8) return;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            idf_dma16_s(stream, vsrc + (uint32_t)(P * 2 * LW1C * 4) + 8192u * j, sdst + (uint32_t)((P % 3) * LPSLOT * 4) + 8192u * j);
+    };
+    issue_pair(0);
+    issue_pair(1);
+    // rows: slab sum, LayerNorm (null lnw: layer 0 takes the embedding as it is), swizzled LDS image (chunk `lane` of row r at
+    // position lane ^ (r & 15)), residual copy
+    {
+        const float4 gw = lnw ? *reinterpret_cast<const float4 *>(lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 gb = lnw ? *reinterpret_cast<const float4 *>(lnb + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[BM / NW];
+#pragma unroll
+        for (int i = 0; i < BM / NW; ++i) v[i] = ld4_sum<NP>(A + (size_t)min(m0 + wave + NW * i, M - 1) * D + lane * 4, a_pstride);
+#pragma unroll
+        for (int i = 0; i < BM / NW; ++i) {
+            const int row = wave + NW * i;
+            float4 x = v[i];
+            if (lnw) {
+                float mean, rstd;
+                ln_row_stats(x, mean, rstd);
+                x.x = (x.x - mean) * rstd * gw.x + gb.x;
+                x.y = (x.y - mean) * rstd * gw.y + gb.y;
+                x.z = (x.z - mean) * rstd * gw.z + gb.z;
+                x.w = (x.w - mean) * rstd * gw.w + gb.w;
+            }
+            *reinterpret_cast<float4 *>(Xs + row * D + ((lane ^ (row & 15)) << 2)) = x;
+            if (xn_out && sl == 0 && m0 + row < M) *reinterpret_cast<float4 *>(xn_out + (size_t)(m0 + row) * D + lane * 4) = x;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // pair 0 (and everything older) has landed; pair 1's three instructions may fly
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // wave w: row tile w & 1, column tiles 3 (w >> 1) .. +2
+    const int r1 = wave & 1, c0 = (wave >> 1) * 3;
+    f32x4 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 a0, a1, b0[3], b1f[3];
+    const float *xb[4], *wb[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xb[m] = Xs + (r1 * 16 + li) * D + (((kq ^ li) ^ (4 * m)) << 2);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) wb[s3] = ring + s3 * LPSLOT + ((kq ^ key) << 2) + li * 16 + c0 * 256;
+    auto rd = [&](int c, float4 &a, float4 (&b)[3]) {
+        a = ldsv4(xb[c & 3] + 64 * (c >> 2));
+        const float *sb = wb[(c >> 1) % 3] + (c & 1) * LW1C;
+        b[0] = ldsv4(sb);
+        b[1] = ldsv4(sb + 256);
+        b[2] = ldsv4(sb + 512);
+    };
+    auto mma3 = [&](const float4 &a, const float4 (&b)[3]) {
+        IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x); IDF_FFN_MFMA(acc[2], a.x, b[2].x);
+        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y); IDF_FFN_MFMA(acc[2], a.y, b[2].y);
+        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z); IDF_FFN_MFMA(acc[2], a.z, b[2].z);
+        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w); IDF_FFN_MFMA(acc[2], a.w, b[2].w);
+    };
+    rd(0, a0, b0);
+#pragma unroll
+    for (int P = 0; P < 8; ++P) {
+        issue_pair(P + 2);
+        rd(2 * P + 1, a1, b1f);
+        mma3(a0, b0);
+        if (P + 2 < 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // pair P+1 has landed; pair P+2 may keep flying
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (P + 1 < 8) rd(2 * P + 2, a0, b0);
+        mma3(a1, b1f);
+    }
+    // epilogue: + bias, through LDS, 16-byte row stores (write-through: the attention kernel reads this from other XCDs)
+    constexpr int LCS = LHS + 4;
+    float *Cs = ring;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float bv = bias[n0 + (c0 + j) * 16 + li];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cs[(r1 * 16 + kq * 4 + rr) * LCS + (c0 + j) * 16 + li] = acc[j][rr] + bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < BM * (LHS / 4) / NT; ++it) {
+        const int idx = tid + it * NT, row = idx / (LHS / 4), c4 = (idx - row * (LHS / 4)) << 2, gr = m0 + row;
+        if (gr < M) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, ldsv4(Cs + row * LCS + c4));
+    }
+}
+
+template <int NP>
+inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
+                             const float *pack, const float *bias, float *C, int ldc, float *xn_out) {
+    hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)idf_cdiv(M, BM), (unsigned)(N / LHS)), dim3(NT), 0, s, A, a_pstride, lnw, lnb, M,
+                       pack, bias, C, ldc, xn_out);
+}
+
 inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {
     hipLaunchKernelGGL(ffn_fused_kernel<0>, dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
 }

@@ -99,6 +99,15 @@ def pack_ffn(w1, w2):
     return out
 
 
+def pack_linear192(w):
+    """[N,256] weight (N % 192 == 0) -> the LayerNorm+linear kernel's stream (csrc/ffn.h ln_linear_kernel): per 192-row slice the 16
+    k-group chunks [192 rows][16 k], each in the swizzled LDS image of ``_swizzle16``."""
+    w = np.asarray(w, np.float32)
+    assert w.shape[1] == D and w.shape[0] % 192 == 0
+    out = [_swizzle16(w[n0:n0 + 192, 16 * g:16 * g + 16]).ravel() for n0 in range(0, w.shape[0], 192) for g in range(D // 16)]
+    return np.concatenate(out)
+
+
 def pad_ffn_bias(b1):
     """linear1.bias [1024] -> [5 * 208] zero-padded + one spare KiB (the kernel fetches a slice's bias with one 1-KiB DMA)."""
     out = np.zeros(FFN_SLICE_H * _lib.FFN_SLICES + 256, np.float32)
@@ -155,6 +164,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.wk = ar.add(g(p + 'wk').reshape(-1))
         else:
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
+            ly.sa_in_pack = ar.add(pack_linear192(g(p + 'self_attn.in_proj_weight')))
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
             ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
@@ -181,6 +191,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
                 ly.wk = ar.add(g(p + 'wk').reshape(-1))
             else:
                 ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
+                ly.sa_in_pack = ar.add(pack_linear192(g(p + 'self_attn.in_proj_weight')))
                 ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
                 ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
                 ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))

@@ -174,3 +174,97 @@ def emulate_ffn(x2, pack, b1p, b2, late):
             p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1p.astype(np.float64), b2.astype(np.float64), mt, sl, late)
             parts[sl, mt * BM:mt * BM + p.shape[0]] = p
     return parts
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# csrc/ffn.h ln_linear_kernel (LayerNorm + linear of the QKV projection), one workgroup
+LCT, LHS = 12, 192
+LW1C = LHS * 16
+LPSLOT = 2 * LW1C
+
+
+def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
+    """A_slabs [NP][M][256] -> C [M][N] (float64), all workgroups; the DMA applied at issue or at the covering wait."""
+    M = A_slabs.shape[1]
+    C = np.zeros((M, N))
+    lane = np.arange(64)
+    li, kq = lane & 15, lane >> 4
+    key = (4 - (li >> 2)) & 3
+    x = A_slabs.astype(np.float64).sum(0)
+    if lnw is not None:
+        mu = x.mean(1, keepdims=True)
+        var = ((x - mu) ** 2).mean(1, keepdims=True)
+        x = (x - mu) / np.sqrt(var + 1e-5) * lnw + lnb
+    for mt in range((M + BM - 1) // BM):
+        for sl in range(N // LHS):
+            m0, n0 = mt * BM, sl * LHS
+            stream = pack[sl * 16 * LW1C:(sl + 1) * 16 * LW1C].astype(np.float64)
+            Xs, ring = np.zeros(BM * D), np.full(3 * LPSLOT, np.nan)
+            pending = {}
+
+            def issue_pair(P):
+                if P >= 8:
+                    return
+                ops = []
+                for wave in range(NW):
+                    for j in range(3):
+                        off = wave * 256 + 2048 * j                      # floats: (wave*1024 + 8192 j) bytes
+                        src = P * 2 * LW1C + off
+                        ops.append(((P % 3) * LPSLOT + off, stream[src:src + 256].copy()))
+                if late:
+                    pending[P] = ops
+                else:
+                    for dst, data in ops:
+                        ring[dst:dst + 256] = data
+
+            def land(P):
+                for dst, data in pending.pop(P, []):
+                    ring[dst:dst + 256] = data
+            issue_pair(0)
+            issue_pair(1)
+            for row in range(BM):
+                src = x[min(m0 + row, M - 1)]
+                for l in range(64):
+                    p = l ^ (row & 15)
+                    Xs[row * D + p * 4:row * D + p * 4 + 4] = src[l * 4:l * 4 + 4]
+            land(0)
+            acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(3)}
+
+            def rd(w, c):
+                r1, c0 = w & 1, (w >> 1) * 3
+                rows = r1 * 16 + li
+                a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
+                bs = []
+                for j in range(3):
+                    base = ((c >> 1) % 3) * LPSLOT + (c & 1) * LW1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
+                    bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
+                return a, bs
+
+            def mma(w, frag):
+                a, bs = frag
+                for j, b in enumerate(bs):
+                    for comp in range(4):
+                        Am, Bm = np.zeros((16, 4)), np.zeros((4, 16))
+                        Am[li, kq] = a[:, comp]
+                        Bm[kq, li] = b[:, comp]
+                        acc[(w, j)] += Am @ Bm
+            f0 = [rd(w, 0) for w in range(NW)]
+            for P in range(8):
+                issue_pair(P + 2)
+                f1 = [rd(w, 2 * P + 1) for w in range(NW)]
+                for w in range(NW):
+                    mma(w, f0[w])
+                land(P + 1)
+                if P + 1 < 8:
+                    f0 = [rd(w, 2 * P + 2) for w in range(NW)]
+                for w in range(NW):
+                    mma(w, f1[w])
+            assert not pending
+            for w in range(NW):
+                r1, c0 = w & 1, (w >> 1) * 3
+                for j in range(3):
+                    for rr in range(16):
+                        gr = m0 + r1 * 16 + rr
+                        if gr < M:
+                            C[gr, n0 + (c0 + j) * 16:n0 + (c0 + j) * 16 + 16] = acc[(w, j)][rr] + bias[n0 + (c0 + j) * 16:n0 + (c0 + j) * 16 + 16]
+    return C

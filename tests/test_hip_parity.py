@@ -306,6 +306,16 @@ def test_full_size_end_to_end_golden(mdm, smpl):
                                        R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3))),
                     markers=rel(v2[:, :, MARKERS67], z['markers']), joints=rel(j2, z['jtr']))
     rep['final_outputs_rel_err_on_the_reference_sample'] = fin_same
+    # fp64 anchor of the rot6d -> matrix step on that same sample (oracle/rotations.py in double): how far the reference's OWN fp32
+    # conversion is from the exact answer there, next to ours
+    from oracle.correction import split_tokens
+    from oracle import rotations as OR
+    body64, _ = split_tokens(torch.from_numpy(z['dump_999']).double())
+    m64 = OR.rotation_6d_to_matrix(body64[..., :132].reshape(T, B, 22, 6))
+    m_ref = R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3)).double()
+    m_hip = R.axis_angle_to_matrix(b2[..., :66].reshape(T, B, 22, 3).cpu()).double()
+    rot_anchor = dict(hip_vs_fp64=rel(m_hip, m64), reference_vs_fp64=rel(m_ref, m64))
+    rep['body_rotations_on_the_reference_sample_vs_fp64'] = rot_anchor
     obj_gt, jtr_gt, body_gt, faces = ev.get_gt(bd, smpl)
     m = ev.Metrics(corr)(obj[past:], jtr[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces, bd['obj_points'])
     rep['metrics_rel_err_vs_reference'] = {k: rel(m[k], z['m_' + k]) for k in m}
@@ -321,7 +331,13 @@ def test_full_size_end_to_end_golden(mdm, smpl):
         assert e['hip_vs_reference'] <= 1e-4, (s_, e)
     assert rep['condition_flips_vs_reference'] == 0 and rep['contact_marker_flips_vs_reference'] == 0
     for k, e in fin_same.items():
-        assert e <= 1e-4, (k, e)
+        if k != 'body_rotations':
+            assert e <= 1e-4, (k, e)
+    # body rotations: a random-init denoiser leaves some joints' two 3-vectors nearly parallel, where Gram-Schmidt amplifies fp32
+    # rounding beyond 1e-4 for ANY fp32 implementation: the gate is the distance to the fp64 answer, ours no further than the
+    # reference's own (+1e-5), and 1e-4 between the two wherever that is attainable
+    assert rot_anchor['hip_vs_fp64'] <= max(1e-4, rot_anchor['reference_vs_fp64'] + 1e-5), rot_anchor
+    assert fin_same['body_rotations'] <= max(1e-4, 2 * rot_anchor['reference_vs_fp64']), (fin_same, rot_anchor)
     for k, e in rep['metrics_rel_err_vs_reference'].items():
         assert e <= (2e-3 if k == 'penetrate' else 2e-4), (k, e)
 

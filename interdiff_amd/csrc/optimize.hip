@@ -101,15 +101,19 @@ __global__ __launch_bounds__(256) void opt_objpts_kernel(const float *__restrict
 // point2point_signed needs, per object point, the nearest vertex (tools.py:45-50); the contact-radius mask needs, per
 // vertex, whether ANY object point lies within 0.5 m.  Both read the same P x V distances, so one pass serves both: every
 // thread owns two object points as a packed pair (exact (dx*dx + dy*dy) + dz*dz, no FMA contraction, lowest index wins:
-// the argmin is bit-identical to geometry.hip and to the oracle), vertices stream through LDS in chunks with their id in
-// .w, and the per-vertex "some point is near" bit is a wave ballot folded into a 64-bit scalar mask (SALU work that
+// the argmin is bit-identical to geometry.hip and to the oracle), vertices stream through LDS in chunks as (x, y, z, z)
+// records, and the per-vertex "some point is near" bit is a wave ballot folded into a 64-bit scalar mask (SALU work that
 // overlaps the VALU of the other waves), OR-ed into LDS once per 64 vertices.
-constexpr int NN_T = 256, NN_RC = 1024;
+// As in correction.hip's contact scan the loop only keeps the running MINIMUM (v_min3_f32 over vertex pairs); which vertex
+// it was is settled per block of 8 -- one compare + two selects per point per block -- and resolved after the scan by
+// re-scoring the winning block (the lowest vertex whose bit-identical distance equals the minimum): 17 -> ~11.5 VALU
+// instructions per vertex per thread.
+constexpr int NN_T = 256, NN_RC = 1024, NN_VB = 8;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ pts, int P, const float *__restrict__ verts, int V,
                                                       int32_t *__restrict__ yidx, int32_t *__restrict__ near /* [N][V], zeroed */) {
-    __shared__ __attribute__((aligned(16))) float4 rs[NN_RC + 4];
+    __shared__ __attribute__((aligned(16))) float4 rs[NN_RC + NN_VB];
     __shared__ unsigned nfw[NN_RC / 32];
     const int64_t n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,49 +124,52 @@ __global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ 
     const v2f QY = v2f{i0 < P ? pn[3 * i0 + 1] : FAR, i1 < P ? pn[3 * i1 + 1] : FAR};
     const v2f QZ = v2f{i0 < P ? pn[3 * i0 + 2] : FAR, i1 < P ? pn[3 * i1 + 2] : FAR};
     v2f best = v2f{FLT_MAX, FLT_MAX};
-    int b0 = 0, b1 = 0;
+    int b0 = 0, b1 = 0;                                   // first vertex of the block that last lowered the minimum
     for (int c0 = 0; c0 < V; c0 += NN_RC) {
         __syncthreads();
-        for (int j = tid; j < NN_RC + 4; j += NN_T) {
+        for (int j = tid; j < NN_RC + NN_VB; j += NN_T) {
             const int v = c0 + j;
-            rs[j] = (v < V && j < NN_RC) ? make_float4(vn[3 * v], vn[3 * v + 1], vn[3 * v + 2], __int_as_float(v))
-                                         : make_float4(-FAR, -FAR, -FAR, 0.f);
+            rs[j] = (v < V && j < NN_RC) ? make_float4(vn[3 * v], vn[3 * v + 1], vn[3 * v + 2], vn[3 * v + 2])
+                                         : make_float4(-FAR, -FAR, -FAR, -FAR);
         }
         if (tid < NN_RC / 32) nfw[tid] = 0;
         __syncthreads();
         const int cn = (min(NN_RC, V - c0) + 63) & ~63;
         {
 #pragma clang fp contract(off)
-            // software pipeline with two register sets: the LDS records of the next four vertices are in flight while the
-            // current four are scored
-            float4 ra[4], rb[4];
-            auto score = [&](const float4 (&r)[4], int k0, unsigned long long &mask) {
+            // software pipeline with two register sets: the LDS records of the next block are in flight while the current
+            // one is scored
+            float4 cur[NN_VB], nxt[NN_VB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 p = r[u];
-                    const v2f dx = QX - v2f{p.x, p.x}, dy = QY - v2f{p.y, p.y}, dz = QZ - v2f{p.z, p.z};
-                    const v2f d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2.x < best.x) { best.x = d2.x; b0 = __float_as_int(p.w); }
-                    if (d2.y < best.y) { best.y = d2.y; b1 = __float_as_int(p.w); }
-                    // sqrt(d2) < 0.5 (optimization.py:75) <=> d2 < 0.25 up to the rounding of the last ulp
-                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(d2.x < 0.25f) | __builtin_amdgcn_ballot_w64(d2.y < 0.25f);
-                    unsigned bit;                                     // (bal != 0) on the scalar unit
-                    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bit) : "s"(bal) : "scc");
-                    mask |= (unsigned long long)bit << (k0 + u);
-                }
-            };
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = rs[u];
+            for (int u = 0; u < NN_VB; ++u) cur[u] = rs[u];
             for (int g = 0; g < cn; g += 64) {
                 unsigned long long mask = 0;
 #pragma unroll 1
-                for (int u8 = 0; u8 < 64; u8 += 8) {
+                for (int u8 = 0; u8 < 64; u8 += NN_VB) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) rb[u] = rs[g + u8 + 4 + u];
-                    score(ra, u8, mask);
+                    for (int u = 0; u < NN_VB; ++u) nxt[u] = rs[g + u8 + NN_VB + u];          // rs has one pad block
+                    v2f bm = v2f{FLT_MAX, FLT_MAX};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ra[u] = rs[g + u8 + 8 + u];          // rs has 4 pad records
-                    score(rb, u8 + 4, mask);
+                    for (int u = 0; u < NN_VB; u += 2) {
+                        const float4 p = cur[u], r = cur[u + 1];
+                        const v2f dx = QX - v2f{p.x, p.x}, dy = QY - v2f{p.y, p.y}, dz = QZ - v2f{p.z, p.w};
+                        const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+                        const v2f ex = QX - v2f{r.x, r.x}, ey = QY - v2f{r.y, r.y}, ez = QZ - v2f{r.z, r.w};
+                        const v2f e2 = (ex * ex + ey * ey) + ez * ez;
+                        bm.x = fminf(fminf(bm.x, d2.x), e2.x);                              // v_min3_f32
+                        bm.y = fminf(fminf(bm.y, d2.y), e2.y);
+                        // sqrt(d2) < 0.5 (optimization.py:75) <=> d2 < 0.25 up to the rounding of the last ulp
+                        const unsigned long long bd = __builtin_amdgcn_ballot_w64(d2.x < 0.25f) | __builtin_amdgcn_ballot_w64(d2.y < 0.25f);
+                        const unsigned long long be = __builtin_amdgcn_ballot_w64(e2.x < 0.25f) | __builtin_amdgcn_ballot_w64(e2.y < 0.25f);
+                        unsigned bitd, bite;                              // (ballot != 0) on the scalar unit
+                        asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bitd) : "s"(bd) : "scc");
+                        asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bite) : "s"(be) : "scc");
+                        mask |= ((unsigned long long)bitd << (u8 + u)) | ((unsigned long long)bite << (u8 + u + 1));
+                    }
+                    if (bm.x < best.x) { best.x = bm.x; b0 = c0 + g + u8; }
+                    if (bm.y < best.y) { best.y = bm.y; b1 = c0 + g + u8; }
+#pragma unroll
+                    for (int u = 0; u < NN_VB; ++u) cur[u] = nxt[u];
                 }
                 if (lane == 0 && mask) {
                     atomicOr(&nfw[g >> 5], (unsigned)mask);
@@ -174,8 +181,21 @@ __global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ 
         for (int j = tid; j < NN_RC; j += NN_T)
             if ((nfw[j >> 5] >> (j & 31)) & 1u) near[(size_t)n * V + c0 + j] = 1;      // several point blocks may store the same 1
     }
-    if (i0 < P) yidx[(size_t)n * P + i0] = b0;
-    if (i1 < P) yidx[(size_t)n * P + i1] = b1;
+    // resolve the index inside the winning block: the lowest vertex whose (bit-identical) distance equals the minimum
+    {
+#pragma clang fp contract(off)
+        int r0 = b0, r1 = b1;
+#pragma unroll
+        for (int u = NN_VB - 1; u >= 0; --u) {
+            const int v0 = min(b0 + u, V - 1), v1 = min(b1 + u, V - 1);
+            const float dx0 = QX.x - vn[3 * v0], dy0 = QY.x - vn[3 * v0 + 1], dz0 = QZ.x - vn[3 * v0 + 2];
+            const float dx1 = QX.y - vn[3 * v1], dy1 = QY.y - vn[3 * v1 + 1], dz1 = QZ.y - vn[3 * v1 + 2];
+            if ((dx0 * dx0 + dy0 * dy0) + dz0 * dz0 == best.x && b0 + u < V) r0 = b0 + u;
+            if ((dx1 * dx1 + dy1 * dy1) + dz1 * dz1 == best.y && b1 + u < V) r1 = b1 + u;
+        }
+        if (i0 < P) yidx[(size_t)n * P + i0] = r0;
+        if (i1 < P) yidx[(size_t)n * P + i1] = r1;
+    }
 }
 
 __device__ __forceinline__ float3 ld3(const float *p) { return make_float3(p[0], p[1], p[2]); }

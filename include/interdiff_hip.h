@@ -229,6 +229,15 @@ int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, v
 int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
                                  const float *table, int64_t *state, int64_t *ts, int32_t B, void *stream);
 int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stream);
+/* One PLAIN reverse step (no denoised_fn hook) = interdiff_mdm_forward + interdiff_posterior_step_dev(ts != NULL) with the x0
+ * prediction consumed inside the denoiser's last GEMM: x [B,1,C,T] is the sampler state, updated in place; ts, table, gt, mask as
+ * above; state is int64[8] here: [0..3] as above, [4..5] scratch (this step's {t, loop index}, parked by one thread of layer 0's
+ * QKV kernel, which also advances [0..1] and ts -- no arrival counter).  Same bits as the two-call form (the update arithmetic and
+ * the noise counter are shared), and the two forms can alternate on one state.  T % 4 == 0 and layer 0 a standard layer
+ * (IDF_E_INVAL otherwise: use the two-call form); replaces gaussian_diffusion.py:425-461 (p_sample) for steps without a hook. */
+int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
+                               const float *gt, const uint8_t *mask, const float *table, int64_t *state,
+                               void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,

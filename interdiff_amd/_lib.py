@@ -97,6 +97,7 @@ _SIGS = {
     'interdiff_mdm_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),
     'interdiff_mdm_forward': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+    'interdiff_mdm_forward_step': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'interdiff_inpaint': (C.c_int, [vp, vp, vp, i64, vp]),
     'interdiff_posterior_step': (C.c_int, [vp, vp, vp, i64, f32, f32, f32, u64, u64, vp]),
     'interdiff_randn': (C.c_int, [vp, i64, u64, u64, vp]),

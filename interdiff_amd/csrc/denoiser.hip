@@ -546,11 +546,29 @@ void run_gemm_ln(int cfg, hipStream_t s, const Args &g, int np) {
 }
 constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_HEADS = 6;          // (the QKV projection has its own kernel: run_qkv)
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
+// the last GEMM with the sampler update in its epilogue (gemm.h E_HEADS_POST): LDS-DMA kernel configurations only
+template <int NP>
+void run_heads_post_np(int cfg, hipStream_t s, const Args &g) {
+    switch (cfg) {
+    case 1: launch_glds<32, 64, 2, 2, 1, 32, A_LN, E_HEADS_POST, 3, NP>(s, g); break;
+    case 3: launch_glds<32, 64, 2, 2, 2, 64, A_LN, E_HEADS_POST, 3, NP>(s, g); break;
+    case 5: launch_glds<32, 32, 2, 2, 1, 64, A_LN, E_HEADS_POST, 3, NP>(s, g); break;
+    default: launch_glds<32, 32, 2, 2, 2, 64, A_LN, E_HEADS_POST, 3, NP>(s, g); break;          // CFG_HEADS
+    }
+}
+void run_heads_post(int cfg, hipStream_t s, const Args &g, int np) {
+    if (np == NSL) run_heads_post_np<NSL>(cfg, s, g);
+    else run_heads_post_np<1>(cfg, s, g);
+}
 // QKV projection: the LayerNorm+linear kernel of ffn.h (tune 0) or, for A/B runs, one of the generic GEMM configurations
-void run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np) {
-    if (tuned) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return; }
-    if (np == NSL) idf_ffn::launch_ln_linear<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out);
-    else idf_ffn::launch_ln_linear<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out);
+// step_state != null (layer 0 of interdiff_mdm_forward_step): one thread of the launch does the step's sampler bookkeeping (philox.h)
+void run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, int64_t *step_state = nullptr, int64_t *step_ts = nullptr,
+             int step_B = 0) {
+    if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return; }
+    if (np == NSL)
+        idf_ffn::launch_ln_linear<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+    else
+        idf_ffn::launch_ln_linear<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
 }
 
 }  // namespace
@@ -684,9 +702,19 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     return IDF_OK;
 }
 
-extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts,
-                                     int32_t B, int32_t T, float *x0, void *ws, size_t ws_bytes, void *stream) {
-    if (!w || !memctx || !x || !ts || !x0 || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
+namespace {
+// the sampler-step operands of interdiff_mdm_forward_step (null x: plain forward, x0 written out)
+struct StepPost {
+    float *x;
+    const float *gt;
+    const uint8_t *mask;
+    const float *table;
+    int64_t *state, *ts;
+};
+
+int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
+                     void *ws, size_t ws_bytes, void *stream, const StepPost &post) {
+    if (!w || !memctx || !x || !ts || (!x0 && !post.x) || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
     if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || (w->C & 3)) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_workspace_bytes(B, T)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
@@ -732,7 +760,8 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
-            run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np);
+            if (post.x && l == 0) run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B);
+            else run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
             // u1 = xn + ctx.Wo^T + bo
@@ -759,9 +788,33 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
         g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + w->out_w; g.bias = ar + w->out_b; g.C = x0;
         g.ldc = C; g.M = N; g.N = C; g.T = T; g.a_pstride = pstride;
         idf_prof_mark(IDF_K_GEMM_HEADS, s);
-        run_gemm_ln<E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g, u_np);
+        if (post.x) {
+            g.post_x = post.x; g.post_gt = post.gt; g.post_mask = post.mask; g.post_table = post.table; g.post_state = post.state;
+            run_heads_post(tune[IDF_TUNE_GEMM_HEADS], s, g, u_np);
+        } else {
+            run_gemm_ln<E_HEADS>(pick(tune[IDF_TUNE_GEMM_HEADS], CFG_HEADS), s, g, u_np);
+        }
     }
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
+}
+}  // namespace
+
+extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts,
+                                     int32_t B, int32_t T, float *x0, void *ws, size_t ws_bytes, void *stream) {
+    if (!x0) return IDF_E_INVAL;
+    return mdm_forward_impl(w, memctx, x, ts, B, T, x0, ws, ws_bytes, stream, StepPost{});
+}
+
+// One plain DDPM reverse step in the denoiser's own launches: the forward above with the x0 tile of the last GEMM consumed in its
+// epilogue (inpaint, posterior mean, in-kernel noise) -- x is updated in place and the sampler state advanced, exactly what
+// interdiff_mdm_forward + interdiff_posterior_step_dev(ts != NULL) do in two more HBM passes and one more launch.
+extern "C" int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
+                                          const float *gt, const uint8_t *mask, const float *table, int64_t *state, void *ws,
+                                          size_t ws_bytes, void *stream) {
+    if (!x || !ts || !table || !state || (mask && !gt) || T <= 0 || (T & 3)) return IDF_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 15 || (reinterpret_cast<uintptr_t>(mask) & 3)) return IDF_E_INVAL;
+    if (!w || w->layer[0].is_qan) return IDF_E_INVAL;         // the step bookkeeping rides on layer 0's QKV kernel
+    return mdm_forward_impl(w, memctx, x, ts, B, T, nullptr, ws, ws_bytes, stream, StepPost{x, gt, mask, table, state, ts});
 }

@@ -30,6 +30,7 @@
 // Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate), gelu = erf form (common.h gelu_fast).
 #pragma once
 #include "common.h"
+#include "philox.h"
 
 namespace idf_ffn {
 
@@ -310,8 +311,11 @@ template <int NP>
 __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__ A, size_t a_pstride, const float *__restrict__ lnw,
                                                         const float *__restrict__ lnb, int M, const float *__restrict__ pack,
                                                         const float *__restrict__ bias, float *__restrict__ C, int ldc,
-                                                        float *__restrict__ xn_out) {
+                                                        float *__restrict__ xn_out, int64_t *__restrict__ step_state,
+                                                        int64_t *__restrict__ step_ts, int step_B) {
     __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * LPSLOT];
+    // sampler bookkeeping of a fused plain step (philox.h): nobody else touches these words while this kernel runs
+    if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
     float *Xs = smem, *ring = smem + XS;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,9 +417,10 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
 
 template <int NP>
 inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
-                             const float *pack, const float *bias, float *C, int ldc, float *xn_out) {
+                             const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
+                             int64_t *step_ts = nullptr, int step_B = 0) {
     hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)idf_cdiv(M, BM), (unsigned)(N / LHS)), dim3(NT), 0, s, A, a_pstride, lnw, lnb, M,
-                       pack, bias, C, ldc, xn_out);
+                       pack, bias, C, ldc, xn_out, step_state, step_ts, step_B);
 }
 
 inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {

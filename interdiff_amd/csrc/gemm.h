@@ -15,11 +15,12 @@
 // Epilogues: bias | gelu | +residual | heads (transposed store back to [b][c][t]) | embed (+temb[ts[b]]+pe[t]).
 #pragma once
 #include "common.h"
+#include "philox.h"
 
 namespace idf_gemm {
 
 enum { A_PLAIN = 0, A_LN = 1, A_TOKT = 2 };
-enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4 };
+enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4, E_HEADS_POST = 5 };
 
 struct Args {
     const float *A;
@@ -36,6 +37,13 @@ struct Args {
     const int64_t *ts;              // E_EMBED: timestep per clip
     const float *temb, *pe;         // E_EMBED: [n_steps][N], [max_T][N]
     int n_steps;
+    // E_HEADS_POST: the x0 tile never reaches HBM -- inpainting, posterior mean and the noise add run on it in the epilogue and
+    // overwrite the sampler state x in place ([b][c][t], same indexing as C).  LDS-DMA kernel only.
+    float *post_x;
+    const float *post_gt;           // nullable together with post_mask
+    const uint8_t *post_mask;
+    const float *post_table;        // [steps][4] = {c1, c2, sigma, .}
+    const int64_t *post_state;      // int64[8]: [2] seed, [4..5] this step's {t, loop index}
 #ifdef IDF_GEMM_PROBE
     long long *probe;               // tools/gemm_probe.hip only (built with -DIDF_GEMM_PROBE): per-workgroup s_memtime stamps
 #endif
@@ -84,6 +92,54 @@ __device__ __forceinline__ void load_resid(const Args &g, float (&rres)[TM][TN][
             const int col = min(col0 + j * 16, g.N - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) rres[i][j][r] = g.resid[(size_t)min(rbase0 + i * 16 + r, g.M - 1) * g.ldc + col];
+        }
+}
+
+// E_HEADS_POST operands of one lane, requested BEFORE the k-loop (the sampler state -> coefficient row -> x / gt / mask chain is
+// three dependent memory round trips, and the Philox + Box-Muller noise is ~500 VALU instructions: in the epilogue they would
+// run after the matrix work of a workgroup that has the CU to itself; up front they hide behind the first operand fetches)
+template <int TM, int TN>
+struct PostOperands {
+    float4 xv[TM][TN], gv[TM][TN], e[TM][TN];
+    uchar4 mk[TM][TN];
+    float c1, c2, sigma;
+};
+template <int TM, int TN>
+__device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN> &po, int rbase0, int col0) {
+    const int64_t st = g.post_state[4];                 // {t, loop index} of THIS step, parked by sampler_prepare_step (philox.h)
+    const uint64_t it = (uint64_t)g.post_state[5], seed = (uint64_t)g.post_state[2];
+    po.c1 = g.post_table[st * 4]; po.c2 = g.post_table[st * 4 + 1]; po.sigma = g.post_table[st * 4 + 2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rbase = min(rbase0 + i * 16, g.M - 4), col = min(col0 + j * 16, g.N - 1);      // clamped: out-of-tile lanes load valid addresses and store nothing
+            const int b = rbase / g.T, t = rbase - b * g.T;
+            const size_t flat = ((size_t)b * g.N + col) * g.T + t;
+            po.xv[i][j] = ld4(g.post_x + flat);
+            po.gv[i][j] = g.post_mask ? ld4(g.post_gt + flat) : zero4();
+            po.mk[i][j] = g.post_mask ? *reinterpret_cast<const uchar4 *>(g.post_mask + flat) : make_uchar4(0, 0, 0, 0);
+            po.e[i][j] = randn4(seed, it, (uint64_t)(flat >> 2));
+            asm volatile("" : "+v"(po.e[i][j].x), "+v"(po.e[i][j].y), "+v"(po.e[i][j].z), "+v"(po.e[i][j].w));     // computed here, not sunk into the epilogue
+        }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[TM][TN], const float (&bvs)[TN], const PostOperands<TM, TN> &po,
+                                              int rbase0, int col0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rbase = rbase0 + i * 16, col = col0 + j * 16;
+            if (col >= g.N || rbase >= g.M) continue;
+            const int b = rbase / g.T, t = rbase - b * g.T;
+            const size_t flat = ((size_t)b * g.N + col) * g.T + t;
+            const float bv = bvs[j];
+            float4 pv = make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+            const uchar4 m = po.mk[i][j];
+            const float4 gv = po.gv[i][j];
+            pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
+            *reinterpret_cast<float4 *>(g.post_x + flat) = posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]);
         }
 }
 
@@ -432,6 +488,10 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     if constexpr (EPI == E_RESID) {
         if (ks == 0) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     }
+    PostOperands<EPI == E_HEADS_POST ? TM : 1, EPI == E_HEADS_POST ? TN : 1> po;
+    if constexpr (EPI == E_HEADS_POST) {
+        if (ks == 0) post_prefetch<TM, TN>(g, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    }
     if constexpr (APRO == A_LN) {
         const float4 gw = g.lnw ? ld4(g.lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 gb = g.lnw ? ld4(g.lnb + lane * 4) : zero4();
@@ -541,7 +601,11 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
         if constexpr (KS > 1) __syncthreads();                    // the split-K partials have been read
         epilogue_rows<BM, BN, TM, TN, EPI, NW * 64>(g, smem, acc, rres, bvs, ks == 0, wm * TM * 16, wn * TN * 16, kq, li, m0, n0, tid);
     } else {
-        if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+        if constexpr (EPI == E_HEADS_POST) {
+            if (ks == 0) epilogue_post<TM, TN>(g, acc, bvs, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+        } else {
+            if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+        }
     }
     IDF_PROBE_STAMP(g, wg, 3);
 }

@@ -6,35 +6,9 @@
 // is either handed in (deterministic parity runs) or produced in-kernel by Philox4x32-10 +
 // Box-Muller keyed by (seed, step, element), so no noise tensor ever round-trips HBM.
 #include "common.h"
+#include "philox.h"
 
 namespace {
-
-__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
-// four N(0,1) draws for element group g of step `step`
-__device__ __forceinline__ float4 randn4(uint64_t seed, uint64_t step, uint64_t g) {
-    uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c0, c1, c2, c3, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    // (0,1] uniforms -> Box-Muller
-    const float u0 = ((float)(c0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c1 >> 8) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c2 >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c3 >> 8) * (1.0f / 16777216.0f);
-    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-    float s0, co0, s1, co1;
-    sincosf(6.283185307179586f * u1, &s0, &co0);
-    sincosf(6.283185307179586f * u3, &s1, &co1);
-    return make_float4(r0 * co0, r0 * s0, r1 * co1, r1 * s1);
-}
 
 __global__ __launch_bounds__(256) void inpaint_kernel(float *__restrict__ x0, const float *__restrict__ gt,
                                                       const uint8_t *__restrict__ mask, int64_t n) {
@@ -56,15 +30,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(float *__restrict__ x, c
             float4 xv = *reinterpret_cast<float4 *>(x + i);
             const float4 pv = *reinterpret_cast<const float4 *>(x0 + i);
             if constexpr (!GEN) e = *reinterpret_cast<const float4 *>(noise + i);
-            xv.x = c1 * pv.x + c2 * xv.x + sigma * e.x;
-            xv.y = c1 * pv.y + c2 * xv.y + sigma * e.y;
-            xv.z = c1 * pv.z + c2 * xv.z + sigma * e.z;
-            xv.w = c1 * pv.w + c2 * xv.w + sigma * e.w;
-            *reinterpret_cast<float4 *>(x + i) = xv;
+            *reinterpret_cast<float4 *>(x + i) = posterior4(c1, c2, sigma, pv, xv, e);
         } else {
             const float ev[4] = {e.x, e.y, e.z, e.w};
             for (int k = 0; k < 4 && i + k < n; ++k)
-                x[i + k] = c1 * x0[i + k] + c2 * x[i + k] + sigma * (GEN ? ev[k] : noise[i + k]);
+                x[i + k] = posterior1(c1, c2, sigma, x0[i + k], x[i + k], GEN ? ev[k] : noise[i + k]);
         }
     }
 }
@@ -101,33 +71,16 @@ __global__ __launch_bounds__(256) void posterior_dev_kernel(float *__restrict__ 
                 const float4 gv = *reinterpret_cast<const float4 *>(gt + i);
                 pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
             }
-            xv.x = c1 * pv.x + c2 * xv.x + sigma * ev[0];
-            xv.y = c1 * pv.y + c2 * xv.y + sigma * ev[1];
-            xv.z = c1 * pv.z + c2 * xv.z + sigma * ev[2];
-            xv.w = c1 * pv.w + c2 * xv.w + sigma * ev[3];
-            *reinterpret_cast<float4 *>(x + i) = xv;
+            *reinterpret_cast<float4 *>(x + i) = posterior4(c1, c2, sigma, pv, xv, e);
         } else {
             for (int k = 0; k < 4 && i + k < n; ++k) {
                 const float p = (mask && mask[i + k]) ? gt[i + k] : x0[i + k];
-                x[i + k] = c1 * p + c2 * x[i + k] + sigma * ev[k];
+                x[i + k] = posterior1(c1, c2, sigma, p, x[i + k], ev[k]);
             }
         }
     }
-    // advance (t -= 1, loop index += 1, ts[b] = max(t, 0)) by the LAST workgroup to arrive: every workgroup has read
-    // the state before it adds itself to the arrival counter, so the update cannot race with a reader of this launch
-    if (ts) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned *arrived = reinterpret_cast<unsigned *>(state + 3);
-            if (atomicAdd(arrived, 1u) == gridDim.x - 1) {
-                *arrived = 0u;
-                const int64_t tn = t - 1;
-                state[0] = tn;
-                state[1] = (int64_t)it + 1;
-                for (int b = 0; b < B; ++b) ts[b] = tn < 0 ? 0 : tn;
-            }
-        }
-    }
+    // advance (t -= 1, loop index += 1, ts[b] = max(t, 0)) by the LAST workgroup to arrive (philox.h)
+    if (ts) sampler_advance_last(state, ts, B, gridDim.x, t, it);
 }
 
 __global__ __launch_bounds__(256) void advance_kernel(int64_t *__restrict__ state, int64_t *__restrict__ ts, int B) {

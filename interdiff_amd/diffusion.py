@@ -72,6 +72,7 @@ class GaussianDiffusion:
         self._sigma = np.exp(np.float32(0.5) * self.posterior_log_variance_clipped.astype(np.float32)).astype(np.float32)
         self._t_cache = {}
         self._tables = {}
+        self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
         self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
     # ------------------------------------------------------------------ helpers
@@ -113,7 +114,7 @@ class GaussianDiffusion:
         st = cache.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),
-                                 state=torch.zeros(4, dtype=torch.int64, device=dev), cond=torch.empty_like(cond, memory_format=torch.contiguous_format),
+                                 state=torch.zeros(8, dtype=torch.int64, device=dev), cond=torch.empty_like(cond, memory_format=torch.contiguous_format),
                                  gt=torch.empty_like(img) if has_mask else None,
                                  mask=torch.empty(img.shape, dtype=torch.uint8, device=dev) if has_mask else None, graphs={})
             st.kwargs = {'y': {'cond': st.cond}}              # what the captured denoiser calls see
@@ -140,18 +141,23 @@ class GaussianDiffusion:
                                                         _lib.dptr(mk, allow_none=True), x.numel(), _lib.dptr(table), _lib.dptr(st.state),
                                                         _lib.dptr(st.ts), B, _lib.stream()), 'posterior_step_dev')
 
+        fused = self.fuse_plain_step and getattr(model, 'supports_forward_step', False) and img.shape[-1] % 4 == 0
+
         def graph_of(k):
             """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
-            if k not in st.graphs:
+            if (k, fused) not in st.graphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     for _ in range(k):
-                        model(st.x, st.ts, out=st.x0, **st.kwargs)
-                        posterior(st.x, st.x0, st.gt, st.mask, st)
-                st.graphs[k] = g
-            return st.graphs[k]
+                        if fused:                   # the update runs in the epilogue of the denoiser's last GEMM (same bits)
+                            model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs)
+                        else:
+                            model(st.x, st.ts, out=st.x0, **st.kwargs)
+                            posterior(st.x, st.x0, st.gt, st.mask, st)
+                st.graphs[(k, fused)] = g
+            return st.graphs[(k, fused)]
         st.x.copy_(img)
-        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, 0, 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         gate = getattr(denoised_fn, 'is_active', None)

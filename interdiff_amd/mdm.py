@@ -343,6 +343,26 @@ class MDM:
 
     __call__ = forward
 
+    @property
+    def supports_forward_step(self):
+        return not self.w.layer[0].is_qan             # the step's sampler bookkeeping rides on layer 0's QKV kernel
+
+    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None):
+        """One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
+        the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place.  T % 4 == 0."""
+        cond = y['cond']
+        if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
+            self.prepare_memory(cond)
+        B, one, Cc, T = x.shape
+        if one != 1 or Cc != self.w.C or not x.is_contiguous():
+            raise ValueError('x must be a contiguous [B,1,%d,T]' % self.w.C)
+        ws = self._workspace(B, T)
+        _lib.check(self.lib.interdiff_mdm_forward_step(C.byref(self.w), _lib.dptr(self._memctx), _lib.dptr(x, torch.float32),
+                                                       _lib.dptr(timesteps, torch.int64), B, T, _lib.dptr(gt, allow_none=True),
+                                                       _lib.dptr(mask, allow_none=True), _lib.dptr(table), _lib.dptr(state),
+                                                       _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_forward_step')
+        return x
+
 
 def ffn_parts(model, x2, layer, encoder=False, out=None):
     """The fused feed-forward block of one layer on ``model``'s weights: x2 [M,256] -> partial slabs [FFN_SLICES, M, 256] whose

@@ -459,7 +459,17 @@ def test_graph_replay_equals_eager(smpl):
         other = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook, seed=78)
         assert not torch.equal(other, eager)
     assert len(model._graph_cache) == 1          # one capture per (schedule, shape, mask, cond shape), living on the denoiser
-
+    # plain steps with the update inside the denoiser's last GEMM (interdiff_mdm_forward_step: the default when T % 4 == 0; T = 14
+    # above went through the two-call form) against the two-call form and against the eager loop
+    assert T % 4 != 0 and diff.fuse_plain_step
+    bt = fx._clip(41, 2, 12, 64)
+    y12, n12 = dev(fx.model_kwargs_y(bt, 12)), bt['noise'].to(DEV)
+    run = lambda **kw: diff.p_sample_loop(model, tuple(n12.shape), noise=n12, clip_denoised=False, model_kwargs={'y': y12}, seed=3, **kw)
+    fused = run()
+    diff.fuse_plain_step = False
+    two_call = run()
+    diff.fuse_plain_step = True
+    assert torch.equal(two_call, fused) and torch.equal(fused, run(use_graph=False))
 
 
 # ------------------------------------------------------------------------------------------ the token GEMM as an op

@@ -729,8 +729,15 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
         g.A = x; g.K = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
         g.ts = ts; g.temb = ar + w->temb_table; g.pe = ar + w->pe; g.n_steps = w->n_steps;
         idf_prof_mark(IDF_K_EMBED, s);
-        if (tune[IDF_TUNE_GEMM_EMBED] == 1) launch<64, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
-        else launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
+        // K = 144: KC = 144 is the whole contraction in ONE chunk -- every operand load of the workgroup in flight at once (one memory
+        // round trip instead of one per 32-deep chunk of the double buffer)
+        switch (tune[IDF_TUNE_GEMM_EMBED]) {
+        case 1: launch<64, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g); break;
+        case 2: launch<32, 64, 2, 2, 144, A_TOKT, E_EMBED>(s, g); break;
+        case 3: launch<32, 32, 2, 2, 144, A_TOKT, E_EMBED>(s, g); break;
+        case 4: launch<32, 64, 2, 2, 48, A_TOKT, E_EMBED>(s, g); break;
+        default: launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g); break;
+        }
     }
     const float *u_in = k.uA;                  // layer input (pre-norm sum of the previous layer): plain for layer 0, then FFN partial slabs
     int u_np = 1;

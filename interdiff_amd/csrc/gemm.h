@@ -95,6 +95,25 @@ __device__ __forceinline__ void load_resid(const Args &g, float (&rres)[TM][TN][
         }
 }
 
+// E_EMBED: temb[ts[b]][col] + pe[t][col] of every accumulator element, requested before the k-loop like the residual (the
+// ts -> temb row chain is two dependent round trips; in the epilogue they would follow the matrix work)
+template <int TM, int TN>
+__device__ __forceinline__ void load_embed_add(const Args &g, float (&rres)[TM][TN][4], int rbase0, int col0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rc = min(rbase0 + i * 16 + r, g.M - 1), b = rc / g.T, t = rc - b * g.T;
+            int64_t step = g.ts[b];
+            step = step < 0 ? 0 : (step >= g.n_steps ? g.n_steps - 1 : step);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cc = min(col0 + j * 16, g.N - 1);
+                rres[i][j][r] = g.temb[(size_t)step * g.N + cc] + g.pe[(size_t)t * g.N + cc];
+            }
+        }
+}
+
 // E_HEADS_POST operands of one lane, requested BEFORE the k-loop (the sampler state -> coefficient row -> x / gt / mask chain is
 // three dependent memory round trips, and the Philox + Box-Muller noise is ~500 VALU instructions: in the epilogue they would
 // run after the matrix work of a workgroup that has the CU to itself; up front they hide behind the first operand fetches)
@@ -209,7 +228,7 @@ __device__ __forceinline__ void epilogue_rows(const Args &g, float *cs, const f3
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bvs[j];
                     if constexpr (EPI == E_GELU) v = gelu_fast(v);
-                    if constexpr (EPI == E_RESID) v += rres[i][j][r];
+                    if constexpr (EPI == E_RESID || EPI == E_EMBED) v += rres[i][j][r];
                     cs[(wrow0 + i * 16 + kq * 4 + r) * CS + wcol0 + j * 16 + li] = v;
                 }
     }
@@ -300,6 +319,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
 
     IDF_PROBE_STAMP(g, wg, 0);
     load_b(0);
+    // epilogue operands requested up front: they are in registers long before the k-loop ends
+    float rres[TM][TN][4], bvs[TN];
+    load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_RESID) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    if constexpr (EPI == E_EMBED) load_embed_add<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     if constexpr (APRO == A_LN) {
         // whole rows: wave w owns rows w, w+NW, ...; a lane holds 4 consecutive features of the 256-wide row
         constexpr int NW = WM * WN;
@@ -374,10 +398,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     }
 
     IDF_PROBE_STAMP(g, wg, 2);
-    float rres[TM][TN][4], bvs[TN];
-    load_bias<TN>(g, bvs, n0 + wn * TN * 16 + li);
-    if constexpr (EPI == E_RESID) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
-    if constexpr (EPI == E_BIAS || EPI == E_GELU || EPI == E_RESID) {
+    if constexpr (EPI == E_BIAS || EPI == E_GELU || EPI == E_RESID || EPI == E_EMBED) {
         static_assert(BM * (BN + 4) <= A_FLOATS + 2 * QC * BQ, "C tile must fit the operand buffers");
         epilogue_rows<BM, BN, TM, TN, EPI, NT>(g, smem, acc, rres, bvs, true, wm * TM * 16, wn * TN * 16, kq, li, m0, n0, tid);
     } else {

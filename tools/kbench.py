@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--T', type=int, default=100)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--sweep', action='store_true')
+    ap.add_argument('--sites', default='outproj,qkv,heads,embed')
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     lib = _lib.load()
@@ -129,18 +130,21 @@ def main():
     result['ffn'] = ffn_ab(model, args.B * args.T)
     print('== feed-forward block at M=%d (graph-replayed bursts, us per layer): %s' % (args.B * args.T, json.dumps(result['ffn'])))
     if args.sweep:
-        for site in ('outproj', 'qkv', 'heads', 'embed'):
-            cfgs = range(2) if site == 'embed' else range(10)
+        ref = model(x, ts, y=y).clone()
+        for site in args.sites.split(','):
+            cfgs = range(5) if site == 'embed' else range(10)
             row = {}
             for c in cfgs:
                 model.w.tune[TUNE[site]] = c
                 p = profile_forward(lib, model, x, ts, y, args.reps)
                 row[c] = p[KIND_OF[site]]
+                err = ((model(x, ts, y=y) - ref).abs().max() / ref.abs().max()).item()
+                assert err < 1e-5, (site, c, err)
             model.w.tune[TUNE[site]] = 0
             result['sweeps'][site] = row
             print('== %s' % site)
             for c, v in row.items():
-                print('   cfg %d %-18s %8.2f us' % (c, CFGS[c], v))
+                print('   cfg %d %-18s %8.2f us' % (c, CFGS[c] if site != 'embed' else 'embed variant', v))
     print(json.dumps(result))
 
 

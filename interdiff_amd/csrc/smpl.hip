@@ -90,7 +90,13 @@ constexpr int BT = 256;                                 // threads (4 waves x 48
 constexpr int FM = FT / 16;                             // 16-frame MFMA tiles per wave (each basis fragment feeds FM*4 MFMAs)
 constexpr int STS = NTC + 1;                            // stage row stride
 constexpr int SF = 16;                                  // frames per skinning sub-step (their joint transforms are staged in LDS)
-constexpr int TBF = 10, TBV = 4;                        // workgroup order: blocks of TBF frame tiles x TBV vertex tiles (L2 working set ~2.9 MiB)
+#ifndef IDF_SMPL_TBF                                     // (tools/smpl_probe.hip rebuilds this file with other block shapes)
+#define IDF_SMPL_TBF 10
+#define IDF_SMPL_TBV 4
+#define IDF_SMPL_FRAME_SLOW 1
+#endif
+constexpr int TBF = IDF_SMPL_TBF, TBV = IDF_SMPL_TBV;   // workgroup order: blocks of TBF frame tiles x TBV vertex tiles (L2 working set ~2.9 MiB)
+constexpr bool FRAME_SLOW = IDF_SMPL_FRAME_SLOW;        // consecutive blocks walk the vertex blocks of one frame block (else the frame blocks of one vertex block)
 
 // One workgroup = 32 frames x 64 vertices.  Phase 1: the blend-shape GEMM feat[32,KB] x blend[KB,192] on the fp32 MFMA; the feature
 // tile sits in LDS, each wave streams the basis rows of its 48 output coordinates straight from global memory (three register sets,
@@ -111,16 +117,19 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
     // Workgroup order, for L2 locality (speed only).  (1) XCD-affine: workgroup id runs on XCD id % 8, each with its own 4-MiB L2,
     // so the logical index is permuted to give one XCD CONSECUTIVE logical workgroups.  (2) The logical index walks blocks of
     // TBF frame tiles x TBV vertex tiles: the ~64 workgroups an XCD runs at a time then share TBV basis slices (4 x 368 KiB) and
-    // TBF frame tiles' features + joint transforms (10 x 141 KiB) -- 2.9 MiB, resident -- and every operand reaches the XCD from
-    // the Infinity Cache about once per block.  (Frame-tile-major order cycled each XCD through all 7 MiB of features + transforms
-    // for every vertex tile: an LRU-hostile sweep that missed L2 on nearly every read; round 1 additionally spread each basis
-    // slice over all eight L2s: 657 MB of fabric reads for a 40-MB basis.)
+    // TBF frame tiles' features + joint transforms (10 x 141 KiB) -- 2.9 MiB, resident.  Consecutive blocks keep the frame block
+    // and move to the next vertex block.  Fabric-side reads per call (rocprofv3 FETCH_SIZE, tools/smpl_probe.hip rebuilt with
+    // other shapes): 144 MB this way, 203 MB with the vertex block kept instead, 142-210 MB for 17x3 / 25x2 / 10x8 / 13x4 blocks
+    // -- and 430-440 us for ALL of them: the 40-MB basis + 7 MB of per-frame operands live in the Infinity Cache and the kernel
+    // is bound by its matrix and skinning phases, not by these reads.  (Frame-tile-major order cycled each XCD through all 7 MiB
+    // of features + transforms for every vertex tile; round 1 additionally spread each basis slice over all eight L2s: 657 MB.)
     const int nft = (int)((N + FT - 1) / FT), nvt = (V + VT - 1) / VT, nfb = (nft + TBF - 1) / TBF;
     const int nwg = gridDim.x, id = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
     const int blk = lid / (TBF * TBV), wi = lid - blk * (TBF * TBV);
-    const int ftile = (blk % nfb) * TBF + wi % TBF, vtile = (blk / nfb) * TBV + wi / TBF;
+    const int nvb = (nvt + TBV - 1) / TBV;
+    const int ftile = (FRAME_SLOW ? blk / nvb : blk % nfb) * TBF + wi % TBF, vtile = (FRAME_SLOW ? blk % nvb : blk / nfb) * TBV + wi / TBF;
     if (ftile >= nft || vtile >= nvt) return;          // ragged edge blocks (workgroup-uniform)
     const int64_t f0 = (int64_t)ftile * FT;
     const int v0 = vtile * VT;

@@ -237,7 +237,7 @@ def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
     out = dict(workload='optimization.py: %d clips x %d frames, %d object points, 200 Adam iterations' % (B, T, n_points),
                ms_per_iteration=best / 200 * 1e3, clips_per_sec=B / best, saved=bool(res['saved'].all()),
                nn_scan=dict(kernel='opt_nn_kernel', bound='valu', pairs_per_iteration=pairs,
-                            note='62% of an iteration; 17.1 VALU instructions per vertex per thread (2 points, packed fp32); VALU-issue-bound, see profiles/r01_pmc_sq_postopt.txt'))
+                            note='61% of an iteration; ~11.5 VALU instructions per vertex per thread (2 points, packed fp32, running minimum + index resolved per 8-vertex block); VALU-issue-bound, see profiles/r02_pmc_sq_postopt.txt'))
     if with_cpu:
         from oracle import optimization as oo
         model = {k: torch.from_numpy(v) for k, v in smpl_np.items()}

@@ -379,20 +379,38 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 32, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
-    for (int i = tid; i < TP * 16; i += 256) {
-        const int j = i >> 4, d4 = (i & 15) * 4;
-        float4 k = zero4(), v = zero4();
-        if (j < T) {
-            const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + d4;
-            k = ld4(src + D);
-            v = ld4(src + 2 * D);
-        }
-        *reinterpret_cast<float4 *>(Ks + j * AS + d4) = k;
-        *reinterpret_cast<float4 *>(Vs + j * AS + d4) = v;
+    // Operand fetch, all requests of a batch in flight together: clamped (always valid) addresses, no guard around a load -- a guarded
+    // load inside a run-time loop costs one full memory round trip per iteration (7 at T = 100).  TP * 16 is a multiple of 256, so a
+    // sweep `it` covers key rows 16 it .. 16 it + 15 for the whole workgroup; 8 sweeps per batch (T <= 128: one batch).
+    float4 qreg[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u, r = i >> 4, d4 = (i & 15) * 4;
+        qreg[u] = ld4(qkv + (rowbase + min(q0 + r, T - 1)) * (3 * D) + h * HD + d4);
     }
-    for (int i = tid; i < 32 * 16; i += 256) {
-        const int r = i >> 4, d4 = (i & 15) * 4, t = q0 + r;
-        *reinterpret_cast<float4 *>(Qs + r * AS + d4) = t < T ? ld4(qkv + (rowbase + t) * (3 * D) + h * HD + d4) : zero4();
+    const int nsweep = TP >> 4;
+    for (int it0 = 0; it0 < nsweep; it0 += 8) {
+        float4 kreg[8], vreg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * (it0 + u), j = i >> 4, d4 = (i & 15) * 4;
+            const float *src = qkv + (rowbase + min(j, T - 1)) * (3 * D) + h * HD + d4;
+            kreg[u] = ld4(src + D);
+            vreg[u] = ld4(src + 2 * D);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * (it0 + u), j = i >> 4, d4 = (i & 15) * 4;
+            if (it0 + u < nsweep) {                                    // workgroup-uniform
+                *reinterpret_cast<float4 *>(Ks + j * AS + d4) = j < T ? kreg[u] : zero4();
+                *reinterpret_cast<float4 *>(Vs + j * AS + d4) = j < T ? vreg[u] : zero4();
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u, r = i >> 4, d4 = (i & 15) * 4;
+        *reinterpret_cast<float4 *>(Qs + r * AS + d4) = q0 + r < T ? qreg[u] : zero4();
     }
     __syncthreads();
     // S = Q K^T / 8: wave w owns key tiles w, w+4, ... for both 16-query tiles

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4_sum<NP>(g.A + (size_t)m * g.lda + lane * 4, g.a_pstride) : zero4();
+            float4 v = ld4_sum<NP>(g.A + (size_t)min(m, M - 1) * g.lda + lane * 4, g.a_pstride);     // clamped, unguarded: all rows in flight together (rows >= M are never stored)
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
 #pragma unroll
         for (int i = 0; i < BM / NW; ++i) {
             const int row = wave + NW * i, m = m0 + row;
-            float4 v = m < M ? ld4_sum<NP>(g.A + (size_t)m * g.lda + lane * 4, g.a_pstride) : zero4();
+            float4 v = ld4_sum<NP>(g.A + (size_t)min(m, M - 1) * g.lda + lane * 4, g.a_pstride);     // clamped, unguarded: all rows in flight together (rows >= M are never stored)
             if (g.lnw) {
                 float mean, rstd;
                 ln_row_stats(v, mean, rstd);

@@ -120,7 +120,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // within 5e-7 absolute of the exact one over the whole fp32 range, torch's own fp32 gelu is within 1.2e-6).
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);      // v_rcp_f32 (1 ulp): __frcp_rn expands to the 10-instruction IEEE division
     const float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float er = 1.0f - p * __expf(-(z * z));
     return 0.5f * x * (1.0f + copysignf(er, x));

@@ -165,7 +165,15 @@ class GaussianDiffusion:
         dump, it, i, end = [], 0, t_start, t_start - todo
         while i > end:
             if active(i):
-                x0 = model(st.x, st.ts, out=st.x0, **st.kwargs)
+                # hook step, two-call form; its denoiser forward is replayed from a graph too (24 eager launches cost the host more
+                # than the GPU needs to run them)
+                if 'fwd' not in st.graphs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        model(st.x, st.ts, out=st.x0, **st.kwargs)
+                    st.graphs['fwd'] = g
+                st.graphs['fwd'].replay()
+                x0 = st.x0
                 if has_mask:
                     _lib.check(lib.interdiff_inpaint(_lib.dptr(x0), _lib.dptr(st.gt), _lib.dptr(st.mask), x0.numel(), _lib.stream()), 'inpaint')
                 t = ts_all[i]

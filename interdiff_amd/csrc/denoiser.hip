@@ -86,7 +86,7 @@ __device__ __forceinline__ void ln_row16_lds(Row16 &r, const float *w, const flo
         const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
         qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
-    const float rstd = 1.0f / sqrtf(row16_sum(qv) * (1.0f / 256.0f) + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(row16_sum(qv) * (1.0f / 256.0f) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 g = *reinterpret_cast<const float4 *>(w + (i * 16 + l16) * 4), be = *reinterpret_cast<const float4 *>(b + (i * 16 + l16) * 4);
@@ -122,13 +122,11 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */) {
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     __shared__ __attribute__((aligned(1024))) float prm[7 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias (DMA targets)
-    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + NQ * TR * 4 + TR * 4 + TR * PS];
+    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
     float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
-    float *cw = part + 4 * 3 * 256;               // [NQ][TR][4]
-    float *coef = cw + NQ * TR * 4;               // [TR][4]
-    float *Ps = coef + TR * 4;                    // [TR][PS]
+    float *Ps = part + 4 * 3 * 256;               // [TR][PS]
 
     const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     }
     Row16 ra, rb;
     float4 q[4][3], gv[4][3], vw[HMP / 16][4];
-    float wk_n = 0.f, g0v[MEM];
+    float wk_n = 0.f, g0v[3];                     // g0 of (head = wave, memory slots q, q+4, q+8 with q = lane & 3)
     const int ta = QAN ? t0 - 1 + rown : t0 + rown, tb = t0 + 15 + kq;
     const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && kq < 2 && tb < T;
     Row16Raw<NP> raw_a, raw_b;
@@ -173,11 +171,11 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
             for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (min(li, NQ - 1) * 3 + j) * D + 16 * (wave * 4 + ss) + 4 * kq);
-        wk_n = wk[min(tid >> 4, NQ - 1)];
+        wk_n = wk[min(li, NQ - 1)];
     }
     if constexpr (CROSS) {
 #pragma unroll
-        for (int m = 0; m < MEM; ++m) g0v[m] = g0b[min(tid >> 4, H - 1) * MEM + m];
+        for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
     }
     auto fetch_g = [&]() {
         if constexpr (CROSS) {
@@ -236,43 +234,33 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         fetch_vw();
         __syncthreads();
         IDF_RB_STAMP(2);                                 // logits MFMA
+        // tap softmax + coefficients: the 16-lane group of token `rown` holds query n = li; c_j = sum_n wk[n] softmax_j(logits) is a
+        // row reduction on the DPP path, so the coefficients stay in the registers of the group that applies them below (an earlier
+        // version went (t, n) -> LDS -> barrier -> 64 threads summing over n -> LDS -> barrier)
+        float c0, c1, c2;
         {
-            const int t = tid & 15, n = tid >> 4;
-            if (n < NQ) {
-                float l[3];
+            const int t = rown, n = min(li, NQ - 1);
+            float l[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    l[j] = (part[(0 * 3 + j) * 256 + t * 16 + n] + part[(1 * 3 + j) * 256 + t * 16 + n]) +
-                           (part[(2 * 3 + j) * 256 + t * 16 + n] + part[(3 * 3 + j) * 256 + t * 16 + n]);
-                const int tg = t0 + t;
-                if (tg <= 0) l[0] = -FLT_MAX;
-                if (tg + 1 >= T) l[2] = -FLT_MAX;
-                const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
-                const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
-                const float w = wk_n / (e0 + e1 + e2);
-                float *o = cw + (n * TR + t) * 4;
-                o[0] = w * e0;
-                o[1] = w * e1;
-                o[2] = w * e2;
-            }
+            for (int j = 0; j < 3; ++j)
+                l[j] = (part[(0 * 3 + j) * 256 + t * 16 + n] + part[(1 * 3 + j) * 256 + t * 16 + n]) +
+                       (part[(2 * 3 + j) * 256 + t * 16 + n] + part[(3 * 3 + j) * 256 + t * 16 + n]);
+            const int tg = t0 + t;
+            if (tg <= 0) l[0] = -FLT_MAX;
+            if (tg + 1 >= T) l[2] = -FLT_MAX;
+            const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
+            const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
+            const float w = li < NQ ? wk_n / (e0 + e1 + e2) : 0.f;
+            c0 = row16_sum(w * e0);
+            c1 = row16_sum(w * e1);
+            c2 = row16_sum(w * e2);
         }
-        __syncthreads();
-        if (tid < TR * 4) {
-            const int t = tid >> 2, j = tid & 3;
-            float c = 0.f;
-            if (j < 3)
-#pragma unroll
-                for (int n = 0; n < NQ; ++n) c += cw[(n * TR + t) * 4 + j];
-            coef[tid] = c;
-        }
-        __syncthreads();
         IDF_RB_STAMP(3);                                 // tap softmax + coefficient sums
         {   // u1 = x_t + sum_j c_j x_{t+j-1} ;  x1 = LN1(u1)
             Row16 xm, xc, xp;
             row16_load(xm, xs + rown * RS, li);
             row16_load(xc, xs + (rown + 1) * RS, li);
             row16_load(xp, xs + (rown + 2) * RS, li);
-            const float c0 = coef[rown * 4], c1 = coef[rown * 4 + 1], c2 = coef[rown * 4 + 2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 xc.c[i].x = xc.c[i].x + (c0 * xm.c[i].x + c1 * xc.c[i].x + c2 * xp.c[i].x);
@@ -311,29 +299,39 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     }
     __syncthreads();
     IDF_RB_STAMP(5);                                     // folded scores MFMA
-    {
-        const int t = tid & 15, h = tid >> 4;
-        if (h < H) {
-            float sc[MEM], mx = -FLT_MAX;
+    {   // softmax over the MEM memory slots of each head: wave = head, token = lane >> 2, the four lanes of a quad take slots
+        // q, q+4, q+8 and combine by two quad permutes (all 256 lanes busy; one wave doing all 40 columns of its 16 tokens took 2 k cycles)
+        static_assert(H == 4 && MEM <= 12, "one wave per head, <= 3 slots per lane");
+#define IDF_QUAD_XOR1(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false))
+#define IDF_QUAD_XOR2(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false))
+        const int tq = lane >> 2, qd = lane & 3;
+        float sc[3], mx = -FLT_MAX;
 #pragma unroll
-            for (int m = 0; m < MEM; ++m) {
-                const int idx = h * MEM + m, ct = idx >> 4, cl = idx & 15, o = t * 16 + cl;
-                sc[m] = ((part[(0 * 3 + ct) * 256 + o] + part[(1 * 3 + ct) * 256 + o]) +
-                         (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0v[m];
-                mx = fmaxf(mx, sc[m]);
-            }
-            float sum = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            const int m = qd + 4 * i, idx = wave * MEM + min(m, MEM - 1), ct = idx >> 4, cl = idx & 15, o = tq * 16 + cl;
+            const float v = ((part[(0 * 3 + ct) * 256 + o] + part[(1 * 3 + ct) * 256 + o]) +
+                             (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0v[i];
+            sc[i] = m < MEM ? v : -FLT_MAX;
+            mx = fmaxf(mx, sc[i]);
+        }
+        mx = fmaxf(mx, IDF_QUAD_XOR1(mx));
+        mx = fmaxf(mx, IDF_QUAD_XOR2(mx));
+        float sum = 0.f;
 #pragma unroll
-            for (int m = 0; m < MEM; ++m) {
-                sc[m] = __expf(sc[m] - mx);
-                sum += sc[m];
-            }
-            const float inv = 1.0f / sum;
+        for (int i = 0; i < 3; ++i) {
+            sc[i] = qd + 4 * i < MEM ? __expf(sc[i] - mx) : 0.f;
+            sum += sc[i];
+        }
+        sum += IDF_QUAD_XOR1(sum);
+        sum += IDF_QUAD_XOR2(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-            for (int m = 0; m < MEM; ++m) Ps[t * PS + h * MEM + m] = sc[m] * inv;
-        } else if (h == H) {
+        for (int i = 0; i < 3; ++i)
+            if (qd + 4 * i < MEM) Ps[tq * PS + wave * MEM + qd + 4 * i] = sc[i] * inv;
+        if (wave == 0 && qd < (HMP - HM + 3) / 4) {
 #pragma unroll
-            for (int c = HM; c < HMP; ++c) Ps[t * PS + c] = 0.f;
+            for (int i = 0; i < 4; ++i)
+                if (HM + qd * 4 + i < HMP) Ps[tq * PS + HM + qd * 4 + i] = 0.f;
         }
     }
     __syncthreads();

@@ -107,6 +107,14 @@ __device__ __forceinline__ void ln_row16_lds(Row16 &r, const float *w, const flo
 // grid (ceil(T/16), B), 256 threads.
 // ------------------------------------------------------------------------------------
 constexpr int TR = 16;
+// MFMA B-operand fragments of the row block are stored IN FRAGMENT ORDER -- [wave = K quarter][k-group of 16][tile][lane][4 floats] --
+// so that one wave load instruction reads 1 KiB contiguous (8 cache lines).  Fetched from the row-major matrices the same
+// instruction gathered sixteen 64-byte pieces, and the kernel spent 5.9 k of its 20 k cycles just ISSUING its first batch of
+// requests (tools/rowblock_probe.hip): the vector memory pipe handles about one line request every two cycles.
+//   Qc  (weights, mdm.py qan_fragments):      [4][4][3 taps][64][4],  row of lane = query min(li, NQ-1)
+//   G   (per sample, mem_fold_kernel):        [4][4][3 column tiles][64][4], column = 16 ct + li of the 40 (head, slot) pairs (+8 zero)
+//   VWT (per sample, mem_fold_kernel):        [4 waves = output column quarter][3 k-groups][4 tiles][64][4]
+constexpr int G_FRAG = 4 * 4 * 3 * 64 * 4;     // 12288 floats per (layer, clip)
 constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
 constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     const size_t rowbase = (size_t)b * T;
     // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
     const int rown = wave * 4 + kq;
-    const float *Gb = CROSS ? G + (size_t)b * HM * D : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
+    const float *Gb = CROSS ? G + (size_t)b * G_FRAG : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
     const float *VWTb = CROSS ? VWT + (size_t)b * D * HMP : nullptr;
     IDF_RB_STAMP(0);
 
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (min(li, NQ - 1) * 3 + j) * D + 16 * (wave * 4 + ss) + 4 * kq);
+            for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (((wave * 4 + ss) * 3 + j) * 64 + lane) * 4);        // fragment order (FRAG_* below)
         wk_n = wk[min(li, NQ - 1)];
     }
     if constexpr (CROSS) {
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) gv[ss][ct] = ld4(Gb + (size_t)min(ct * 16 + li, HM - 1) * D + 16 * (wave * 4 + ss) + 4 * kq);
+                for (int ct = 0; ct < 3; ++ct) gv[ss][ct] = ld4(Gb + (((wave * 4 + ss) * 3 + ct) * 64 + lane) * 4);
         }
     };
     auto fetch_vw = [&]() {
@@ -190,12 +198,14 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
             for (int sidx = 0; sidx < HMP / 16; ++sidx)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vw[sidx][c] = ld4(VWTb + (size_t)((wave * 4 + c) * 16 + li) * HMP + 16 * sidx + 4 * kq);
+                for (int c = 0; c < 4; ++c) vw[sidx][c] = ld4(VWTb + (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + lane) * 4);
         }
     };
     // the DMA'd vectors must have landed for every wave before anyone reads them: each wave drains its own queue (its rows come
     // with it -- they are needed now anyway), then one barrier
+    IDF_RB_STAMP(9);                                     // every request of the first batch issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDF_RB_STAMP(10);                                    // this wave's share has landed
     __syncthreads();
     raw_a.reduce(ra);
     if constexpr (QAN) {
@@ -501,10 +511,22 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
         sg += Wq[(size_t)(h * HD + d) * D + i] * kd[d];
         sv += vd[d] * Wo[(size_t)i * D + h * HD + d];
     }
-    G[(((size_t)l * B + b) * HM + hm) * D + i] = sg * 0.125f;
-    float *vrow = VWT + (((size_t)l * B + b) * D + i) * HMP;
-    vrow[hm] = sv;
-    if (hm < HMP - HM) vrow[HM + hm] = 0.f;
+    // fragment order (see G_FRAG): the reader's lane is kq * 16 + li
+    auto g_slot = [](int col, int k) {             // score column col (0..47), feature k (0..255)
+        const int ks = k >> 4, kq = (k >> 2) & 3, e = k & 3, ct = col >> 4, li = col & 15;
+        return ((ks * 3 + ct) * 64 + kq * 16 + li) * 4 + e;
+    };
+    auto vw_slot = [](int o, int col) {            // output feature o (0..255), probability column col (0..47)
+        const int wave = o >> 6, c = (o >> 4) & 3, li = o & 15, sidx = col >> 4, kq = (col >> 2) & 3, e = col & 3;
+        return (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + kq * 16 + li) * 4 + e;
+    };
+    float *Gf = G + ((size_t)l * B + b) * G_FRAG, *Vf = VWT + ((size_t)l * B + b) * D * HMP;
+    Gf[g_slot(hm, i)] = sg * 0.125f;
+    Vf[vw_slot(i, hm)] = sv;
+    if (hm < HMP - HM) {
+        Gf[g_slot(HM + hm, i)] = 0.f;
+        Vf[vw_slot(i, HM + hm)] = 0.f;
+    }
     if (i == 0) {
         float s = 0.f;
         for (int d = 0; d < HD; ++d) s += bq[h * HD + d] * kd[d];
@@ -617,7 +639,7 @@ extern "C" int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, c
 }
 
 extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) {
-    return (size_t)L * B * HM * D + (size_t)L * B * D * HMP + (size_t)L * B * HM;
+    return (size_t)L * B * G_FRAG + (size_t)L * B * D * HMP + (size_t)L * B * HM;
 }
 
 extern "C" size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T) {
@@ -633,7 +655,7 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
     if (ws_bytes < (size_t)L * MEM * B * 512 * sizeof(float)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     float *kv = reinterpret_cast<float *>(ws);
-    float *G = memctx, *VWT = memctx + (size_t)L * B * HM * D, *g0 = VWT + (size_t)L * B * D * HMP;
+    float *G = memctx, *VWT = memctx + (size_t)L * B * G_FRAG, *g0 = VWT + (size_t)L * B * D * HMP;
     idf_prof_mark(IDF_K_MEM_PREP, s);
     hipLaunchKernelGGL(mem_kv_kernel, dim3(2, MEM * B, L), dim3(256), 0, s, w->arena, *w, cond, MEM * B, kv);
     hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VWT);
@@ -737,7 +759,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const float *ar = w->arena;
     const int N = B * T, C = w->C;
     Ws k = carve(ws, N);
-    const float *G = memctx, *VWT = memctx + (size_t)L * B * HM * D, *g0 = VWT + (size_t)L * B * D * HMP;
+    const float *G = memctx, *VWT = memctx + (size_t)L * B * G_FRAG, *g0 = VWT + (size_t)L * B * D * HMP;
     const int32_t *tune = w->tune;
 
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
@@ -766,7 +788,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];
-        const float *Gl = G + (size_t)l * B * HM * D, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
+        const float *Gl = G + (size_t)l * B * G_FRAG, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
             if (u_np == NSL)

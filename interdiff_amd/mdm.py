@@ -56,6 +56,20 @@ def qan_constants(queries, rotary=ROTARY_DEFAULT, heads=HEADS):
     return out.astype(np.float32)
 
 
+def qan_fragments(qc):
+    """Qc [NQ, 3, D] -> the row block's MFMA B-operand fragment order [16 k-groups][3 taps][64 lanes][4] (csrc/denoiser.hip FRAG note):
+    lane = kq * 16 + li holds Qc[min(li, NQ-1), tap, 16 kg + 4 kq : +4], so a wave's load instruction reads 1 KiB contiguous."""
+    qc = np.asarray(qc, np.float32)
+    nq, _, d = qc.shape
+    lane = np.arange(64)
+    li, kq = np.minimum(lane & 15, nq - 1), lane >> 4
+    out = np.empty((d // 16, 3, 64, 4), np.float32)
+    for kg in range(d // 16):
+        for e in range(4):
+            out[kg, :, :, e] = qc[li, :, 16 * kg + 4 * kq + e].T
+    return out
+
+
 def _np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
@@ -160,7 +174,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         p, ly = 'decoder.layers.%d.' % l, w.layer[l]
         ly.is_qan = 1 if (p + 'queries') in sd else 0
         if ly.is_qan:
-            ly.qc = ar.add(qan_constants(g(p + 'queries'), rotary))
+            ly.qc = ar.add(qan_fragments(qan_constants(g(p + 'queries'), rotary)))
             ly.wk = ar.add(g(p + 'wk').reshape(-1))
         else:
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
@@ -187,7 +201,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             p, ly = 'encoder.layers.%d.' % l, w.enc_layer[l]
             ly.is_qan = 1 if (p + 'queries') in sd else 0
             if ly.is_qan:
-                ly.qc = ar.add(qan_constants(g(p + 'queries'), rotary))
+                ly.qc = ar.add(qan_fragments(qan_constants(g(p + 'queries'), rotary)))
                 ly.wk = ar.add(g(p + 'wk').reshape(-1))
             else:
                 ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))

@@ -7,6 +7,7 @@
 __device__ long long g_rb_stamps[8192 * 16];
 #define IDF_RB_STAMP(i) do { if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
 #include "denoiser.hip"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -34,7 +35,7 @@ int main(int argc, char **argv) {
         idf_mdm_layer &ly = w.layer[l];
         ly.is_qan = (l >= 1);                 // the last launch is a QaN row block: its stamps are the ones read back
         ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256);
-        ly.qc = take(30 * 256); ly.wk = take(64);
+        ly.qc = take(16 * 3 * 64 * 4); ly.wk = take(64);
         ly.ca_out_b = take(256);
         ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
         for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }
@@ -63,5 +64,16 @@ int main(int argc, char **argv) {
     printf("QaN row block (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", B, T, nwg);
     for (int i = 1; i < 9; ++i) { printf("  %-46s %8.0f\n", names[i], acc[i] / nwg); tot += acc[i] / nwg; }
     printf("  total %.0f\n", tot);
+    double a9 = 0, a10 = 0, spread = 0;
+    long long first = st[0], last = st[0];
+    for (int wgi = 0; wgi < nwg; ++wgi) {
+        a9 += (double)(st[(size_t)wgi * 16 + 9] - st[(size_t)wgi * 16]);
+        a10 += (double)(st[(size_t)wgi * 16 + 10] - st[(size_t)wgi * 16]);
+        first = std::min(first, st[(size_t)wgi * 16]);
+        last = std::max(last, st[(size_t)wgi * 16]);
+    }
+    (void)spread;
+    printf("  inside the first phase: entry -> all requests issued %.0f, -> first batch landed (wave 0) %.0f; workgroup entry times spread over %lld cycles\n",
+           a9 / nwg, a10 / nwg, last - first);
     return 0;
 }

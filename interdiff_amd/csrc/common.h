@@ -78,6 +78,15 @@ __device__ __forceinline__ void idf_store16_wt(float *p, const float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
+// Kernel arguments live in the kernarg segment and reach SGPRs by s_load; the compiler sinks each s_load (+ s_waitcnt) next to its
+// first use, often behind a branch, so a kernel with a dozen pointer arguments starts with a CHAIN of scalar-cache misses (the row
+// block: ~5 k cycles before its first vector load was issued, tools/rowblock_probe.hip).  Naming the arguments in one empty asm
+// at kernel entry forces all of them into SGPRs there: the s_loads go out back to back and the misses overlap.
+template <class T>
+__device__ __forceinline__ void idf_arg_now(T a) { asm volatile("" ::"s"(a)); }
+template <class... A>
+__device__ __forceinline__ void idf_args_now(A... a) { (idf_arg_now(a), ...); }
+
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
 extern bool g_idf_prof_on;
 void idf_prof_mark_slow(int kind, hipStream_t s);

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
                                                         float *__restrict__ parts) {
     __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * PSLOT + 256];
     float *Xs = smem, *ring = smem + XS, *Bs = ring + 3 * PSLOT;             // Bs: the slice's linear1 bias (208 floats)
+    idf_args_now(x2, M, pack, b1p, b2, parts);                              // every kernel argument into SGPRs now (common.h)
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
                                                         float *__restrict__ xn_out, int64_t *__restrict__ step_state,
                                                         int64_t *__restrict__ step_ts, int step_B) {
     __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * LPSLOT];
+    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, xn_out, step_state, step_ts, step_B);
     // sampler bookkeeping of a fused plain step (philox.h): nobody else touches these words while this kernel runs
     if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
     float *Xs = smem, *ring = smem + XS;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
     float *Ps = part + 4 * 3 * 256;               // [TR][PS]
 
-    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride);
+    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, gridDim.x, gridDim.y);
     const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -383,7 +383,7 @@ constexpr int ATTN_MAX_T = 208;
 
 __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
     extern __shared__ __attribute__((aligned(16))) float smx[];
-    idf_args_now(qkv, ctx, T);
+    idf_args_now(qkv, ctx, T, gridDim.x);
     const int TP = (T + 15) & ~15, SS = TP + 4;
     float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + 32 * AS;
     const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 32, tid = threadIdx.x;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
     float *As = smem, *Bs = smem + A_FLOATS;
 
     idf_args_now(g.A, g.lda, g.K, g.lnw, g.lnb, g.a_pstride, g.W, g.bias, g.C, g.ldc, g.M, g.N, g.xn_out, g.resid, g.T, g.ts, g.temb, g.pe, g.n_steps,
-                 g.post_x, g.post_gt, g.post_mask, g.post_table, g.post_state);       // the whole argument block into SGPRs now (common.h)
+                 g.post_x, g.post_gt, g.post_mask, g.post_table, g.post_state, gridDim.x);       // the whole argument block into SGPRs now (common.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int mt_, nt_, wg;
     xcd_tile((g.N + BN - 1) / BN, mt_, nt_, wg);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     float *Aln = smem, *stages = smem + A_LN_FLOATS;
 
     idf_args_now(g.A, g.lda, g.K, g.lnw, g.lnb, g.a_pstride, g.W, g.bias, g.C, g.ldc, g.M, g.N, g.xn_out, g.resid, g.T, g.ts, g.temb, g.pe, g.n_steps,
-                 g.post_x, g.post_gt, g.post_mask, g.post_table, g.post_state);       // the whole argument block into SGPRs now (common.h)
+                 g.post_x, g.post_gt, g.post_mask, g.post_table, g.post_state, gridDim.x);       // the whole argument block into SGPRs now (common.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int mt_, nt_, wg;

@@ -24,6 +24,9 @@
 #include <float.h>
 
 // phase stamps of the row-block kernel exist only in tools/rowblock_probe.hip (which defines the macro before including this file)
+#ifndef IDF_AT_STAMP
+#define IDF_AT_STAMP(i) do { } while (0)        // tools/rowblock_probe.hip: phase stamps of the self-attention kernel
+#endif
 #ifndef IDF_RB_STAMP
 #define IDF_RB_STAMP(i) do { } while (0)
 #endif
@@ -384,6 +387,7 @@ constexpr int ATTN_MAX_T = 208;
 __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
     extern __shared__ __attribute__((aligned(16))) float smx[];
     idf_args_now(qkv, ctx, T, gridDim.x);
+    IDF_AT_STAMP(0);
     const int TP = (T + 15) & ~15, SS = TP + 4;
     float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + 32 * AS;
     const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 32, tid = threadIdx.x;
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
         *reinterpret_cast<float4 *>(Qs + r * AS + d4) = q0 + r < T ? qreg[u] : zero4();
     }
     __syncthreads();
+    IDF_AT_STAMP(1);                                     // K, V, Q in LDS
     // S = Q K^T / 8: wave w owns key tiles w, w+4, ... for both 16-query tiles
     for (int ct = wave; ct < TP / 16; ct += 4) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -439,23 +444,63 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
             for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = acc[rt][r] * 0.125f;
     }
     __syncthreads();
-    {   // row softmax: one 16-lane group per row, 16 rows per sweep; lane l16 owns columns l16, 16+l16, ...
+    IDF_AT_STAMP(2);                                     // S = Q K^T
+    {   // row softmax: one 16-lane group per row, 16 rows per sweep; lane l16 owns columns l16, 16+l16, ... and keeps them in
+        // registers between the max, the exp/sum and the normalisation (one LDS read and one write per element; three run-time loops
+        // over LDS took 7.2 k of the kernel's 19 k cycles)
+        constexpr int NC = ATTN_MAX_T / 16, NC0 = 8;     // columns per lane at the longest clip; the first NC0 cover T <= 128
+        const int ncol = TP >> 4;
+        const bool tail = ncol > NC0;                    // workgroup-uniform: ONE branch around the columns past 128
         for (int i = wave * 4 + kq; i < 32; i += 16) {
             float *row = Ss + i * SS;
-            float mx = -FLT_MAX;
-            for (int j = li; j < T; j += 16) mx = fmaxf(mx, row[j]);
+            float v[NC], mx = -FLT_MAX;
+            // reads are unconditional with clamped addresses (a guard per column makes the compiler wait for every read separately)
+#pragma unroll
+            for (int c = 0; c < NC0; ++c) {
+                const int j = 16 * c + li;
+                v[c] = row[min(j, TP - 1)];
+                v[c] = j < T ? v[c] : -FLT_MAX;
+            }
+            if (tail) {
+#pragma unroll
+                for (int c = NC0; c < NC; ++c) {
+                    const int j = 16 * c + li;
+                    v[c] = row[min(j, TP - 1)];
+                    v[c] = j < T ? v[c] : -FLT_MAX;
+                }
+            } else {
+#pragma unroll
+                for (int c = NC0; c < NC; ++c) v[c] = -FLT_MAX;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mx = fmaxf(mx, v[c]);
             mx = row16_max(mx);
             float sum = 0.f;
-            for (int j = li; j < T; j += 16) {
-                const float e = __expf(row[j] - mx);
-                row[j] = e;
-                sum += e;
+#pragma unroll
+            for (int c = 0; c < NC0; ++c) {
+                v[c] = 16 * c + li < T ? __expf(v[c] - mx) : 0.f;
+                sum += v[c];
             }
-            const float inv = 1.0f / row16_sum(sum);
-            for (int j = li; j < TP; j += 16) row[j] = j < T ? row[j] * inv : 0.f;
+            if (tail) {
+#pragma unroll
+                for (int c = NC0; c < NC; ++c) {
+                    v[c] = 16 * c + li < T ? __expf(v[c] - mx) : 0.f;
+                    sum += v[c];
+                }
+            }
+            const float inv = __builtin_amdgcn_rcpf(row16_sum(sum));
+#pragma unroll
+            for (int c = 0; c < NC0; ++c)
+                if (16 * c + li < TP) row[16 * c + li] = v[c] * inv;
+            if (tail) {
+#pragma unroll
+                for (int c = NC0; c < NC; ++c)
+                    if (16 * c + li < TP) row[16 * c + li] = v[c] * inv;
+            }
         }
     }
     __syncthreads();
+    IDF_AT_STAMP(3);                                     // softmax
     {   // ctx = P V: wave w owns the 16 head-dim columns [16w, 16w+16) for both query tiles
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const int dcol = wave * 16 + li;
@@ -474,6 +519,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
                 if (t < T) ctx[(rowbase + t) * D + h * HD + dcol] = acc[rt][r];
             }
     }
+    IDF_AT_STAMP(4);                                     // P V + store
 }
 
 // ------------------------------------------------------------------------------------

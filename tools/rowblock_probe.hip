@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 __device__ long long g_rb_stamps[8192 * 16];
 #define IDF_RB_STAMP(i) do { if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
+__device__ long long g_at_stamps[8192 * 8];
+#define IDF_AT_STAMP(i) do { if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); } while (0)
 #include "denoiser.hip"
 #include <algorithm>
 #include <cstdio>
@@ -75,5 +77,17 @@ int main(int argc, char **argv) {
     (void)spread;
     printf("  inside the first phase: entry -> all requests issued %.0f, -> first batch landed (wave 0) %.0f; workgroup entry times spread over %lld cycles\n",
            a9 / nwg, a10 / nwg, last - first);
+    {
+        const int nat = ((T + 31) / 32) * 4 * B;
+        std::vector<long long> sa((size_t)nat * 8);
+        CK(hipMemcpyFromSymbol(sa.data(), HIP_SYMBOL(g_at_stamps), sa.size() * 8));
+        const char *an[5] = {"", "K, V, Q -> LDS", "S = Q K^T", "row softmax", "P V + store"};
+        double aa[5] = {0}, at = 0;
+        for (int w = 0; w < nat; ++w)
+            for (int i = 1; i < 5; ++i) aa[i] += (double)(sa[(size_t)w * 8 + i] - sa[(size_t)w * 8 + i - 1]);
+        printf("self-attention (last launch), %d workgroups; mean cycles per phase:\n", nat);
+        for (int i = 1; i < 5; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nat); at += aa[i] / nat; }
+        printf("  total %.0f\n", at);
+    }
     return 0;
 }

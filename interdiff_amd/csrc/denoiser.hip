@@ -174,21 +174,25 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     const int ta = QAN ? t0 - 1 + rown : t0 + rown, tb = t0 + 15 + kq;
     const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && kq < 2 && tb < T;
     Row16Raw<NP> raw_a, raw_b;
+    // issue order is pinned (sched_barrier) because the wait below COUNTS: small vectors, then the token rows, then -- youngest -- the
+    // twelve learned-query fragments, which are not needed before the logits and may keep flying across the first barrier
+    if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
+    if constexpr (CROSS) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
+    }
     if constexpr (QAN) {
         if (wave == 0) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16 (wave-uniform branch)
     }
     raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, li, u_pstride);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (QAN) {
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
             for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (((wave * 4 + ss) * 3 + j) * 64 + lane) * 4);        // fragment order (FRAG_* below)
-        wk_n = wk[min(li, NQ - 1)];
     }
-    if constexpr (CROSS) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
-    }
+    __builtin_amdgcn_sched_barrier(0);
     auto fetch_g = [&]() {
         if constexpr (CROSS) {
 #pragma unroll
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     // the DMA'd vectors must have landed for every wave before anyone reads them: each wave drains its own queue (its rows come
     // with it -- they are needed now anyway), then one barrier
     IDF_RB_STAMP(9);                                     // every request of the first batch issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (QAN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // everything older than the 12 Qc fragment loads has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IDF_RB_STAMP(10);                                    // this wave's share has landed
     __syncthreads();
     raw_a.reduce(ra);

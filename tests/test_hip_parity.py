@@ -789,6 +789,40 @@ def test_denoiser_rejects_unsupported_sizes(mdm):
 
 
 @pytest.mark.gpu
+def test_forward_step_matches_two_call_form_and_rejects_ragged_T(mdm):
+    """interdiff_mdm_forward_step (denoiser + inpaint + posterior + in-kernel noise + state advance in the denoiser's own launches)
+    against interdiff_mdm_forward followed by interdiff_posterior_step_dev on copies of the same state, two consecutive steps, bit
+    for bit; a clip length that is not a multiple of 4 is refused (IDF_E_INVAL), the caller keeps the two-call form."""
+    from interdiff_amd import _lib
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    lib = _lib.load()
+    B, T = 3, 20
+    x, ts0, cond = fx.mdm_inputs(B, T)
+    g = torch.Generator().manual_seed(9)
+    gt, mask = torch.randn(x.shape, generator=g).to(DEV), (torch.rand(x.shape, generator=g) < 0.2).to(DEV).view(torch.uint8)
+    table = create_gaussian_diffusion('cosine', 1000)._table(torch.device(DEV))
+    y = {'cond': cond.to(DEV)}
+    assert mdm.supports_forward_step
+
+    def fresh():
+        st = torch.tensor([700, 11, 1234567, 0, 0, 0, 0, 0], dtype=torch.int64, device=DEV)
+        return x.to(DEV).clone(), torch.full((B,), 700, dtype=torch.int64, device=DEV), st
+    xa, tsa, sta = fresh()
+    xb, tsb, stb = fresh()
+    x0 = torch.empty_like(xb)
+    for step in range(2):
+        mdm.forward_step(xa, tsa, table, sta, gt=gt, mask=mask, y=y)
+        mdm(xb, tsb, y=y, out=x0)
+        _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(xb), _lib.dptr(x0), _lib.dptr(gt), _lib.dptr(mask), xb.numel(), _lib.dptr(table),
+                                                    _lib.dptr(stb), _lib.dptr(tsb), B, _lib.stream()), 'posterior_step_dev')
+        assert torch.equal(xa, xb), 'step %d: %g' % (step, (xa - xb).abs().max())
+        assert torch.equal(tsa, tsb) and torch.equal(sta[:3], stb[:3]) and int(sta[0]) == 699 - step and int(sta[1]) == 12 + step
+    x13, ts13, c13 = fx.mdm_inputs(2, 13)
+    with pytest.raises((RuntimeError, ValueError)):
+        mdm.forward_step(x13.to(DEV), ts13.to(DEV), table, sta, y={'cond': c13.to(DEV)})
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('T,B,P', [(11, 1, 1), (12, 2, 63), (13, 1, 1000), (11, 2, 2048)])
 def test_correction_edge_sizes(smpl, T, B, P):
     """Correction hook with ragged point counts (a single point, below one wave, not a multiple of the workgroup, the

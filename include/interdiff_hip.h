@@ -120,7 +120,7 @@ int interdiff_point2point_signed(const float *x, int32_t P1, const float *y, int
 typedef struct {
     int64_t is_qan;            /* 0: torch TransformerDecoderLayer, 1: QaN               */
     int64_t sa_in_w, sa_in_b, sa_out_w, sa_out_b;   /* std only: [768,256],[768],[256,256],[256] */
-    int64_t qc, wk;            /* QaN only: Qc [NQ][3][256] (pre-rotated, pre-scaled) in MFMA fragment order [16][3][64][4] (mdm.py qan_fragments), wk [NQ] */
+    int64_t qc, wk;            /* QaN only: Qc [NQ][3][256] (pre-rotated, pre-scaled) in MFMA fragment order [16][3][4][NQ][4] (mdm.py qan_fragments), wk [NQ] */
     int64_t ca_q_w, ca_q_b;    /* cross-attn query proj [256,256],[256]                  */
     int64_t ca_kv_w, ca_kv_b;  /* cross-attn key|value proj [512,256],[512]              */
     int64_t ca_out_w, ca_out_b;

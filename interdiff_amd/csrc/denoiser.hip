@@ -114,7 +114,7 @@ constexpr int TR = 16;
 // so that one wave load instruction reads 1 KiB contiguous (8 cache lines).  Fetched from the row-major matrices the same
 // instruction gathered sixteen 64-byte pieces, and the kernel spent 5.9 k of its 20 k cycles just ISSUING its first batch of
 // requests (tools/rowblock_probe.hip): the vector memory pipe handles about one line request every two cycles.
-//   Qc  (weights, mdm.py qan_fragments):      [4][4][3 taps][64][4],  row of lane = query min(li, NQ-1)
+//   Qc  (weights, mdm.py qan_fragments):      [4][4][3 taps][4 kq][NQ][4]: only lanes li < NQ fetch (logit columns >= NQ are never read)
 //   G   (per sample, mem_fold_kernel):        [4][4][3 column tiles][64][4], column = 16 ct + li of the 40 (head, slot) pairs (+8 zero)
 //   VWT (per sample, mem_fold_kernel):        [4 waves = output column quarter][3 k-groups][4 tiles][64][4]
 constexpr int G_FRAG = 4 * 4 * 3 * 64 * 4;     // 12288 floats per (layer, clip)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
     }
     if constexpr (QAN) {
-        if (wave == 0) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16 (wave-uniform branch)
+        if (wave == 0 && kq < 2) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16: two lane groups of wave 0 (exec-masked loads)
     }
     raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, li, u_pstride);
     __builtin_amdgcn_sched_barrier(0);
@@ -190,7 +190,13 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (((wave * 4 + ss) * 3 + j) * 64 + lane) * 4);        // fragment order (FRAG_* below)
+            for (int j = 0; j < 3; ++j) q[ss][j] = zero4();
+        if (li < NQ) {                                   // compact fragment order: only the NQ valid query columns are stored and fetched
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (((wave * 4 + ss) * 3 + j) * (4 * NQ) + kq * NQ + li) * 4);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     auto fetch_g = [&]() {

@@ -57,16 +57,14 @@ def qan_constants(queries, rotary=ROTARY_DEFAULT, heads=HEADS):
 
 
 def qan_fragments(qc):
-    """Qc [NQ, 3, D] -> the row block's MFMA B-operand fragment order [16 k-groups][3 taps][64 lanes][4] (csrc/denoiser.hip FRAG note):
-    lane = kq * 16 + li holds Qc[min(li, NQ-1), tap, 16 kg + 4 kq : +4], so a wave's load instruction reads 1 KiB contiguous."""
+    """Qc [NQ, 3, D] -> the row block's MFMA B-operand fragment order [16 k-groups][3 taps][4 kq][NQ][4] (csrc/denoiser.hip FRAG note):
+    lane (kq, li < NQ) holds Qc[li, tap, 16 kg + 4 kq : +4]; a wave's load instruction reads 4 * NQ * 16 contiguous bytes."""
     qc = np.asarray(qc, np.float32)
     nq, _, d = qc.shape
-    lane = np.arange(64)
-    li, kq = np.minimum(lane & 15, nq - 1), lane >> 4
-    out = np.empty((d // 16, 3, 64, 4), np.float32)
+    out = np.empty((d // 16, 3, 4, nq, 4), np.float32)
     for kg in range(d // 16):
-        for e in range(4):
-            out[kg, :, :, e] = qc[li, :, 16 * kg + 4 * kq + e].T
+        for kq in range(4):
+            out[kg, :, kq] = qc[:, :, 16 * kg + 4 * kq:16 * kg + 4 * kq + 4].transpose(1, 0, 2)
     return out
 
 

@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
         idf_mdm_layer &ly = w.layer[l];
         ly.is_qan = (l >= 1);                 // the last launch is a QaN row block: its stamps are the ones read back
         ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256);
-        ly.qc = take(16 * 3 * 64 * 4); ly.wk = take(64);
+        ly.qc = take(16 * 3 * 40 * 4); ly.wk = take(64);
         ly.ca_out_b = take(256);
         ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
         for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }

@@ -298,40 +298,50 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
 // LayerNorm + linear for the QKV projection of the two standard layers, on the same skeleton as phase 1 above:
 //     C[M, N] = LN(sum of NP slabs of A)[M,256] . W[N,256]^T + bias            (nn.MultiheadAttention in_proj after the previous
 //                                                                               layer's norm3; torch TransformerDecoderLayer)
-// grid = ceil(M/32) x (N / 192) workgroups of 512 threads: a workgroup normalises its 32 rows ONCE (wave w: rows w, w+8, w+16, w+24;
-// the slab sum of common.h ld4_sum, all loads in flight together), parks them in the swizzled LDS image and streams its 192 weight
-// rows as 16 pre-packed k-group chunks ([192 rows][16 k] = 12 KiB, two per ring slot, two slots ahead).  The generic GEMM it
-// replaces tiled N by 64, so every row block was fetched (five slabs) and normalised by TWELVE workgroups instead of four.
+// grid = ceil(M/32) x ceil(N/160) workgroups of 512 threads (50 x 5 = 250 at M = 1600, N = 768: one per CU; the last slice's
+// columns >= N are zero weights and are not stored).  A workgroup normalises its 32 rows ONCE (wave w: rows w, w+8, w+16, w+24;
+// the slab sum of common.h ld4_sum, all loads in flight together), parks them in the swizzled LDS image and streams its 160
+// weight rows as 16 pre-packed k-group chunks ([160 rows][16 k] = 10 KiB, two per ring slot, two slots ahead).  The kernel is
+// bound by its CU's matrix pipe: 2 row tiles x 10 column tiles = 5 tiles per SIMD (waves 0..3 own three column tiles, waves 4..7
+// two; SIMD s holds waves s and s+4).  An earlier geometry -- 4 slices of 192 columns, 200 workgroups -- left 56 CUs idle and
+// put 6 tiles on every SIMD (12.3 k instead of 10.2 k MFMA cycles per workgroup); the generic GEMM before it tiled N by 64, so
+// every row block was fetched (five slabs) and normalised by TWELVE workgroups.
 // The slice-0 workgroups also write the normalised rows (the residual of the attention block) to xn_out.
-constexpr int LCT = 12, LHS = LCT * 16;                 // column tiles / columns per workgroup
+constexpr int LCT = 10, LHS = LCT * 16;                 // column tiles / columns per workgroup
 constexpr int LW1C = LHS * 16;                          // floats per k-group chunk
-constexpr int LPSLOT = 2 * LW1C;                        // floats per ring slot (24 KiB)
-static_assert(2 * LW1C / 256 == 3 * NW, "three DMA instructions per wave per pair");
+constexpr int LPSLOT = 2 * LW1C;                        // floats per ring slot (20 KiB)
+constexpr int LPI = 2 * LW1C / 256;                     // 1-KiB DMA instructions per pair: 20 = 8 + 8 + 4 (waves 0..3 issue a third one)
+static_assert(LPI == 2 * NW + NW / 2, "pair = two instructions per wave + a third for the low half");
 
 template <int NP>
 __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__ A, size_t a_pstride, const float *__restrict__ lnw,
                                                         const float *__restrict__ lnb, int M, const float *__restrict__ pack,
-                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
                                                         float *__restrict__ xn_out, int64_t *__restrict__ step_state,
                                                         int64_t *__restrict__ step_ts, int step_B) {
     __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * LPSLOT];
-    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, xn_out, step_state, step_ts, step_B);
+    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
     // sampler bookkeeping of a fused plain step (philox.h): nobody else touches these words while this kernel runs
     if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
     float *Xs = smem, *ring = smem + XS;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsl = gridDim.y, mt = blockIdx.x, sl = blockIdx.y, m0 = mt * BM, n0 = sl * LHS;
+    const int mt = blockIdx.x, sl = blockIdx.y, m0 = mt * BM, n0 = sl * LHS;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * (16 * LW1C));
     const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
     const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
     const int key = (4 - (li >> 2)) & 3;
-    (void)nsl;
-    auto issue_pair = [&](int P) {                        // pair P = chunks 2P, 2P+1: 24 KiB contiguous in the stream and in slot P % 3
+    const bool low = wave < NW / 2;                       // waves 0..3: a third DMA instruction per pair, a third column tile
+    auto issue_pair = [&](int P) {                        // pair P = chunks 2P, 2P+1: 20 KiB contiguous in the stream and in slot P % 3
         if (P >= 8) return;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            idf_dma16_s(stream, vsrc + (uint32_t)(P * 2 * LW1C * 4) + 8192u * j, sdst + (uint32_t)((P % 3) * LPSLOT * 4) + 8192u * j);
+        const uint32_t so = (uint32_t)(P * 2 * LW1C * 4), dof = (uint32_t)((P % 3) * LPSLOT * 4);
+        idf_dma16_s(stream, vsrc + so, sdst + dof);
+        idf_dma16_s(stream, vsrc + so + 8192u, sdst + dof + 8192u);
+        if (low) idf_dma16_s(stream, vsrc + so + 16384u, sdst + dof + 16384u);
+    };
+    auto wait_one_pair_flying = [&]() {                   // everything older than this wave's instructions of the youngest pair has landed
+        if (low) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     };
     issue_pair(0);
     issue_pair(1);
@@ -359,12 +369,12 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
             if (xn_out && sl == 0 && m0 + row < M) *reinterpret_cast<float4 *>(xn_out + (size_t)(m0 + row) * D + lane * 4) = x;
         }
     }
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // pair 0 (and everything older) has landed; pair 1's three instructions may fly
+    wait_one_pair_flying();                               // pair 0 (and everything older) has landed; pair 1 may fly
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // wave w: row tile w & 1, column tiles 3 (w >> 1) .. +2
-    const int r1 = wave & 1, c0 = (wave >> 1) * 3;
+    // wave w: row tile w & 1; column tiles 3 (w >> 1) .. +2 (w < 4) or 6 + 2 ((w - 4) >> 1) .. +1 (w >= 4)
+    const int r1 = wave & 1, c0 = low ? (wave >> 1) * 3 : 6 + ((wave - 4) >> 1) * 2;
     f32x4 acc[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -379,13 +389,16 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
         const float *sb = wb[(c >> 1) % 3] + (c & 1) * LW1C;
         b[0] = ldsv4(sb);
         b[1] = ldsv4(sb + 256);
-        b[2] = ldsv4(sb + 512);
+        if (low) b[2] = ldsv4(sb + 512);
     };
     auto mma3 = [&](const float4 &a, const float4 (&b)[3]) {
-        IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x); IDF_FFN_MFMA(acc[2], a.x, b[2].x);
-        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y); IDF_FFN_MFMA(acc[2], a.y, b[2].y);
-        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z); IDF_FFN_MFMA(acc[2], a.z, b[2].z);
-        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w); IDF_FFN_MFMA(acc[2], a.w, b[2].w);
+        IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x);
+        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y);
+        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z);
+        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w);
+        if (low) {
+            IDF_FFN_MFMA(acc[2], a.x, b[2].x); IDF_FFN_MFMA(acc[2], a.y, b[2].y); IDF_FFN_MFMA(acc[2], a.z, b[2].z); IDF_FFN_MFMA(acc[2], a.w, b[2].w);
+        }
     };
     rd(0, a0, b0);
 #pragma unroll
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
         issue_pair(P + 2);
         rd(2 * P + 1, a1, b1f);
         mma3(a0, b0);
-        if (P + 2 < 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // pair P+1 has landed; pair P+2 may keep flying
+        if (P + 2 < 8) wait_one_pair_flying();            // pair P+1 has landed; pair P+2 may keep flying
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -405,15 +418,17 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
     float *Cs = ring;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const float bv = bias[n0 + (c0 + j) * 16 + li];
+        if (j < 2 || low) {
+            const float bv = bias[min(n0 + (c0 + j) * 16 + li, N - 1)];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Cs[(r1 * 16 + kq * 4 + rr) * LCS + (c0 + j) * 16 + li] = acc[j][rr] + bv;
+            for (int rr = 0; rr < 4; ++rr) Cs[(r1 * 16 + kq * 4 + rr) * LCS + (c0 + j) * 16 + li] = acc[j][rr] + bv;
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < BM * (LHS / 4) / NT; ++it) {
+    for (int it = 0; it < (BM * (LHS / 4) + NT - 1) / NT; ++it) {
         const int idx = tid + it * NT, row = idx / (LHS / 4), c4 = (idx - row * (LHS / 4)) << 2, gr = m0 + row;
-        if (gr < M) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, ldsv4(Cs + row * LCS + c4));
+        if (idx < BM * (LHS / 4) && gr < M && n0 + c4 < N) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, ldsv4(Cs + row * LCS + c4));
     }
 }
 
@@ -421,8 +436,8 @@ template <int NP>
 inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
                              const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
                              int64_t *step_ts = nullptr, int step_B = 0) {
-    hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)idf_cdiv(M, BM), (unsigned)(N / LHS)), dim3(NT), 0, s, A, a_pstride, lnw, lnb, M,
-                       pack, bias, C, ldc, xn_out, step_state, step_ts, step_B);
+    hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)idf_cdiv(M, BM), (unsigned)idf_cdiv(N, LHS)), dim3(NT), 0, s, A, a_pstride, lnw, lnb,
+                       M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
 }
 
 inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {

@@ -111,12 +111,18 @@ def pack_ffn(w1, w2):
     return out
 
 
-def pack_linear192(w):
-    """[N,256] weight (N % 192 == 0) -> the LayerNorm+linear kernel's stream (csrc/ffn.h ln_linear_kernel): per 192-row slice the 16
-    k-group chunks [192 rows][16 k], each in the swizzled LDS image of ``_swizzle16``."""
+QKV_SLICE = 160          # output columns per workgroup of the LayerNorm+linear kernel (csrc/ffn.h LHS)
+
+
+def pack_linear160(w):
+    """[N,256] weight -> the LayerNorm+linear kernel's stream (csrc/ffn.h ln_linear_kernel): per 160-row slice (the last one zero-padded
+    past N) the 16 k-group chunks [160 rows][16 k], each in the swizzled LDS image of ``_swizzle16``."""
     w = np.asarray(w, np.float32)
-    assert w.shape[1] == D and w.shape[0] % 192 == 0
-    out = [_swizzle16(w[n0:n0 + 192, 16 * g:16 * g + 16]).ravel() for n0 in range(0, w.shape[0], 192) for g in range(D // 16)]
+    assert w.shape[1] == D
+    ns = -(-w.shape[0] // QKV_SLICE)
+    wp = np.zeros((ns * QKV_SLICE, D), np.float32)
+    wp[:w.shape[0]] = w
+    out = [_swizzle16(wp[n0:n0 + QKV_SLICE, 16 * g:16 * g + 16]).ravel() for n0 in range(0, wp.shape[0], QKV_SLICE) for g in range(D // 16)]
     return np.concatenate(out)
 
 
@@ -176,7 +182,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.wk = ar.add(g(p + 'wk').reshape(-1))
         else:
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
-            ly.sa_in_pack = ar.add(pack_linear192(g(p + 'self_attn.in_proj_weight')))
+            ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
             ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
@@ -203,7 +209,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
                 ly.wk = ar.add(g(p + 'wk').reshape(-1))
             else:
                 ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
-                ly.sa_in_pack = ar.add(pack_linear192(g(p + 'self_attn.in_proj_weight')))
+                ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
                 ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
                 ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
                 ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))

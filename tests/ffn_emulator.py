@@ -178,7 +178,7 @@ def emulate_ffn(x2, pack, b1p, b2, late):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # csrc/ffn.h ln_linear_kernel (LayerNorm + linear of the QKV projection), one workgroup
-LCT, LHS = 12, 192
+LCT, LHS = 10, 160
 LW1C = LHS * 16
 LPSLOT = 2 * LW1C
 
@@ -195,8 +195,10 @@ def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
         mu = x.mean(1, keepdims=True)
         var = ((x - mu) ** 2).mean(1, keepdims=True)
         x = (x - mu) / np.sqrt(var + 1e-5) * lnw + lnb
+    tiles = [(w & 1, (w >> 1) * 3 if w < 4 else 6 + ((w - 4) >> 1) * 2, 3 if w < 4 else 2) for w in range(NW)]      # (row tile, first column tile, count)
+    assert sorted((r, c0 + j) for r, c0, n in tiles for j in range(n)) == [(r, c) for r in range(2) for c in range(LCT)]
     for mt in range((M + BM - 1) // BM):
-        for sl in range(N // LHS):
+        for sl in range((N + LHS - 1) // LHS):
             m0, n0 = mt * BM, sl * LHS
             stream = pack[sl * 16 * LW1C:(sl + 1) * 16 * LW1C].astype(np.float64)
             Xs, ring = np.zeros(BM * D), np.full(3 * LPSLOT, np.nan)
@@ -208,9 +210,11 @@ def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
                 ops = []
                 for wave in range(NW):
                     for j in range(3):
-                        off = wave * 256 + 2048 * j                      # floats: (wave*1024 + 8192 j) bytes
-                        src = P * 2 * LW1C + off
-                        ops.append(((P % 3) * LPSLOT + off, stream[src:src + 256].copy()))
+                        if j < 2 or wave < 4:                            # the third instruction: waves 0..3
+                            off = wave * 256 + 2048 * j                  # floats: (wave*1024 + 8192 j) bytes
+                            src = P * 2 * LW1C + off
+                            ops.append(((P % 3) * LPSLOT + off, stream[src:src + 256].copy()))
+                assert len(ops) * 256 == 2 * LW1C
                 if late:
                     pending[P] = ops
                 else:
@@ -228,14 +232,14 @@ def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
                     p = l ^ (row & 15)
                     Xs[row * D + p * 4:row * D + p * 4 + 4] = src[l * 4:l * 4 + 4]
             land(0)
-            acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(3)}
+            acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(tiles[w][2])}
 
             def rd(w, c):
-                r1, c0 = w & 1, (w >> 1) * 3
+                r1, c0, n = tiles[w]
                 rows = r1 * 16 + li
                 a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
                 bs = []
-                for j in range(3):
+                for j in range(n):
                     base = ((c >> 1) % 3) * LPSLOT + (c & 1) * LW1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
                     bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
                 return a, bs
@@ -261,10 +265,12 @@ def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
                     mma(w, f1[w])
             assert not pending
             for w in range(NW):
-                r1, c0 = w & 1, (w >> 1) * 3
-                for j in range(3):
+                r1, c0, n = tiles[w]
+                for j in range(n):
                     for rr in range(16):
                         gr = m0 + r1 * 16 + rr
-                        if gr < M:
-                            C[gr, n0 + (c0 + j) * 16:n0 + (c0 + j) * 16 + 16] = acc[(w, j)][rr] + bias[n0 + (c0 + j) * 16:n0 + (c0 + j) * 16 + 16]
+                        for cc in range(16):
+                            col = n0 + (c0 + j) * 16 + cc
+                            if gr < M and col < N:
+                                C[gr, col] = acc[(w, j)][rr, cc] + bias[col]
     return C

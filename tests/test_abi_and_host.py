@@ -204,17 +204,17 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
 
 def test_qkv_pack_and_kernel_addressing_by_emulation():
     """The LayerNorm+linear kernel of the QKV projection (csrc/ffn.h ln_linear_kernel) restated lane by lane on the stream
-    pack_linear192 builds: LN(sum of the five slabs) . W^T + b for a ragged row count, DMA applied at issue and at the wait."""
+    pack_linear160 builds: LN(sum of the five slabs) . W^T + b for a ragged row count, DMA applied at issue and at the wait."""
     import numpy as np
-    from interdiff_amd.mdm import pack_linear192
+    from interdiff_amd.mdm import pack_linear160
     from tests.ffn_emulator import emulate_ln_linear
     rs = np.random.RandomState(1)
     M, N = 37, 768
     slabs = rs.standard_normal((5, M, 256)).astype(np.float32)
     w = (rs.standard_normal((N, 256)) / 16).astype(np.float32)
     b, lnw, lnb = (rs.standard_normal(n).astype(np.float32) for n in (N, 256, 256))
-    pack = pack_linear192(w)
-    assert pack.size == N * 256
+    pack = pack_linear160(w)
+    assert pack.size == 5 * 160 * 256                       # 768 rows in 5 slices of 160, the tail zero
     x = slabs.astype(np.float64).sum(0)
     xn = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * lnw + lnb
     for late in (False, True):

@@ -14,16 +14,17 @@ using namespace idf_ffn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static const int G4[4] = {0, 3, 2, 1};
-// mdm.py pack_linear192
-static void pack192(const std::vector<float> &w, int N, std::vector<float> &out) {
-    out.assign((size_t)N * D, 0.f);
+// mdm.py pack_linear160
+static void pack160(const std::vector<float> &w, int N, std::vector<float> &out) {
+    const int ns = (N + LHS - 1) / LHS;
+    out.assign((size_t)ns * LHS * D, 0.f);
     size_t o = 0;
-    for (int n0 = 0; n0 < N; n0 += 192)
+    for (int n0 = 0; n0 < ns * LHS; n0 += LHS)
         for (int g = 0; g < 16; ++g)
-            for (int r = 0; r < 192; ++r)
+            for (int r = 0; r < LHS; ++r)
                 for (int p = 0; p < 4; ++p) {
                     const int cell = p ^ G4[(r >> 2) & 3];
-                    for (int e = 0; e < 4; ++e) out[o++] = w[(size_t)(n0 + r) * D + 16 * g + cell * 4 + e];
+                    for (int e = 0; e < 4; ++e) out[o++] = n0 + r < N ? w[(size_t)(n0 + r) * D + 16 * g + cell * 4 + e] : 0.f;
                 }
 }
 
@@ -34,13 +35,13 @@ int main(int argc, char **argv) {
     srand(3);
     for (auto &v : A) v = rand() / (float)RAND_MAX - 0.5f;
     float *dA, *dP, *dB, *dC, *dX;
-    CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dP, W.size() * 4)); CK(hipMalloc(&dB, N * 4)); CK(hipMalloc(&dC, Cg.size() * 4));
+    CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dP, (size_t)((N + LHS - 1) / LHS) * LHS * D * 4)); CK(hipMalloc(&dB, N * 4)); CK(hipMalloc(&dC, Cg.size() * 4));
     CK(hipMalloc(&dX, xn.size() * 4));
     CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, bias.data(), N * 4, hipMemcpyHostToDevice));
     for (int k0 : {0, 1, 4, 5, 16, 21, 37, 100, 255}) {
         for (size_t i = 0; i < W.size(); ++i) W[i] = ((int)(i % D) == k0) ? 1.f : 0.f;
-        pack192(W, N, P);
+        pack160(W, N, P);
         CK(hipMemcpy(dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(dC, 0xff, Cg.size() * 4));
         launch_ln_linear<1>(0, dA, 0, nullptr, nullptr, M, N, dP, dB, dC, N, dX);
@@ -64,7 +65,7 @@ int main(int argc, char **argv) {
     }
     // random weights
     for (auto &v : W) v = rand() / (float)RAND_MAX - 0.5f;
-    pack192(W, N, P);
+    pack160(W, N, P);
     CK(hipMemcpy(dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
     launch_ln_linear<1>(0, dA, 0, nullptr, nullptr, M, N, dP, dB, dC, N, dX);
     CK(hipDeviceSynchronize());

@@ -110,8 +110,9 @@ template <int MODE = 0>
 __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
                                                         const float *__restrict__ b1p, const float *__restrict__ b2,
                                                         float *__restrict__ parts) {
-    __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * PSLOT + 256];
+    __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * PSLOT + 256 + 512];
     float *Xs = smem, *ring = smem + XS, *Bs = ring + 3 * PSLOT;             // Bs: the slice's linear1 bias (208 floats)
+    float *scr = Bs + 256;                                                  // 2 x 64 x 4 floats: the helpers' half of the shared tile (below)
     idf_args_now(x2, M, pack, b1p, b2, parts);                              // every kernel argument into SGPRs now (common.h)
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
@@ -157,10 +158,14 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
     };
 
     // ---- phase-1 tile map: SIMD (w & 3) holds waves w and w+4; row tile (w>>1)&1; the 13 column tiles go 4|3 (waves w, w+4 of the
-    // SIMDs with w even) and 3|3 (w odd): 7,6,7,6 tiles per SIMD
+    // SIMDs with w even) and 3|3 (w odd): 7,6,7,6 tiles per SIMD -- so the fourth tile of waves 0 / 2 (column tile 3) is SHARED in K
+    // with waves 1 / 3 (the same row tile on the neighbouring SIMD): the owner accumulates it over the even chunks and the last one,
+    // the helper over the other odd ones; the helper's partial tile crosses through LDS around the last barrier of the loop.  Between
+    // two barriers (one per pair, in its middle) every SIMD then issues 13 tile groups instead of 14 | 12.
     const int r1 = (wave >> 1) & 1;
     const int c0 = (wave & 1) ? (wave < 4 ? 7 : 10) : (wave < 4 ? 0 : 4);
-    const bool four = wave == 0 || wave == 2;
+    const bool four = wave == 0 || wave == 2;        // owner of (row tile r1, column tile 3): even chunks
+    const bool help = wave == 1 || wave == 3;        // helper for that tile: odd chunks
 
     // ---- prologue: the bias slice (one DMA, the oldest in the queue), the x2 rows (row i = DMA instruction i, source chunk =
     // position ^ (i & 15)), the first two chunk pairs.  Every global->LDS move of this kernel is an asm DMA: no compiler-visible
@@ -184,11 +189,14 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 a0, a1, b0[4], b1f[4];
-    const float *xb1[4], *wb1[3];
+    const float *xb1[4], *wb1[3], *wbx[3];
 #pragma unroll
     for (int m = 0; m < 4; ++m) xb1[m] = Xs + (r1 * 16 + li) * D + (((kq ^ li) ^ (4 * m)) << 2);
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) wb1[s3] = ring + s3 * PSLOT + ((kq ^ key) << 2) + li * 16 + c0 * 256;
+    for (int s3 = 0; s3 < 3; ++s3) {
+        wb1[s3] = ring + s3 * PSLOT + ((kq ^ key) << 2) + li * 16 + c0 * 256;
+        wbx[s3] = ring + s3 * PSLOT + ((kq ^ key) << 2) + li * 16 + 3 * 256;          // the shared column tile 3
+    }
     auto read1 = [&](int c, float4 &a, float4 (&b)[4]) {        // fragments of W1 k-group c (chunk c & 1 of pair c >> 1)
         if constexpr (MODE == 4) { if (c > 1) return; }
         a = ldsv4(xb1[c & 3] + 64 * (c >> 2));
@@ -196,19 +204,24 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         b[0] = ldsv4(sb);
         b[1] = ldsv4(sb + 256);
         b[2] = ldsv4(sb + 512);
-        if (four) b[3] = ldsv4(sb + 768);
+        if ((c & 1) && c != 2 * NP1 - 1 ? help : four) b[3] = ldsv4(wbx[(c >> 1) % 3] + (c & 1) * W1C);
     };
     read1(0, a0, b0);
 #pragma unroll
     for (int P = 0; P < NP1; ++P) {
         issue_pair(P + 2);                               // into the slot of pair P-1 (every wave is past the barrier that followed its reads)
         read1(2 * P + 1, a1, b1f);
-        mma_group<MODE>(acc, a0, b0, four);
+        // the helpers' half of the shared tile is complete after chunk 13: it crosses to the owners around the last barrier
+        if (P == NP1 - 1 && help) *reinterpret_cast<f32x4 *>(scr + ((wave >> 1) * 64 + lane) * 4) = acc[3];
+        mma_group<MODE>(acc, a0, b0, four);              // even chunk: the owners take the shared tile
         wait_pair_before(P + 2);                         // pair P+1 has landed; pair P+2 may keep flying
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (P + 1 < NP1) read1(2 * P + 2, a0, b0);
-        mma_group<MODE>(acc, a1, b1f, four);
+        f32x4 other = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (P == NP1 - 1 && four) other = *reinterpret_cast<const f32x4 *>(scr + ((wave >> 1) * 64 + lane) * 4);
+        mma_group<MODE>(acc, a1, b1f, P == NP1 - 1 ? four : help);          // odd chunk: the helpers do, except the last one
+        if (P == NP1 - 1 && four) acc[3] += other;
         stamp();
     }
 

@@ -86,7 +86,7 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
         c0 = ((7 if wave < 4 else 10) if wave & 1 else (0 if wave < 4 else 4))
         nct = 4 if wave in (0, 2) else 3
         maps.append((r1, c0, nct))
-        for j in range(nct):
+        for j in range(4 if wave < 4 else 3):         # waves 1, 3 hold the odd-chunk half of their neighbour's fourth tile in acc[3]
             hid_acc[(wave, j)] = np.zeros((16, 16))
 
     def read1(wave, c):
@@ -94,8 +94,12 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
         rows = r1 * 16 + li
         a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
         bs = []
-        for j in range(nct):
+        for j in range(3):
             base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
+            bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
+        # the shared column tile 3: owners (waves 0, 2) on even chunks and the last one, helpers (waves 1, 3) on the other odd chunks
+        if (wave in (1, 3)) if (c & 1 and c != 15) else (wave in (0, 2)):
+            base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + 3 * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
     frag0 = [read1(w, 0) for w in range(NW)]
@@ -113,6 +117,9 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
             a, bs = frag1[w]
             for j, b in enumerate(bs):
                 mfma_group(hid_acc[(w, j)], a, b)
+    assert maps[0][0] == maps[1][0] and maps[2][0] == maps[3][0]            # owner and helper work on the same row tile
+    hid_acc[(0, 3)] += hid_acc.pop((1, 3))
+    hid_acc[(2, 3)] += hid_acc.pop((3, 3))
     # epilogue 1: gelu(acc + b1) -> Xs (swizzled), D layout: lane (li, kq), reg rr -> row kq*4+rr, col li
     for w in range(NW):
         r1, c0, nct = maps[w]

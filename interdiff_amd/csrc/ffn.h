@@ -100,7 +100,7 @@ __device__ __forceinline__ void mma_group4(f32x4 (&acc)[4], const float4 &a, con
 // b1p [NSL*208] (linear1 bias, zero-padded), b2 [256], parts [NSL][M][256].  grid = ceil(M/32) * NSL workgroups of 512 threads.
 // MODE 0 is the product kernel.  The other instantiations exist only in tools/ffn_probe.hip (ablations for the time budget: 1 = no
 // MFMAs, 2 = no DMA after the prologue, 3 = s_memtime stamps of workgroup phases behind the slabs, 4 = no LDS fragment reads in the
-// loops); `if constexpr` keeps every trace of them out of MODE 0.
+// loops, 5 = no barrier in the loops (wrong results: what the per-pair synchronisation costs)); `if constexpr` keeps every trace of them out of MODE 0.
 //
 // Every loop over chunk pairs is FULLY UNROLLED and the geometry is constant, so stream offsets, ring slots, DMA counts and LDS
 // fragment addresses are immediates: the scalar unit (one per CU, shared by the eight waves) has almost nothing to do.  A first
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         mma_group<MODE>(acc, a0, b0, four);              // even chunk: the owners take the shared tile
         wait_pair_before(P + 2);                         // pair P+1 has landed; pair P+2 may keep flying
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (MODE != 5) __builtin_amdgcn_s_barrier();
         if (P + 1 < NP1) read1(2 * P + 2, a0, b0);
         f32x4 other = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P == NP1 - 1 && four) other = *reinterpret_cast<const f32x4 *>(scr + ((wave >> 1) * 64 + lane) * 4);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         mma_group4<MODE>(acc, a0, b0);
         wait_pair_before(P + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (MODE != 5) __builtin_amdgcn_s_barrier();
         if (q + 2 < NTILE) read2(q + 2, a0, b0);
         if (two) mma_group4<MODE>(acc, a1, b1f);
         stamp();

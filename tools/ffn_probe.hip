@@ -39,14 +39,15 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&parts, (size_t)NSL * M * D * 4 + (size_t)nwg * 32 * 8));
     const float *pack = d, *x2 = d + (size_t)2 * D * FF, *b1 = x2 + (size_t)M * D, *b2 = b1 + FF;
     const double fl = 2.0 * 2.0 * M * D * FF;
-    const char *names[5] = {"product", "no MFMA", "no DMA after prologue", "stamped", "no LDS fragment reads in the loops"};
-    float us[5];
+    const char *names[6] = {"product", "no MFMA", "no DMA after prologue", "stamped", "no LDS fragment reads in the loops", "no barrier in the loops (wrong results)"};
+    float us[6];
     us[0] = run<0>(x2, M, pack, b1, b2, parts, 200);
     us[1] = run<1>(x2, M, pack, b1, b2, parts, 200);
     us[2] = run<2>(x2, M, pack, b1, b2, parts, 200);
     us[4] = run<4>(x2, M, pack, b1, b2, parts, 200);
+    us[5] = run<5>(x2, M, pack, b1, b2, parts, 200);
     us[3] = run<3>(x2, M, pack, b1, b2, parts, 50);
-    for (int i = 0; i < 5; ++i) printf("M=%d  %-36s %8.2f us  (%.1f TFLOP/s equivalent)\n", M, names[i], us[i], fl / us[i] / 1e6);
+    for (int i = 0; i < 6; ++i) printf("M=%d  %-36s %8.2f us  (%.1f TFLOP/s equivalent)\n", M, names[i], us[i], fl / us[i] / 1e6);
     std::vector<long long> st((size_t)nwg * 32);
     CK(hipMemcpy(st.data(), reinterpret_cast<char *>(parts) + (size_t)NSL * M * D * 4, st.size() * 8, hipMemcpyDeviceToHost));
     // stamps: 0 entry, 1 after prologue barrier, 2..9 phase-1 pairs, 10 after the gelu epilogue, 11.. phase-2 pairs, last = exit

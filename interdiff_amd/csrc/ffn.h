@@ -84,6 +84,35 @@ __device__ __forceinline__ void mma_group(f32x4 (&acc)[4], const float4 &a, cons
         IDF_FFN_MFMA(acc[3], a.x, b[3].x); IDF_FFN_MFMA(acc[3], a.y, b[3].y); IDF_FFN_MFMA(acc[3], a.z, b[3].z); IDF_FFN_MFMA(acc[3], a.w, b[3].w);
     }
 }
+// the same group in two parts, so that LDS reads can be issued BETWEEN them: right after a barrier all eight waves want to fetch
+// their next fragments at once, and a wave whose MFMAs sit behind its own reads in program order leaves the matrix pipe idle until
+// the LDS has taken them
+template <int MODE>
+__device__ __forceinline__ void mma_head(f32x4 (&acc)[4], const float4 &a, const float4 (&b)[4], bool ext, bool all4) {
+    if constexpr (MODE == 1) return;
+    IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x); IDF_FFN_MFMA(acc[2], a.x, b[2].x);
+    if (all4) IDF_FFN_MFMA(acc[3], a.x, b[3].x);
+    (void)ext;
+}
+template <int MODE>
+__device__ __forceinline__ void mma_tail(f32x4 (&acc)[4], const float4 &a, const float4 (&b)[4], bool ext, bool all4) {
+    if constexpr (MODE == 1) {
+        asm volatile("" ::"v"(a.x), "v"(b[0].x), "v"(b[1].y), "v"(b[2].z), "v"(b[3].w));
+        return;
+    }
+    if (all4) {
+        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y); IDF_FFN_MFMA(acc[2], a.y, b[2].y); IDF_FFN_MFMA(acc[3], a.y, b[3].y);
+        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z); IDF_FFN_MFMA(acc[2], a.z, b[2].z); IDF_FFN_MFMA(acc[3], a.z, b[3].z);
+        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w); IDF_FFN_MFMA(acc[2], a.w, b[2].w); IDF_FFN_MFMA(acc[3], a.w, b[3].w);
+    } else {
+        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y); IDF_FFN_MFMA(acc[2], a.y, b[2].y);
+        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z); IDF_FFN_MFMA(acc[2], a.z, b[2].z);
+        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w); IDF_FFN_MFMA(acc[2], a.w, b[2].w);
+        if (ext) {
+            IDF_FFN_MFMA(acc[3], a.x, b[3].x); IDF_FFN_MFMA(acc[3], a.y, b[3].y); IDF_FFN_MFMA(acc[3], a.z, b[3].z); IDF_FFN_MFMA(acc[3], a.w, b[3].w);
+        }
+    }
+}
 template <int MODE>
 __device__ __forceinline__ void mma_group4(f32x4 (&acc)[4], const float4 &a, const float4 (&b)[4]) {
     if constexpr (MODE == 1) {
@@ -215,12 +244,16 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         if (P == NP1 - 1 && help) *reinterpret_cast<f32x4 *>(scr + ((wave >> 1) * 64 + lane) * 4) = acc[3];
         mma_group<MODE>(acc, a0, b0, four);              // even chunk: the owners take the shared tile
         wait_pair_before(P + 2);                         // pair P+1 has landed; pair P+2 may keep flying
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin: the compiler then KNOWS the LDS queue is empty (an asm wait is invisible to its own counting)
         if constexpr (MODE != 5) __builtin_amdgcn_s_barrier();
+        const bool ext_odd = P == NP1 - 1 ? four : help;                    // odd chunk: the helpers take the shared tile, except the last one
+        mma_head<MODE>(acc, a1, b1f, ext_odd, false);                       // matrix pipe first, then the LDS requests of the next chunk
+        __builtin_amdgcn_sched_barrier(0);
         if (P + 1 < NP1) read1(2 * P + 2, a0, b0);
         f32x4 other = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P == NP1 - 1 && four) other = *reinterpret_cast<const f32x4 *>(scr + ((wave >> 1) * 64 + lane) * 4);
-        mma_group<MODE>(acc, a1, b1f, P == NP1 - 1 ? four : help);          // odd chunk: the helpers do, except the last one
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tail<MODE>(acc, a1, b1f, ext_odd, false);
         if (P == NP1 - 1 && four) acc[3] += other;
         stamp();
     }
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin: the compiler then KNOWS the LDS queue is empty (an asm wait is invisible to its own counting)
     __builtin_amdgcn_s_barrier();
     stamp();
 
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
         if (two) read2(q + 1, a1, b1f);
         mma_group4<MODE>(acc, a0, b0);
         wait_pair_before(P + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin: the compiler then KNOWS the LDS queue is empty (an asm wait is invisible to its own counting)
         if constexpr (MODE != 5) __builtin_amdgcn_s_barrier();
         if (q + 2 < NTILE) read2(q + 2, a0, b0);
         if (two) mma_group4<MODE>(acc, a1, b1f);
@@ -383,7 +416,7 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
         }
     }
     wait_one_pair_flying();                               // pair 0 (and everything older) has landed; pair 1 may fly
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin: the compiler then KNOWS the LDS queue is empty (an asm wait is invisible to its own counting)
     __builtin_amdgcn_s_barrier();
 
     // wave w: row tile w & 1; column tiles 3 (w >> 1) .. +2 (w < 4) or 6 + 2 ((w - 4) >> 1) .. +1 (w >= 4)
@@ -421,7 +454,7 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
         mma3(a0, b0);
         if (P + 2 < 8) wait_one_pair_flying();            // pair P+1 has landed; pair P+2 may keep flying
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin: the compiler then KNOWS the LDS queue is empty (an asm wait is invisible to its own counting)
         __builtin_amdgcn_s_barrier();
         if (P + 1 < 8) rd(2 * P + 2, a0, b0);
         mma3(a1, b1f);

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     }
     // chunk 0 landed (later chunks may still fly); the compiler's own waits for the ordinary loads above can only be stricter
     wait_landed(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) as a builtin: visible to the compiler's own wait counting (ffn.h)
     __builtin_amdgcn_s_barrier();
     IDF_PROBE_STAMP(g, wg, 1);
 
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
         }
         // chunk kc+1 must have landed before anyone reads it; the chunks issued after it may keep flying
         wait_landed(kc + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) as a builtin: visible to the compiler's own wait counting (ffn.h)
         __builtin_amdgcn_s_barrier();
         st = st == NS - 1 ? 0 : st + 1;
     }

@@ -45,7 +45,7 @@ B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
 FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
-DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r02f'       # the build the roofline block (and profiles/traffic.json) speaks about
+DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r02g'       # the build the roofline block (and profiles/traffic.json) speaks about
 
 
 def tt(d, dev=None):

@@ -817,6 +817,14 @@ def test_forward_step_matches_two_call_form_and_rejects_ragged_T(mdm):
                                                     _lib.dptr(stb), _lib.dptr(tsb), B, _lib.stream()), 'posterior_step_dev')
         assert torch.equal(xa, xb), 'step %d: %g' % (step, (xa - xb).abs().max())
         assert torch.equal(tsa, tsb) and torch.equal(sta[:3], stb[:3]) and int(sta[0]) == 699 - step and int(sta[1]) == 12 + step
+    # without inpainting operands (gt = mask = NULL)
+    xa, tsa, sta = fresh()
+    xb, tsb, stb = fresh()
+    mdm.forward_step(xa, tsa, table, sta, y=y)
+    mdm(xb, tsb, y=y, out=x0)
+    _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(xb), _lib.dptr(x0), None, None, xb.numel(), _lib.dptr(table), _lib.dptr(stb), _lib.dptr(tsb), B,
+                                                _lib.stream()), 'posterior_step_dev')
+    assert torch.equal(xa, xb) and torch.equal(tsa, tsb)
     x13, ts13, c13 = fx.mdm_inputs(2, 13)
     with pytest.raises((RuntimeError, ValueError)):
         mdm.forward_step(x13.to(DEV), ts13.to(DEV), table, sta, y={'cond': c13.to(DEV)})

@@ -70,6 +70,9 @@ __device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base
 // the flush off the kernel boundary (MI355X_MICROARCH.md: a boundary costs + bytes-left-dirty / 6 TB/s) and overlaps it with the
 // rest of the launch.  Invisible to the compiler's vmcnt bookkeeping like every asm memory op: only for data this kernel never
 // reads back.
+__device__ __forceinline__ void idf_store4_wt(float *p, const float v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void idf_store16_wt(float *p, const float4 v) {
     const f32x4 t = {v.x, v.y, v.z, v.w};
     // s_nop: a store of more than 64 bits reads its data registers AFTER issue -- a VALU write to them needs wait states in
@@ -216,6 +219,11 @@ __device__ __forceinline__ void row16_load_sum(Row16 &r, const float *__restrict
 __device__ __forceinline__ void row16_store(const Row16 &r, float *__restrict__ row, int l16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(row + (i * 16 + l16) * 4) = r.c[i];
+}
+// (global rows that other XCDs read next: write-through, see idf_store16_wt)
+__device__ __forceinline__ void row16_store_wt(const Row16 &r, float *__restrict__ row, int l16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) idf_store16_wt(row + (i * 16 + l16) * 4, r.c[i]);
 }
 __device__ __forceinline__ void row16_zero(Row16 &r) {
 #pragma unroll

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         Row16 r;
         row16_load(r, x1s + rown * RS, li);
         ln_row16_lds(r, P_ln2_w, P_ln2_b, li);
-        if (t < T) row16_store(r, x2_out + (rowbase + t) * D, li);
+        if (t < T) row16_store_wt(r, x2_out + (rowbase + t) * D, li);
     }
     IDF_RB_STAMP(8);                                     // LN2 + store
 }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = q0 + rt * 16 + kq * 4 + r;
-                if (t < T) ctx[(rowbase + t) * D + h * HD + dcol] = acc[rt][r];
+                if (t < T) idf_store4_wt(ctx + (rowbase + t) * D + h * HD + dcol, acc[rt][r]);
             }
     }
     IDF_AT_STAMP(4);                                     // P V + store

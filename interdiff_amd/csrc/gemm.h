@@ -235,7 +235,7 @@ __device__ __forceinline__ void epilogue_rows(const Args &g, float *cs, const f3
     __syncthreads();
     for (int idx = tid; idx < BM * Q; idx += NT) {
         const int row = idx / Q, c4 = idx - row * Q, gr = m0 + row, gc = n0 + c4 * 4;
-        if (gr < g.M && gc < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)gr * g.ldc + gc) = ld4(cs + row * CS + c4 * 4);
+        if (gr < g.M && gc < g.N) idf_store16_wt(g.C + (size_t)gr * g.ldc + gc, ld4(cs + row * CS + c4 * 4));      // read next by other XCDs: write through
     }
 }
 

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
                 x.w = (x.w - mean) * rstd * gw.w + gb.w;
             }
             *reinterpret_cast<float4 *>(Xs + row * D + ((lane ^ (row & 15)) << 2)) = x;
-            if (xn_out && sl == 0 && m0 + row < M) *reinterpret_cast<float4 *>(xn_out + (size_t)(m0 + row) * D + lane * 4) = x;
+            if (xn_out && sl == 0 && m0 + row < M) idf_store16_wt(xn_out + (size_t)(m0 + row) * D + lane * 4, x);
         }
     }
     wait_one_pair_flying();                               // pair 0 (and everything older) has landed; pair 1 may fly

@@ -158,7 +158,7 @@ __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[
             const uchar4 m = po.mk[i][j];
             const float4 gv = po.gv[i][j];
             pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
-            *reinterpret_cast<float4 *>(g.post_x + flat) = posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]);
+            idf_store16_wt(g.post_x + flat, posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]));      // the next step's embedding reads x from other XCDs
         }
 }
 

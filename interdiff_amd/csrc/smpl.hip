@@ -110,6 +110,7 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
                                                               int64_t N, float *__restrict__ verts,
                                                               float *__restrict__ v_posed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    idf_args_now(m.V, m.J, m.S, m.blend, m.skin_idx, m.skin_w, feat, A, trans, N, verts, v_posed, gridDim.x);      // every argument into SGPRs now (common.h)
     constexpr int KB = 16 * NG, nq = KB / 4;
     const int V = m.V, J = m.J, S = m.S;
     float *As = sm, *stage = sm;                       // the stage image reuses the feature image once the contraction is done

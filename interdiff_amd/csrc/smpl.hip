@@ -85,11 +85,15 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const idf_smpl_model m, c
     }
 }
 
-constexpr int FT = 32, VT = 64, NTC = 3 * VT;          // frames / vertices / coordinates per workgroup
+#ifndef IDF_SMPL_FT
+#define IDF_SMPL_FT 32
+#define IDF_SMPL_SF 16
+#endif
+constexpr int FT = IDF_SMPL_FT, VT = 64, NTC = 3 * VT;  // frames / vertices / coordinates per workgroup
 constexpr int BT = 256;                                 // threads (4 waves x 48 coordinates); two workgroups share a CU (one's skinning phase beside the other's MFMA loop)
 constexpr int FM = FT / 16;                             // 16-frame MFMA tiles per wave (each basis fragment feeds FM*4 MFMAs)
 constexpr int STS = NTC + 1;                            // stage row stride
-constexpr int SF = 16;                                  // frames per skinning sub-step (their joint transforms are staged in LDS)
+constexpr int SF = IDF_SMPL_SF;                         // frames per skinning sub-step (their joint transforms are staged in LDS)
 #ifndef IDF_SMPL_TBF                                     // (tools/smpl_probe.hip rebuilds this file with other block shapes)
 #define IDF_SMPL_TBF 10
 #define IDF_SMPL_TBV 4
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
             for (int r = 0; r < 4; ++r) stage[((fh * FM + i) * 16 + kq * 4 + r) * STS + (wave * 3 + t) * 16 + li] = acc[i][t][r];
 
     float *Asub = sm + ((FT * STS + 255) & ~255);      // [SF][J*12] joint transforms of the current 16 frames (1-KiB aligned: DMA target)
-    float *ost = Asub + ((SF * J * 12 + 3) & ~3);      // [SF][NTC] skinned vertices of the current 16 frames
+    float *ost = Asub + ((SF * J * 12 + 255) & ~255);  // [SF][NTC] skinned vertices of the current frames (Asub rounded up to whole KiB: its DMA copies whole KiB)
     float *trs = ost + SF * NTC;                       // [FT][3] translations of the tile's frames
     const int arow = J * 12;
     if (tid < FT * 3) trs[tid] = trans[min(f0 + tid / 3, N - 1) * 3 + tid % 3];     // consumed after the barriers below
@@ -308,9 +312,9 @@ extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose
     float *A = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + idf_align((size_t)N * m->KB * sizeof(float)));
     idf_prof_mark(IDF_K_SMPL_POSE, s);
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((unsigned)N), dim3(64), 0, s, *m, pose, betas, trans, feat, A, jtr);
-    const size_t lds = std::max((size_t)FT * m->KB, (size_t)((FT * STS + 255) & ~255) + ((SF * m->J * 12 + 3) & ~3) + (size_t)SF * NTC + FT * 3) * sizeof(float);
+    const size_t lds = std::max((size_t)FT * m->KB, (size_t)((FT * STS + 255) & ~255) + ((SF * m->J * 12 + 255) & ~255) + (size_t)SF * NTC + FT * 3) * sizeof(float);
     // KB % 32: the swizzled feature image; J*12*SF % 256: the joint transforms of 16 frames are whole KiB; <= 4 bones per vertex
-    if (lds > 150 * 1024 || m->KB % 32 != 0 || (SF * m->J * 12) % 256 != 0 || (m->V * 3) % 2 != 0 || m->S > 4) return IDF_E_INVAL;     // <= 4 bones per vertex (SMPL / SMPL-H skinning)
+    if (lds > 150 * 1024 || m->KB % 32 != 0 || (m->V * 3) % 2 != 0 || m->S > 4) return IDF_E_INVAL;     // <= 4 bones per vertex (SMPL / SMPL-H skinning)
     if (m->KB != 480) return IDF_E_INVAL;              // SMPL-H: 9 * 51 pose + 10 shape + 1 template = 470 -> 480 (the only basis width built)
     static std::atomic<uint64_t> lds_ok{0};
     if (lds > 64 * 1024 && idf_opt_in_lds(reinterpret_cast<const void *>(smpl_blend_skin_kernel<30>), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;

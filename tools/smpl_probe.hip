@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -I interdiff_amd/csrc tools/smpl_probe.hip -o build_tools/smpl_probe
 // Builds csrc/smpl.hip as one translation unit with IDF_SMPL_STAMP defined; random model / inputs (timing only), N frames.
 #include <hip/hip_runtime.h>
-__device__ long long g_stamps[8192 * 16];
+__device__ long long g_stamps[32768 * 16];
 #define IDF_SMPL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[blockIdx.x * 16 + (i)] = clock64(); } while (0)
 #include "smpl.hip"
 #include <cstdio>

@@ -63,7 +63,7 @@ int interdiff_rotation_6d_to_axis_angle(const float *d6, float *aa, int64_t n, v
  * ---------------------------------------------------------------------------------- */
 typedef struct {
     int32_t V, J, n_betas, KB, S;
-    const float   *blend;
+    const float   *blend;      /* blend basis [posedirs | shapedirs | template] (KB columns) in the kernel's MFMA fragment order: [ceil(V/64)][4][3][KB/16][64][4], rows past 3V zero (smpl.py pack_smpl_model) */
     const float   *jt;
     const float   *js;
     const int32_t *parents;

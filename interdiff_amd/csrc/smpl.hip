@@ -172,14 +172,11 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
     __syncthreads();                                   // ... and so has everybody else's
     IDF_SMPL_STAMP(1);                                 // feature tile in LDS
 
+    // the basis is stored in MFMA fragment order [vertex tile][wave][t][k-group][lane][4] (smpl.py pack_smpl_model; rows past 3V are
+    // zero): a wave's load reads 1 KiB contiguous instead of gathering sixteen 64-byte pieces of sixteen rows
     const float *brow[3];
-    bool bval[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int nrow = 3 * v0 + (wave * 3 + t) * 16 + li;
-        bval[t] = nrow < 3 * V;
-        brow[t] = m.blend + (size_t)(bval[t] ? nrow : 0) * KB + kq * 4;
-    }
+    for (int t = 0; t < 3; ++t) brow[t] = m.blend + ((size_t)((vtile * 4 + wave) * 3 + t) * NG * 64 + lane) * 4;
     f32x4 acc[FM][3];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -195,7 +192,7 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
     float4 bq[PD + 1][3];
     auto ldg = [&](float4 (&dst)[3], int gi) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) dst[t] = *reinterpret_cast<const float4 *>(brow[t] + gi * 16);
+        for (int t = 0; t < 3; ++t) dst[t] = *reinterpret_cast<const float4 *>(brow[t] + gi * 256);
     };
     auto mac = [&](const float4 (&bc)[3], int gi) {
 #pragma unroll

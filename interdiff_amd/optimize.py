@@ -34,7 +34,7 @@ class PhysicsOptimizer:
         # constants of the backward pass: the blend basis transposed (k-major rows, zero padded to the split-K slice) and
         # the skinning weights regrouped by joint
         self.K3P = (3 * cm.V + KSLICE - 1) // KSLICE * KSLICE
-        blend = smpl_layer._bufs['blend']                                   # [3V][KB]
+        blend = smpl_layer._bufs['blend_rows']                              # [3V][KB]
         self.blendT = torch.zeros(cm.KB, self.K3P, dtype=torch.float32, device=self.device)
         self.blendT[:, :3 * cm.V] = blend.t()
         idx, w = smpl_layer._bufs['skin_idx'].cpu().numpy(), smpl_layer._bufs['skin_w'].cpu().numpy()

@@ -46,11 +46,18 @@ def pack_smpl_model(model, device):
         skin_w[v, :len(js_)] = wts[v, js_]
     parents[0] = 0
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    bufs = dict(blend=t(blend), jt=t(jt), js=t(js), parents=t(parents.astype(np.int32)), skin_idx=t(skin_idx), skin_w=t(skin_w))
+    # the kernel's MFMA B-operand order (csrc/smpl.hip): [vertex tile of 64][wave 4][t 3][k-group][lane = kq*16 + li][4], row of a lane =
+    # 192 tile + (3 wave + t) 16 + li, k = 16 group + 4 kq + e; rows past 3V are zero
+    nvt = -(-V // 64)
+    rows = np.zeros((nvt * 192, KB), np.float32)
+    rows[:3 * V] = blend
+    frag = rows.reshape(nvt, 4, 3, 16, KB // 16, 4, 4).transpose(0, 1, 2, 4, 5, 3, 6)
+    bufs = dict(blend=t(frag), blend_rows=t(blend), jt=t(jt), js=t(js), parents=t(parents.astype(np.int32)), skin_idx=t(skin_idx), skin_w=t(skin_w))
     m = _lib.SmplModel()
     m.V, m.J, m.n_betas, m.KB, m.S = V, J, nb, KB, S
     for k, v in bufs.items():
-        setattr(m, k, v.data_ptr())
+        if k != 'blend_rows':                       # (row-major copy: host-side users only, e.g. the optimiser's transposed basis)
+            setattr(m, k, v.data_ptr())
     return m, bufs
 
 

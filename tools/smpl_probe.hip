@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     for (auto &v : h) v = (rand() / (float)RAND_MAX - 0.5f) * 0.01f;
     float *blend, *jt, *js, *sw, *pose, *betas, *trans, *verts, *jtr;
     int32_t *parents, *sidx;
-    CK(hipMalloc(&blend, (size_t)3 * V * KB * 4)); CK(hipMemcpy(blend, h.data(), (size_t)3 * V * KB * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&blend, (size_t)((V + 63) / 64) * 192 * KB * 4)); CK(hipMemcpy(blend, h.data(), (size_t)3 * V * KB * 4, hipMemcpyHostToDevice));      // fragment-order basis: [ceil(V/64)] tiles of 192 rows (random content: timing only)
     CK(hipMalloc(&jt, J * 3 * 4)); CK(hipMalloc(&js, J * 3 * nb * 4)); CK(hipMalloc(&sw, (size_t)V * S * 4)); CK(hipMalloc(&sidx, (size_t)V * S * 4));
     CK(hipMalloc(&parents, J * 4));
     CK(hipMemcpy(jt, h.data(), J * 3 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(js, h.data(), J * 3 * nb * 4, hipMemcpyHostToDevice));

@@ -130,11 +130,20 @@ __global__ __launch_bounds__(BT) void smpl_blend_skin_kernel(const idf_smpl_mode
     // of features + transforms for every vertex tile; round 1 additionally spread each basis slice over all eight L2s: 657 MB.)
     const int nft = (int)((N + FT - 1) / FT), nvt = (V + VT - 1) / VT, nfb = (nft + TBF - 1) / TBF;
     const int nwg = gridDim.x, id = blockIdx.x;
+#ifdef IDF_SMPL_XF                                      // tools/smpl_probe.hip only: XCD x owns frame part x % XF, vertex part x / XF; frames fast
+    constexpr int XF = IDF_SMPL_XF, XV = 8 / XF;
+    const int nfp = (nft + XF - 1) / XF, nvp = (nvt + XV - 1) / XV, xcd = id & 7, l = id >> 3;
+    (void)nwg; (void)nfb;
+    const int fl = l % nfp, vpl = l / nfp;
+    const int ftile = (xcd % XF) * nfp + fl, vtile = (xcd / XF) * nvp + vpl;
+    if (vpl >= nvp) return;
+#else
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
     const int blk = lid / (TBF * TBV), wi = lid - blk * (TBF * TBV);
     const int nvb = (nvt + TBV - 1) / TBV;
     const int ftile = (FRAME_SLOW ? blk / nvb : blk % nfb) * TBF + wi % TBF, vtile = (FRAME_SLOW ? blk % nvb : blk / nfb) * TBV + wi / TBF;
+#endif
     if (ftile >= nft || vtile >= nvt) return;          // ragged edge blocks (workgroup-uniform)
     const int64_t f0 = (int64_t)ftile * FT;
     const int v0 = vtile * VT;
@@ -316,7 +325,12 @@ extern "C" int interdiff_smpl_forward(const idf_smpl_model *m, const float *pose
     static std::atomic<uint64_t> lds_ok{0};
     if (lds > 64 * 1024 && idf_opt_in_lds(reinterpret_cast<const void *>(smpl_blend_skin_kernel<30>), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     idf_prof_mark(IDF_K_SMPL_BLEND_SKIN, s);
-    hipLaunchKernelGGL(smpl_blend_skin_kernel<30>, dim3((unsigned)(idf_cdiv(idf_cdiv(N, FT), TBF) * idf_cdiv(idf_cdiv(m->V, VT), TBV) * TBF * TBV)), dim3(BT), lds, s, *m,
+#ifdef IDF_SMPL_XF
+    const unsigned nwg_launch = (unsigned)(8 * idf_cdiv(idf_cdiv(N, FT), IDF_SMPL_XF) * idf_cdiv(idf_cdiv(m->V, VT), 8 / IDF_SMPL_XF));
+#else
+    const unsigned nwg_launch = (unsigned)(idf_cdiv(idf_cdiv(N, FT), TBF) * idf_cdiv(idf_cdiv(m->V, VT), TBV) * TBF * TBV);
+#endif
+    hipLaunchKernelGGL(smpl_blend_skin_kernel<30>, dim3(nwg_launch), dim3(BT), lds, s, *m,
                        feat, A, trans, N, verts, v_posed);
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();

@@ -98,7 +98,7 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
 
 def time_dominant_kernel(model, dev, reps=200):
     """The roofline kernel: the fused feed-forward block of one layer (csrc/ffn.h: [1600,256] -> linear1 -> gelu -> linear2 as five
-    partial slabs; 8 of the 24 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
+    partial slabs; 8 of the 22 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
     stream around `reps` back-to-back launches on the model's own weights (layer 1).  The launches are replayed from a hipGraph so
     that the figure is the GPU's, whatever the host is doing.  Returns the MEAN of three bursts (and the best, for reference)."""
     from interdiff_amd.mdm import ffn_parts
@@ -131,7 +131,7 @@ def time_dominant_kernel(model, dev, reps=200):
 
 
 def time_forward_graph(model, bt, y, dev, per_graph=10, reps=5):
-    """One denoiser forward (24 launches) replayed from a hipGraph on a side stream, HIP events around `reps` replays of
+    """One denoiser forward (22 launches) replayed from a hipGraph on a side stream, HIP events around `reps` replays of
     `per_graph` forwards: the GPU's time for MDM.forward, launch gaps as they are inside the sampler's captured steps."""
     x = bt['noise'].clone()
     ts = torch.full((x.shape[0],), 500, dtype=torch.int64, device=dev)
@@ -418,13 +418,13 @@ def main():
                                 traffic=traffic, us_per_launch=us, us_per_launch_best_burst=dom_best, algorithmic_flop_per_launch=flops,
                                 kernel_id=DOMINANT_KERNEL_ID,
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
-                                note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 24 launches '
+                                note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
                                      'of a denoiser forward; duration = mean of three bursts of 200 back-to-back launches replayed from a hipGraph, HIP '
                                      'events on the launch stream (rocprofv3 in-situ average: profiles/)' % (B_PER_GPU * T))
         fl = FLOP_PER_TOKEN * B_PER_GPU * T
         line['denoiser_forward'] = dict(us=fwd_us, achieved_tflops=fl / (fwd_us * 1e-6) / 1e12,
-                                        frac_of_f32_mfma_peak=fl / (fwd_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, launches=24,
-                                        how='MDM.forward (24 launches, B=%d T=%d) replayed from a hipGraph, HIP events on its stream' % (B_PER_GPU, T))
+                                        frac_of_f32_mfma_peak=fl / (fwd_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, launches=22,
+                                        how='MDM.forward (22 launches, B=%d T=%d) replayed from a hipGraph, HIP events on its stream' % (B_PER_GPU, T))
         line['kernels_us_event_to_event'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}    # includes the launch gap + event records
     line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)
     if post:

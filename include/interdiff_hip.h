@@ -128,6 +128,7 @@ typedef struct {
     int64_t ffn_pack;          /* linear1 + linear2 weights in the fused FFN kernel's stream order (5 x 106496 floats, mdm.py pack_ffn) */
     int64_t ffn_b1p;           /* linear1 bias zero-padded to 5 x 208 (+ 256 spare floats)                                      */
     int64_t sa_in_pack;        /* std only: sa_in_w in the LayerNorm+linear kernel's stream order (5 slices x 16 chunks [160][16], rows past 768 zero; mdm.py pack_linear160) */
+    int64_t sa_out_frag;       /* std only: sa_out_w in MFMA fragment order [head][4 column quarters][4 k-groups][4 column tiles][64 lanes][4] (mdm.py sa_out_fragments): the attention kernel's out-projection tail */
     int64_t ln_w[3], ln_b[3];
 } idf_mdm_layer;
 

@@ -130,16 +130,18 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        const float *__restrict__ bout, const float *__restrict__ ln2_w,
                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
                                                        int out_frame_major /* encoder output: row = t*B + b */,
-                                                       size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */) {
+                                                       size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */,
+                                                       const float *__restrict__ sa_resid /* !QAN, nullable: u1 = sum(u_in slabs) + sa_resid row + sa_bias */,
+                                                       const float *__restrict__ sa_bias) {
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
-    __shared__ __attribute__((aligned(1024))) float prm[7 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias (DMA targets)
+    __shared__ __attribute__((aligned(1024))) float prm[8 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias + self-attention output bias (DMA targets)
     __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
     float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
     float *Ps = part + 4 * 3 * 256;               // [TR][PS]
 
-    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, gridDim.x, gridDim.y);
+    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, sa_resid, sa_bias, gridDim.x, gridDim.y);
     const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -161,11 +163,11 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     // 26 k cycles).  Rows / columns duplicated by the clamps are never consumed (logit columns >= NQ, score columns >= HM) or are
     // zeroed below.
     {
-        const float *srcs[7] = {lnp_w ? lnp_w : ln1_w, lnp_w ? lnp_b : ln1_b, ln1_w, ln1_b, CROSS ? ln2_w : ln1_w, CROSS ? ln2_b : ln1_b,
-                                CROSS ? bout : ln1_b};
+        const float *srcs[8] = {lnp_w ? lnp_w : ln1_w, lnp_w ? lnp_b : ln1_b, ln1_w, ln1_b, CROSS ? ln2_w : ln1_w, CROSS ? ln2_b : ln1_b,
+                                CROSS ? bout : ln1_b, sa_bias ? sa_bias : ln1_b};
         const uint32_t prm_lds = idf_lds_addr(prm);
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < 8; ++i)
             if ((i & 3) == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
     }
     Row16 ra, rb;
@@ -185,6 +187,10 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         if (wave == 0 && kq < 2) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16: two lane groups of wave 0 (exec-masked loads)
     }
     raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, li, u_pstride);
+    Row16Raw<1> raw_r;                            // standard layers with the out-projection folded into the attention kernel: the residual row
+    if constexpr (!QAN) {
+        if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, li, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (QAN) {
 #pragma unroll
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         if (wave == 0) raw_b.reduce(rb);
     }
     const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
-                *P_bout = prm + 1536;
+                *P_bout = prm + 1536, *P_sab = prm + 1792;
 
     if constexpr (QAN) {
         // rows t0-1 .. t0+14 by all groups, halo rows t0+15, t0+16 by the first two groups of wave 0
@@ -299,6 +305,18 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         }
     } else {
         const int t = t0 + rown;
+        if (sa_resid) {                               // u1 = (head partials) + xn + b_o   (workgroup-uniform branch)
+            Row16 rr;
+            raw_r.reduce(rr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 bo = *reinterpret_cast<const float4 *>(P_sab + (i * 16 + li) * 4);
+                ra.c[i].x += rr.c[i].x + bo.x;
+                ra.c[i].y += rr.c[i].y + bo.y;
+                ra.c[i].z += rr.c[i].z + bo.z;
+                ra.c[i].w += rr.c[i].w + bo.w;
+            }
+        }
         if (!va) row16_zero(ra);
         fetch_g();
         fetch_vw();
@@ -390,26 +408,39 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 
 // ------------------------------------------------------------------------------------
 // Temporal self-attention of the two standard layers: softmax(Q K^T / 8) V per (clip, head), on the MFMA.
-// grid (ceil(T/32), H, B), 256 threads.  LDS: K,V [TP][68], Q [32][68], S [32][TP+4]; TP = T rounded up to 16.
+// grid (ceil(T/QT), H, B), 256 threads.  LDS: K,V [TP][68], Q [QT][68], S [QT][TP+4]; TP = T rounded up to 16, QT = 16 or 32 query rows.
 // ------------------------------------------------------------------------------------
 constexpr int AS = HD + 4;
 constexpr int ATTN_MAX_T = 208;
+#ifndef IDF_ATTN_RT
+#define IDF_ATTN_RT 1
+#endif
+constexpr int ATTN_RT = IDF_ATTN_RT;     // 16-query tiles per workgroup of the fused attention + out-projection kernel
 
-__global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
+// OUTPROJ: the workgroup also multiplies its [32 x 64] context tile with its head's 64 rows of W_o^T (K = 64, wave w owns output
+// columns [64w, 64w+64)) and writes a [32 x 256] PARTIAL of the out-projection into slab `head` of `slabs`; the row block that follows
+// sums the H slabs + residual + bias (one launch, one kernel boundary and the ctx round trip less than a separate GEMM).
+// wo_frag: this layer's W_o in fragment order [head][wave][k-group of 16][column tile][lane][4] (mdm.py sa_out_fragments).
+// RT: 16-query tiles per workgroup (grid.x = ceil(T / (16 RT))).  RT = 1 halves a workgroup's LDS image (73 KB at T = 100), so that two
+// workgroups share a CU and one's loads / softmax run beside the other's MFMA phases.
+template <bool OUTPROJ, int RT>
+__global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T,
+                                                        const float *__restrict__ wo_frag, float *__restrict__ slabs, size_t pstride) {
     extern __shared__ __attribute__((aligned(16))) float smx[];
-    idf_args_now(qkv, ctx, T, gridDim.x);
+    idf_args_now(qkv, ctx, T, wo_frag, slabs, pstride, gridDim.x);
     IDF_AT_STAMP(0);
     const int TP = (T + 15) & ~15, SS = TP + 4;
-    float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + 32 * AS;
-    const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 32, tid = threadIdx.x;
+    constexpr int QT = 16 * RT;
+    float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + QT * AS;
+    const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     // Operand fetch, all requests of a batch in flight together: clamped (always valid) addresses, no guard around a load -- a guarded
     // load inside a run-time loop costs one full memory round trip per iteration (7 at T = 100).  TP * 16 is a multiple of 256, so a
     // sweep `it` covers key rows 16 it .. 16 it + 15 for the whole workgroup; 8 sweeps per batch (T <= 128: one batch).
-    float4 qreg[2];
+    float4 qreg[RT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RT; ++u) {
         const int i = tid + 256 * u, r = i >> 4, d4 = (i & 15) * 4;
         qreg[u] = ld4(qkv + (rowbase + min(q0 + r, T - 1)) * (3 * D) + h * HD + d4);
     }
@@ -432,8 +463,16 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
             }
         }
     }
+    float4 wo[4][4];                                     // out-projection fragments: requested now (behind K / V, pinned), consumed after P V
+    if constexpr (OUTPROJ) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wo[sidx][c] = ld4(wo_frag + ((((size_t)(h * 4 + wave) * 4 + sidx) * 4 + c) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
         const int i = tid + 256 * u, r = i >> 4, d4 = (i & 15) * 4;
         *reinterpret_cast<float4 *>(Qs + r * AS + d4) = q0 + r < T ? qreg[u] : zero4();
     }
@@ -441,16 +480,20 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     IDF_AT_STAMP(1);                                     // K, V, Q in LDS
     // S = Q K^T / 8: wave w owns key tiles w, w+4, ... for both 16-query tiles
     for (int ct = wave; ct < TP / 16; ct += 4) {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
             const int koff = 16 * s + 4 * kq;
             const float4 kv = ld4(Ks + (ct * 16 + li) * AS + koff);
-            float4 a[2] = {ld4(Qs + li * AS + koff), ld4(Qs + (16 + li) * AS + koff)}, bb[2] = {kv, kv};
-            mma_rounds<2>(acc, a, bb);
+            float4 a[RT], bb[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { a[rt] = ld4(Qs + (rt * 16 + li) * AS + koff); bb[rt] = kv; }
+            mma_rounds<RT>(acc, a, bb);
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = acc[rt][r] * 0.125f;
     }
@@ -462,7 +505,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
         constexpr int NC = ATTN_MAX_T / 16, NC0 = 8;     // columns per lane at the longest clip; the first NC0 cover T <= 128
         const int ncol = TP >> 4;
         const bool tail = ncol > NC0;                    // workgroup-uniform: ONE branch around the columns past 128
-        for (int i = wave * 4 + kq; i < 32; i += 16) {
+        for (int i = wave * 4 + kq; i < QT; i += 16) {
             float *row = Ss + i * SS;
             float v[NC], mx = -FLT_MAX;
             // reads are unconditional with clamped addresses (a guard per column makes the compiler wait for every read separately)
@@ -513,24 +556,66 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     __syncthreads();
     IDF_AT_STAMP(3);                                     // softmax
     {   // ctx = P V: wave w owns the 16 head-dim columns [16w, 16w+16) for both query tiles
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int dcol = wave * 16 + li;
         for (int s = 0; s < TP / 16; ++s) {
             const int koff = 16 * s + 4 * kq;
             const float *vp = Vs + koff * AS + dcol;
             const float4 vv = make_float4(vp[0], vp[AS], vp[2 * AS], vp[3 * AS]);
-            float4 a[2] = {ld4(Ss + li * SS + koff), ld4(Ss + (16 + li) * SS + koff)}, bb[2] = {vv, vv};
-            mma_rounds<2>(acc, a, bb);
-        }
+            float4 a[RT], bb[RT];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt) { a[rt] = ld4(Ss + (rt * 16 + li) * SS + koff); bb[rt] = vv; }
+            mma_rounds<RT>(acc, a, bb);
+        }
+        if constexpr (!OUTPROJ) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = q0 + rt * 16 + kq * 4 + r;
+                    if (t < T) idf_store4_wt(ctx + (rowbase + t) * D + h * HD + dcol, acc[rt][r]);
+                }
+        } else {
+            // context tile -> LDS in A-operand (row-major) form; the Q image is dead since the S phase
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Qs[(rt * 16 + kq * 4 + r) * AS + dcol] = acc[rt][r];
+        }
+    }
+    IDF_AT_STAMP(4);                                     // P V (+ store)
+    if constexpr (OUTPROJ) {
+        __syncthreads();
+        f32x4 o[4 * RT];
+#pragma unroll
+        for (int i = 0; i < 4 * RT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int koff = 16 * sidx + 4 * kq;
+            float4 a[4 * RT], bb[4 * RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 av = ld4(Qs + (rt * 16 + li) * AS + koff);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a[rt * 4 + c] = av; bb[rt * 4 + c] = wo[sidx][c]; }
+            }
+            mma_rounds<4 * RT>(o, a, bb);
+        }
+        float *slab = slabs + (size_t)h * pstride;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = q0 + rt * 16 + kq * 4 + r;
-                if (t < T) idf_store4_wt(ctx + (rowbase + t) * D + h * HD + dcol, acc[rt][r]);
+                if (t < T) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) idf_store4_wt(slab + (rowbase + t) * D + (wave * 4 + c) * 16 + li, o[rt * 4 + c][r]);
+                }
             }
+        IDF_AT_STAMP(5);                                 // out-projection partial + store
     }
-    IDF_AT_STAMP(4);                                     // P V + store
 }
 
 // ------------------------------------------------------------------------------------
@@ -596,8 +681,14 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
 // self_attn_kernel needs more than 64 KiB of dynamic LDS for long clips: per-device opt-in (common.h)
 int attn_opt_in() {
     static std::atomic<uint64_t> lds_ok{0};
-    return idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel),
-                          (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float)), lds_ok);
+    static std::atomic<uint64_t> lds_ok_op{0};
+    const int bytes = (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float));
+    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel<false, 2>), bytes, lds_ok);
+    return rc != IDF_OK ? rc : idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel<true, ATTN_RT>), bytes, lds_ok_op);
+}
+inline size_t attn_lds_bytes(int T, int rt) {
+    const int TP = (T + 15) & ~15;
+    return ((size_t)2 * TP * AS + 16 * rt * AS + 16 * rt * (TP + 4)) * sizeof(float);
 }
 
 struct Ws {
@@ -641,7 +732,7 @@ void run_gemm_ln(int cfg, hipStream_t s, const Args &g, int np) {
     if (np == NSL) run_gemm<A_LN, EPI, NSL>(cfg, s, g);
     else run_gemm<A_LN, EPI, 1>(cfg, s, g);
 }
-constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_OUTPROJ = 5, CFG_HEADS = 6;          // (the QKV projection has its own kernel: run_qkv)
+constexpr int CFG_FFN1 = 7, CFG_FFN2 = 6, CFG_HEADS = 6;          // (the QKV projection has its own kernel: run_qkv; the out-projection rides in the attention kernel, as a separate GEMM -- tune != 0 -- configuration 5 was the fastest)
 inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 // the last GEMM with the sampler update in its epilogue (gemm.h E_HEADS_POST): LDS-DMA kernel configurations only
 template <int NP>
@@ -758,10 +849,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     const float *u_in = k.uA;                  // layer input: plain [N,256] for layer 0, then the FFN's partial slabs
     int u_np = 1;
     const size_t pstride = (size_t)N * D;
-    float *u_tmp = k.uB;
     const float *lnp_w = nullptr, *lnp_b = nullptr;
-    const int TP = (T + 15) & ~15;
-    const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
     if (attn_opt_in() != IDF_OK) return IDF_E_LAUNCH;
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
@@ -769,22 +857,20 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
         if (ly.is_qan) {
             if (u_np == NSL)
                 hipLaunchKernelGGL((rowblock_kernel<true, false, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride);
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr);
             else
                 hipLaunchKernelGGL((rowblock_kernel<true, false, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride);
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr);
         } else {
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             run_qkv(0, s, g, ar + ly.sa_in_pack, u_np);
-            hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
-            Args o{};
-            o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
-            o.N = D; o.resid = k.xn; o.T = T;
-            run_gemm<A_PLAIN, E_RESID>(CFG_OUTPROJ, s, o);
-            hipLaunchKernelGGL((rowblock_kernel<false, false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, (size_t)0);
+            hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s,
+                               k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
+            hipLaunchKernelGGL((rowblock_kernel<false, false, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
+                               ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride,
+                               k.xn, ar + ly.sa_out_b);
         }
         idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts);
         u_in = k.parts;
@@ -794,7 +880,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     }
     // cond[t][b][:] = LN2_last(u[b*T + t])
     hipLaunchKernelGGL((rowblock_kernel<false, false, NSL>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, pstride);       // after 8 layers u_in is always the slabs
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, pstride, nullptr, nullptr);       // after 8 layers u_in is always the slabs
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -841,8 +927,6 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const size_t pstride = (size_t)N * D;
     float *u_tmp = k.uB;
     const float *lnp_w = nullptr, *lnp_b = nullptr;   // LayerNorm still to be applied to u_in (none for layer 0)
-    const int TP = (T + 15) & ~15;
-    const size_t attn_lds = ((size_t)2 * TP * AS + 32 * AS + 32 * (TP + 4)) * sizeof(float);
     if (attn_opt_in() != IDF_OK) return IDF_E_LAUNCH;
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
@@ -853,11 +937,11 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             if (u_np == NSL)
                 hipLaunchKernelGGL((rowblock_kernel<true, true, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride);
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr);
             else
                 hipLaunchKernelGGL((rowblock_kernel<true, true, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride);
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr);
         } else {
             // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
             Args g{};
@@ -867,17 +951,28 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             if (post.x && l == 0) run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B);
             else run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np);
             idf_prof_mark(IDF_K_SELF_ATTN, s);
-            hipLaunchKernelGGL(self_attn_kernel, dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds, s, k.qkv, k.ctx, T);
-            // u1 = xn + ctx.Wo^T + bo
-            Args o{};
-            o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
-            o.N = D; o.resid = k.xn; o.T = T;
-            idf_prof_mark(IDF_K_GEMM_OUTPROJ, s);
-            run_gemm<A_PLAIN, E_RESID>(pick(tune[IDF_TUNE_GEMM_OUTPROJ], CFG_OUTPROJ), s, o);
-            idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
-            hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
-                               ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                               ar + ly.ln_b[1], k.x2, T, 0, (size_t)0);
+            if (tune[IDF_TUNE_GEMM_OUTPROJ] == 0) {
+                // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's
+                // slab buffer (its previous contents were consumed by the QKV kernel), summed with xn + bo by the row block
+                hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256),
+                                   attn_lds_bytes(T, ATTN_RT), s, k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
+                idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
+                hipLaunchKernelGGL((rowblock_kernel<false, true, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b);
+            } else {                                   // A/B runs: the out-projection as a separate GEMM (tools/kbench.py)
+                hipLaunchKernelGGL((self_attn_kernel<false, 2>), dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds_bytes(T, 2), s, k.qkv, k.ctx, T,
+                                   nullptr, nullptr, (size_t)0);
+                Args o{};
+                o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
+                o.N = D; o.resid = k.xn; o.T = T;
+                idf_prof_mark(IDF_K_GEMM_OUTPROJ, s);
+                run_gemm<A_PLAIN, E_RESID>(tune[IDF_TUNE_GEMM_OUTPROJ], s, o);
+                idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
+                hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, (size_t)0, nullptr, nullptr);
+            }
         }
         // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
         idf_prof_mark(IDF_K_FFN_FUSED, s);

@@ -155,5 +155,5 @@ extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t st
     return IDF_OK;
 }
 
-extern "C" int interdiff_abi_version(void) { return 7; }
+extern "C" int interdiff_abi_version(void) { return 8; }
 extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 6"; }

@@ -126,6 +126,16 @@ def pack_linear160(w):
     return np.concatenate(out)
 
 
+def sa_out_fragments(w):
+    """out_proj.weight [256 out, 256 in] -> MFMA B-operand fragment order of the attention kernel's out-projection tail
+    (csrc/denoiser.hip self_attn_kernel<true>): [head][wave = output column quarter][k-group of 16][column tile][lane = kq*16+li][4],
+    element e of lane (kq, li) = w[(wave*4 + tile)*16 + li][head*64 + 16*kgroup + 4*kq + e]."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (D, D)
+    f = w.reshape(4, 4, 16, HEADS, 4, 4, 4)          # [wave][tile][li][head][kgroup][kq][e]
+    return np.ascontiguousarray(f.transpose(3, 0, 4, 1, 5, 2, 6)).ravel()      # [head][wave][kgroup][tile][kq][li][e]
+
+
 def pad_ffn_bias(b1):
     """linear1.bias [1024] -> [5 * 208] zero-padded + one spare KiB (the kernel fetches a slice's bias with one 1-KiB DMA)."""
     out = np.zeros(FFN_SLICE_H * _lib.FFN_SLICES + 256, np.float32)
@@ -185,6 +195,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
+            ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))
             ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
         cw, cb = g(p + 'multihead_attn.in_proj_weight'), g(p + 'multihead_attn.in_proj_bias')
         ly.ca_q_w, ly.ca_q_b = ar.add(cw[:D]), ar.add(cb[:D])
@@ -212,6 +223,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
                 ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
                 ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
                 ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
+                ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))
                 ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
             ly.ff1_w, ly.ff1_b = ar.add(g(p + 'linear1.weight')), ar.add(g(p + 'linear1.bias'))
             ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))

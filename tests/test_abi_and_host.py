@@ -202,6 +202,30 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
         assert err < 1e-9, (late, err)
 
 
+def test_out_projection_fragments_match_the_attention_kernel_addressing():
+    """mdm.sa_out_fragments vs the loads of self_attn_kernel<true> (csrc/denoiser.hip): lane (kq, li) of wave `wave` reads, for head h,
+    k-group s and column tile c, the float4 at ((((h*4+wave)*4+s)*4+c)*64+lane)*4 and uses element e as W_o[(wave*4+c)*16+li][h*64+16s+4kq+e];
+    the per-head partial products it forms must add up to the plain out-projection."""
+    from interdiff_amd.mdm import sa_out_fragments
+    rs = np.random.RandomState(0)
+    w = rs.randn(256, 256).astype(np.float32)
+    f = sa_out_fragments(w)
+    assert f.shape == (256 * 256,)
+    h, wave, s, c, lane, e = np.meshgrid(*[np.arange(n) for n in (4, 4, 4, 4, 64, 4)], indexing='ij')
+    li, kq = lane & 15, lane >> 4
+    idx = ((((h * 4 + wave) * 4 + s) * 4 + c) * 64 + lane) * 4 + e
+    assert np.array_equal(f[idx], w[(wave * 4 + c) * 16 + li, h * 64 + 16 * s + 4 * kq + e])
+    assert np.array_equal(np.sort(idx.ravel()), np.arange(256 * 256))          # a permutation: every weight exactly once
+    # the kernel's contraction, in numpy: out[:, n] = sum_h ctx[:, h*64:(h+1)*64] . W_o[n, h*64:(h+1)*64]
+    ctx = rs.randn(32, 256)
+    fr = f.reshape(4, 4, 4, 4, 4, 16, 4).astype(np.float64)                    # [h][wave][s][c][kq][li][e]
+    out = np.zeros((32, 256))
+    for hh in range(4):
+        a = ctx[:, hh * 64:(hh + 1) * 64].reshape(32, 4, 4, 4)                 # [row][s][kq][e]
+        out += np.einsum('rsqe,wscqle->rwcl', a, fr[hh]).reshape(32, 256)
+    assert np.allclose(out, ctx @ w.astype(np.float64).T, rtol=1e-12, atol=1e-12)
+
+
 def test_qkv_pack_and_kernel_addressing_by_emulation():
     """The LayerNorm+linear kernel of the QKV projection (csrc/ffn.h ln_linear_kernel) restated lane by lane on the stream
     pack_linear160 builds: LN(sum of the five slabs) . W^T + b for a ragged row count, DMA applied at issue and at the wait."""

@@ -137,14 +137,16 @@ def main():
             for c in cfgs:
                 model.w.tune[TUNE[site]] = c
                 p = profile_forward(lib, model, x, ts, y, args.reps)
-                row[c] = p[KIND_OF[site]]
+                # out-projection: cfg 0 = folded into the attention kernel (no GEMM launch), so compare the whole attention block
+                row[c] = (sum(p.get(k, 0.0) for k in ('self_attn', 'gemm_outproj', 'rowblock_std')) if site == 'outproj' else p[KIND_OF[site]])
                 err = ((model(x, ts, y=y) - ref).abs().max() / ref.abs().max()).item()
-                assert err < 1e-5, (site, c, err)
+                assert err < (2e-5 if site == 'outproj' else 1e-5), (site, c, err)      # (per-head partial sums round differently)
             model.w.tune[TUNE[site]] = 0
             result['sweeps'][site] = row
             print('== %s' % site)
             for c, v in row.items():
-                print('   cfg %d %-18s %8.2f us' % (c, CFGS[c] if site != 'embed' else 'embed variant', v))
+                print('   cfg %d %-18s %8.2f us%s' % (c, CFGS[c] if site != 'embed' else 'embed variant', v,
+                                                     ' (self_attn + out-projection + row block)' if site == 'outproj' else ''))
     print(json.dumps(result))
 
 

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     for (int l = 0; l < 8; ++l) {
         idf_mdm_layer &ly = w.layer[l];
         ly.is_qan = (l >= 1);                 // the last launch is a QaN row block: its stamps are the ones read back
-        ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256);
+        ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256); ly.sa_out_frag = take(256 * 256);
         ly.qc = take(16 * 3 * 40 * 4); ly.wk = take(64);
         ly.ca_out_b = take(256);
         ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
@@ -78,15 +78,15 @@ int main(int argc, char **argv) {
     printf("  inside the first phase: entry -> all requests issued %.0f, -> first batch landed (wave 0) %.0f; workgroup entry times spread over %lld cycles\n",
            a9 / nwg, a10 / nwg, last - first);
     {
-        const int nat = ((T + 31) / 32) * 4 * B;
+        const int nat = ((T + 16 * ATTN_RT - 1) / (16 * ATTN_RT)) * 4 * B;
         std::vector<long long> sa((size_t)nat * 8);
         CK(hipMemcpyFromSymbol(sa.data(), HIP_SYMBOL(g_at_stamps), sa.size() * 8));
-        const char *an[5] = {"", "K, V, Q -> LDS", "S = Q K^T", "row softmax", "P V + store"};
-        double aa[5] = {0}, at = 0;
+        const char *an[6] = {"", "K, V, Q -> LDS (+ W_o requested)", "S = Q K^T", "row softmax", "P V", "out-projection partial + store"};
+        double aa[6] = {0}, at = 0;
         for (int w = 0; w < nat; ++w)
-            for (int i = 1; i < 5; ++i) aa[i] += (double)(sa[(size_t)w * 8 + i] - sa[(size_t)w * 8 + i - 1]);
+            for (int i = 1; i < 6; ++i) aa[i] += (double)(sa[(size_t)w * 8 + i] - sa[(size_t)w * 8 + i - 1]);
         printf("self-attention (last launch), %d workgroups; mean cycles per phase:\n", nat);
-        for (int i = 1; i < 5; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nat); at += aa[i] / nat; }
+        for (int i = 1; i < 6; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nat); at += aa[i] / nat; }
         printf("  total %.0f\n", at);
     }
     return 0;

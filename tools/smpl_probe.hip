@@ -26,7 +26,10 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(jt, h.data(), J * 3 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(js, h.data(), J * 3 * nb * 4, hipMemcpyHostToDevice));
     std::vector<int32_t> par(J), si((size_t)V * S);
     for (int j = 0; j < J; ++j) par[j] = j ? (j - 1) / 2 : 0;
-    for (auto &x : si) x = rand() % J;
+    // argv[2] = "coherent": the bones of a vertex follow its id (blocks of ~133 ids share a bone and its three successors), the way
+    // neighbouring SMPL-H vertex ids do; default: four unrelated bones per vertex (worst case for the skinning phase's LDS reads)
+    const bool coherent = argc > 2 && argv[2][0] == 'c';
+    for (size_t i = 0; i < si.size(); ++i) si[i] = coherent ? (int32_t)((i / S) * J / V + i % S) % J : rand() % J;
     std::vector<float> w((size_t)V * S, 0.25f);
     CK(hipMemcpy(parents, par.data(), J * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(sidx, si.data(), si.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(sw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
@@ -43,7 +46,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 10; ++i) interdiff_smpl_forward(&m, pose, betas, trans, N, verts, jtr, nullptr, ws, wsb, nullptr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("N=%lld: %.1f us per SMPL forward (pose + blend/skin kernels)\n", (long long)N, 1e3 * ms / 10);
+    printf("N=%lld: %.1f us per SMPL forward (pose + blend/skin kernels)%s\n", (long long)N, 1e3 * ms / 10, coherent ? ", bones coherent with vertex ids" : "");
     const int nwg = (int)(((N + FT - 1) / FT + TBF - 1) / TBF * (((V + VT - 1) / VT + TBV - 1) / TBV) * TBF * TBV);
     std::vector<long long> st((size_t)nwg * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));

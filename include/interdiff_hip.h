@@ -233,7 +233,10 @@ int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stre
 /* One PLAIN reverse step (no denoised_fn hook) = interdiff_mdm_forward + interdiff_posterior_step_dev(ts != NULL) with the x0
  * prediction consumed inside the denoiser's last GEMM: x [B,1,C,T] is the sampler state, updated in place; ts, table, gt, mask as
  * above; state is int64[8] here: [0..3] as above, [4..5] scratch (this step's {t, loop index}, parked by one thread of layer 0's
- * QKV kernel, which also advances [0..1] and ts -- no arrival counter).  Same bits as the two-call form (the update arithmetic and
+ * QKV kernel, which also advances [0..1] and ts -- no arrival counter), [6] = element index of x[0] inside the whole sample's x
+ * (a multiple of 4; 0 unless the clips of a sample are stepped as several independent chains, each with its own x slice, ts slice,
+ * state, memctx and workspace: the noise of element e is then drawn at counter [6] + e, i.e. what the undivided batch would draw),
+ * [7] reserved (0).  Same bits as the two-call form (the update arithmetic and
  * the noise counter are shared), and the two forms can alternate on one state.  T % 4 == 0 and layer 0 a standard layer
  * (IDF_E_INVAL otherwise: use the two-call form); replaces gaussian_diffusion.py:425-461 (p_sample) for steps without a hook. */
 int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,

@@ -127,6 +127,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN> &po, int rbase0, int col0) {
     const int64_t st = g.post_state[4];                 // {t, loop index} of THIS step, parked by sampler_prepare_step (philox.h)
     const uint64_t it = (uint64_t)g.post_state[5], seed = (uint64_t)g.post_state[2];
+    const size_t elem0 = (size_t)g.post_state[6];       // position of x[0] inside the whole sample (a chain of a split batch draws the whole batch's noise)
     po.c1 = g.post_table[st * 4]; po.c2 = g.post_table[st * 4 + 1]; po.sigma = g.post_table[st * 4 + 2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -138,7 +139,7 @@ __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN
             po.xv[i][j] = ld4(g.post_x + flat);
             po.gv[i][j] = g.post_mask ? ld4(g.post_gt + flat) : zero4();
             po.mk[i][j] = g.post_mask ? *reinterpret_cast<const uchar4 *>(g.post_mask + flat) : make_uchar4(0, 0, 0, 0);
-            po.e[i][j] = randn4(seed, it, (uint64_t)(flat >> 2));
+            po.e[i][j] = randn4(seed, it, (uint64_t)((flat + elem0) >> 2));
             asm volatile("" : "+v"(po.e[i][j].x), "+v"(po.e[i][j].y), "+v"(po.e[i][j].z), "+v"(po.e[i][j].w));     // computed here, not sunk into the epilogue
         }
 }

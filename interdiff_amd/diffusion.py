@@ -40,6 +40,8 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
 
 
 GRAPH_BLOCKS = (49, 7, 1)          # plain steps per captured hipGraph (49 = the gap between two correction steps)
+SPLIT_MAX_BATCH = int(os.environ.get('INTERDIFF_SPLIT_MAX_BATCH', 32))      # plain steps of a batch of up to this many clips run as N_CHAINS independent chains (see _graph_loop)
+N_CHAINS = int(os.environ.get('INTERDIFF_CHAINS', 2))
 MAX_GRAPH_SHAPES = 8               # captured (shape, mask, cond) entries kept per denoiser before the cache is dropped wholesale
 _UID = itertools.count(1)
 
@@ -73,6 +75,7 @@ class GaussianDiffusion:
         self._t_cache = {}
         self._tables = {}
         self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
+        self.split_chains = True             # ... and, for batches that do not fill the chip, as two independent half-batch chains
         self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
     # ------------------------------------------------------------------ helpers
@@ -142,22 +145,56 @@ class GaussianDiffusion:
                                                         _lib.dptr(st.ts), B, _lib.stream()), 'posterior_step_dev')
 
         fused = self.fuse_plain_step and getattr(model, 'supports_forward_step', False) and img.shape[-1] % 4 == 0
+        # Chains: at <= 16 clips every kernel of a step is one partial wave of workgroups bounded by latency (operand round trips,
+        # kernel boundaries), so the two halves of the batch, stepped as independent kernel chains on two branches of the SAME captured
+        # graph, overlap each other's dead time.  Clips never interact in a plain step, the noise of a chain is drawn at the whole
+        # batch's counters (state[6]), so the result is bit-identical to the single chain.  Hook steps stay whole-batch.
+        nch = N_CHAINS
+        split = fused and self.split_chains and nch > 1 and B % nch == 0 and 2 * nch <= B <= SPLIT_MAX_BATCH
+        if split and not hasattr(st, 'chains'):
+            h = B // nch
+            st.chains = []
+            for c in range(nch):
+                sl = slice(c * h, (c + 1) * h)
+                st.chains.append(SimpleNamespace(
+                    sl=sl, x=st.x[sl], ts=st.ts[sl], gt=st.gt[sl] if has_mask else None, mask=st.mask[sl] if has_mask else None,
+                    state=st.state if c == 0 else torch.zeros(8, dtype=torch.int64, device=dev),
+                    cond=torch.empty(cond.shape[0], h, cond.shape[2], device=dev),
+                    memctx=torch.empty(model.memctx_floats(h), dtype=torch.float32, device=dev),
+                    ws=torch.empty(model.workspace_bytes(h, img.shape[-1]), dtype=torch.uint8, device=dev), stream=torch.cuda.Stream(dev)))
+        if split:
+            for ch in st.chains:                      # this sample's memory, folded per chain (its layout is per batch)
+                ch.cond.copy_(st.cond[:, ch.sl])
+                model.prepare_memory(ch.cond, into=ch.memctx)
 
         def graph_of(k):
             """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
-            if (k, fused) not in st.graphs:
+            if (k, fused, split) not in st.graphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    for _ in range(k):
-                        if fused:                   # the update runs in the epilogue of the denoiser's last GEMM (same bits)
-                            model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs)
-                        else:
-                            model(st.x, st.ts, out=st.x0, **st.kwargs)
-                            posterior(st.x, st.x0, st.gt, st.mask, st)
-                st.graphs[(k, fused)] = g
-            return st.graphs[(k, fused)]
+                    if split:                       # fork: each chain runs its k steps on its own branch; join at the end
+                        cur = torch.cuda.current_stream()
+                        for ch in st.chains:
+                            ch.stream.wait_stream(cur)
+                            with torch.cuda.stream(ch.stream):
+                                for _ in range(k):
+                                    model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws)
+                        for ch in st.chains:
+                            cur.wait_stream(ch.stream)
+                    else:
+                        for _ in range(k):
+                            if fused:               # the update runs in the epilogue of the denoiser's last GEMM (same bits)
+                                model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs)
+                            else:
+                                model(st.x, st.ts, out=st.x0, **st.kwargs)
+                                posterior(st.x, st.x0, st.gt, st.mask, st)
+                st.graphs[(k, fused, split)] = g
+            return st.graphs[(k, fused, split)]
         st.x.copy_(img)
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, 0, 0], dtype=torch.int64))
+        if split:                                   # the other chains' states: the same schedule position, their x starts c chain-sizes in
+            for c, ch in enumerate(st.chains[1:], 1):
+                ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         gate = getattr(denoised_fn, 'is_active', None)
@@ -180,6 +217,9 @@ class GaussianDiffusion:
                 t.host_value = i
                 x0 = denoised_fn(x0, t, model_kwargs).contiguous()
                 posterior(st.x, x0, None, None, st)
+                if split:
+                    for ch in st.chains[1:]:
+                        ch.state[:6].copy_(st.state[:6])     # the whole-batch update advanced chain 0's state; the others follow
                 k = 1
             else:
                 # length of the plain run ahead (up to the next hook step / dump point / end), replayed in the

@@ -304,14 +304,30 @@ class MDM:
         self._memctx_pool.clear()
         self._ws = self._ws_shape = self._memctx = self._mem_key = self._mem_cond = None
 
-    def prepare_memory(self, cond):
-        """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands."""
+    def memctx_floats(self, B):
+        return self.lib.interdiff_mdm_memctx_floats(B)
+
+    def workspace_bytes(self, B, T):
+        return self.lib.interdiff_mdm_workspace_bytes(B, T)
+
+    def prepare_memory(self, cond, into=None):
+        """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands.  ``into``: a caller-owned
+        buffer of ``memctx_floats(B)`` floats to fill instead of the model's own (a chain of a split batch, diffusion.py); the
+        model's notion of "current memory" is left alone then."""
         if cond.shape[0] != MEM or cond.shape[2] != D:
             raise ValueError('cond must be [%d,B,%d]' % (MEM, D))
         B = cond.shape[1]
         given = cond
         cond = cond.contiguous()
         need = self.lib.interdiff_mdm_memctx_floats(B)
+        if into is not None:
+            if into.numel() != need or into.dtype != torch.float32 or not into.is_contiguous():
+                raise ValueError('into must be %d contiguous floats' % need)
+            ws = self._workspace(B, 16)
+            _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
+                                                             _lib.dptr(into), _lib.dptr(ws), ws.numel(), _lib.stream()),
+                       'mdm_prepare_memory')
+            return into
         # one buffer per batch size, reused for every sample and never released: its address may be baked into a captured hipGraph
         memctx = self._memctx_pool.get(B)
         if memctx is None or memctx.numel() != need:
@@ -377,17 +393,24 @@ class MDM:
     def supports_forward_step(self):
         return not self.w.layer[0].is_qan             # the step's sampler bookkeeping rides on layer 0's QKV kernel
 
-    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None):
+    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None):
         """One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
-        the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place.  T % 4 == 0."""
-        cond = y['cond']
-        if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
-            self.prepare_memory(cond)
+        the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place.  T % 4 == 0.  ``memctx`` / ``ws``:
+        caller-owned folded memory (``prepare_memory(cond, into=)``) and workspace (``workspace_bytes(B, T)`` bytes) instead of the
+        model's -- what lets two chains of one sample run side by side."""
         B, one, Cc, T = x.shape
         if one != 1 or Cc != self.w.C or not x.is_contiguous():
             raise ValueError('x must be a contiguous [B,1,%d,T]' % self.w.C)
-        ws = self._workspace(B, T)
-        _lib.check(self.lib.interdiff_mdm_forward_step(C.byref(self.w), _lib.dptr(self._memctx), _lib.dptr(x, torch.float32),
+        if memctx is None:
+            cond = y['cond']
+            if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
+                self.prepare_memory(cond)
+            memctx = self._memctx
+        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats(B):
+            raise ValueError('memctx was folded for another batch size')
+        if ws is None:
+            ws = self._workspace(B, T)
+        _lib.check(self.lib.interdiff_mdm_forward_step(C.byref(self.w), _lib.dptr(memctx), _lib.dptr(x, torch.float32),
                                                        _lib.dptr(timesteps, torch.int64), B, T, _lib.dptr(gt, allow_none=True),
                                                        _lib.dptr(mask, allow_none=True), _lib.dptr(table), _lib.dptr(state),
                                                        _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_forward_step')

@@ -1063,6 +1063,35 @@ def test_graph_cache_serves_new_samples_without_recapture(mdm, smpl):
 
 
 @pytest.mark.gpu
+def test_two_chain_plain_steps_equal_single_chain_and_eager(mdm, smpl):
+    """Even batches of 4..16 clips step their plain steps as two half-batch chains on two branches of one captured graph (own x / ts
+    slices, state, folded memory, workspace; noise drawn at the whole batch's counters through state[6]); hook steps run on the whole
+    batch in between.  Bit-identical to the single chain and to the eager loop, with and without mask / hook, and on graph reuse."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    T, P = 12, 64
+    corr = make_correction(smpl, T, P)
+    for B, seed in ((4, 51), (6, 52)):
+        bt = fx._clip(seed, B, T, P)
+        y = dev(fx.model_kwargs_y(bt, T))
+        noise = bt['noise'].to(DEV)
+        for hook in (corr, None):
+            for yy in (y, {k: v for k, v in y.items() if k not in ('inpainting_mask',)}):
+                run = lambda **kw: diff.p_sample_loop(mdm, tuple(noise.shape), noise=noise, clip_denoised=False, model_kwargs={'y': yy},
+                                                      denoised_fn=hook, seed=5, n_steps=120, first_t=560, **kw)
+                assert diff.split_chains
+                two = run()
+                st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(noise.shape)]
+                assert any(hasattr(v, 'chains') and any(key[2] for key in v.graphs if isinstance(key, tuple)) for v in st), 'split route not taken'
+                assert torch.equal(two, run()), 'graph reuse'
+                diff.split_chains = False
+                one = run()
+                diff.split_chains = True
+                assert torch.equal(two, one), 'two chains differ from one: %g' % (two - one).abs().max()
+                assert torch.equal(two, run(use_graph=False)), 'two chains differ from the eager loop'
+
+
+@pytest.mark.gpu
 def test_captured_graphs_survive_calls_with_other_shapes(mdm, smpl):
     """A sample is captured at one batch size, a bigger batch then runs through the same denoiser (new workspace and memory
     context), and the first shape's captured graphs are replayed: their baked-in buffers must still be theirs."""

@@ -96,26 +96,40 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
             for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
 
 
-def time_dominant_kernel(model, dev, reps=200):
+def time_dominant_kernel(model, dev, reps=200, chains=1):
     """The roofline kernel: the fused feed-forward block of one layer (csrc/ffn.h: [1600,256] -> linear1 -> gelu -> linear2 as five
     partial slabs; 8 of the 22 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
     stream around `reps` back-to-back launches on the model's own weights (layer 1).  The launches are replayed from a hipGraph so
-    that the figure is the GPU's, whatever the host is doing.  Returns the MEAN of three bursts (and the best, for reference)."""
+    that the figure is the GPU's, whatever the host is doing.  Returns the MEAN of three bursts (and the best, for reference).
+    chains = 2: the form the sampler's plain steps launch it in -- the batch's rows as two halves, each half a chain of back-to-back
+    launches on its own branch of the graph; the figure is then per PAIR of concurrent half-size launches (the same FLOP)."""
     from interdiff_amd.mdm import ffn_parts
-    N = B_PER_GPU * T
+    N = B_PER_GPU * T // chains
     g = torch.Generator().manual_seed(5)
-    x2 = torch.randn(N, 256, generator=g).to(dev)
-    parts = torch.empty(_lib.FFN_SLICES, N, 256, device=dev)
+    x2 = [torch.randn(N, 256, generator=g).to(dev) for _ in range(chains)]
+    parts = [torch.empty(_lib.FFN_SLICES, N, 256, device=dev) for _ in range(chains)]
     for _ in range(20):
-        ffn_parts(model, x2, 1, out=parts)
+        for c in range(chains):
+            ffn_parts(model, x2[c], 1, out=parts[c])
     torch.cuda.synchronize()
     per_graph = 50
     side = torch.cuda.Stream(device=dev)
+    branch = [torch.cuda.Stream(device=dev) for _ in range(chains)] if chains > 1 else None
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
-            for _ in range(per_graph):
-                ffn_parts(model, x2, 1, out=parts)
+            if chains == 1:
+                for _ in range(per_graph):
+                    ffn_parts(model, x2[0], 1, out=parts[0])
+            else:
+                cur = torch.cuda.current_stream()
+                for c in range(chains):
+                    branch[c].wait_stream(cur)
+                    with torch.cuda.stream(branch[c]):
+                        for _ in range(per_graph):
+                            ffn_parts(model, x2[c], 1, out=parts[c])
+                for c in range(chains):
+                    cur.wait_stream(branch[c])
         graph.replay()
         side.synchronize()
         ts = []
@@ -366,6 +380,7 @@ def main():
     if not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
         dom_us, dom_best = time_dominant_kernel(model, dev)
+        pair_us, pair_best = time_dominant_kernel(model, dev, chains=2)
         fwd_us = time_forward_graph(model, bt, y, dev)
         log('kernel profile done')
     # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
@@ -417,6 +432,10 @@ def main():
         line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
                                 traffic=traffic, us_per_launch=us, us_per_launch_best_burst=dom_best, algorithmic_flop_per_launch=flops,
                                 kernel_id=DOMINANT_KERNEL_ID,
+                                two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                    note='the sampler steps a batch of <= 32 clips as two half-batch kernel chains on two branches of one '
+                                                         'graph: the same layer = two concurrent launches at M=%d, timed as two such chains of back-to-back '
+                                                         'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
                                 note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
                                      'of a denoiser forward; duration = mean of three bursts of 200 back-to-back launches replayed from a hipGraph, HIP '

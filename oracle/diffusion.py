@@ -60,12 +60,13 @@ def make_schedule(steps=1000, name='cosine'):
 
 
 def p_sample_loop(model, shape, sched, noise, step_noise, model_kwargs,
-                  denoised_fn=None, dump_steps=None, n_steps=None):
+                  denoised_fn=None, dump_steps=None, n_steps=None, first_t=None):
     """model(x[B,1,C,T], t[B] int64, y=dict) -> x0.  ``noise`` is the initial
     image (NOT inpainted when given: gaussian_diffusion.py:691-692).
     ``step_noise(i, x)`` returns the N(0,1) draw used at loop index i (the
     reference draws th.randn_like(x) from the global generator, :532).
-    Runs ``n_steps`` iterations from t = steps-1 downwards (default: all)."""
+    Runs ``n_steps`` iterations from t = steps-1 downwards (default: all); ``first_t`` enters the
+    schedule at that timestep instead, with ``noise`` taken as x_{first_t} (a window of the loop)."""
     steps = len(sched['betas'])
     y = model_kwargs['y']
     c1 = sched['posterior_mean_coef1']
@@ -73,8 +74,9 @@ def p_sample_loop(model, shape, sched, noise, step_noise, model_kwargs,
     lv = sched['posterior_log_variance_clipped']
     img = noise
     dump = []
-    todo = steps if n_steps is None else n_steps
-    for it, i in enumerate(range(steps - 1, steps - 1 - todo, -1)):
+    top = steps - 1 if first_t is None else int(first_t)
+    todo = top + 1 if n_steps is None else min(int(n_steps), top + 1)
+    for it, i in enumerate(range(top, top - todo, -1)):
         t = torch.full((shape[0],), i, dtype=torch.int64)
         x0 = model(img, t, **model_kwargs)
         if 'inpainting_mask' in y and 'inpainted_motion' in y:

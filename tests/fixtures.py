@@ -165,11 +165,11 @@ def corr32_inputs():
     return x, model_kwargs_y(bt, T)
 
 
-PARITY_LOG = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r02.json')
+PARITY_LOG = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r03.json')
 
 
 def record_parity(name, **values):
-    """Measured errors of the chain / end-to-end parity tests -> gpurun_out/parity_r02.json (merged back from the GPU box; the
+    """Measured errors of the chain / end-to-end parity tests -> gpurun_out/parity_r03.json (merged back from the GPU box; the
     copy that is judged lives in profiles/).  Never fails a test."""
     import json
     try:
@@ -210,3 +210,13 @@ def optim_inputs(seed=9000, T=None, P=None):
     betas = np.repeat(rs.standard_normal((1, 10)), T, axis=0)
     obj_points = rs.uniform(-0.25, 0.25, (P, 3))
     return tuple(_t(np.float32(a)) for a in (pose, trans, obj_angles, obj_trans, betas, obj_points))
+
+
+TIMED_T, TIMED_P = 100, 2048          # the shape bench.py times (BASELINE configs #2 / #3): B = 16 / 32 clips of T = 100, P = 2048
+TIMED_FIRST_T, TIMED_STEPS = 560, 120  # a window that crosses the corrected steps t = 500 and t = 450
+
+
+def timed_inputs(B):
+    """Clip batch + x_{first_t} of the timed-route parity tests (no golden: the routes are compared with each other and the oracle)."""
+    bt = _clip(300 + B, B, TIMED_T, TIMED_P)
+    return bt, model_kwargs_y(bt, TIMED_T)

@@ -242,10 +242,22 @@ def _pick(contact):
     return np.where(contact.sum(-1) > 0, 1 + score.argmax(-1), 0)
 
 
+def _poses_fp64(sample, batch):
+    """oracle.correction.finalize (eval_smpl_short.py:154-177) in float64 on a sampler state: the pose-level yardstick."""
+    from oracle.correction import MARKERS67, split_tokens
+    T, B, _ = fx.FULL_SHAPE
+    x = torch.as_tensor(sample).double()
+    smpl64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fx.smpl_model().items()}
+    obj, body, verts, jtr = ocor.finalize(x, batch['gt'].double(), batch['hand_pose'].double(), batch['beta'].double(), smpl64, fx.PAST)
+    b6, o6 = split_tokens(x)
+    return dict(obj_translation=obj[..., 3:], obj_rotation=R.rotation_6d_to_matrix(o6[..., :6]), body_translation_and_hands=body[..., 66:],
+                body_rotations=R.rotation_6d_to_matrix(b6[..., :132].reshape(T, B, 22, 6)), markers=verts[:, :, MARKERS67], joints=jtr)
+
+
 def test_full_size_end_to_end_golden(mdm, smpl):
     """BASELINE config #2 itself, end to end (SURVEY.md §8(d) parity step 4): B=16, T=100, P=2048, the full 1000 steps with 11
     corrections and injected noise, against the REFERENCE's own sample_once_proj / get_gt / metrics run (tests/golden/full.npz) and
-    against the oracle's fp64 twin (full64.npz).  Reported (gpurun_out/parity_r02.json -> profiles/): worst relative error of the
+    against the oracle's fp64 twin (full64.npz).  Reported (gpurun_out/parity_r03.json -> profiles/): worst relative error of the
     sampler state at every dump, of the final poses / joints / markers, of the six metrics, the fraction of (call, clip) hook
     decisions that differ, and the same distances of the reference's fp32 run from the fp64 twin -- the yardstick: after the
     decisions start to act (t <= 500) two fp32 implementations can only agree as well as fp32 agrees with exact arithmetic."""
@@ -296,6 +308,17 @@ def test_full_size_end_to_end_golden(mdm, smpl):
                                   R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3))),
                markers=rel(verts[:, :, MARKERS67], z['markers']), joints=rel(jtr, z['jtr']))
     rep['final_outputs_rel_err_vs_reference'] = fin
+    # pose-level fp64 yardstick: the oracle's finalize in float64 on the fp64 twin's final sample (full64.npz stores it rounded to
+    # fp32: 6e-8, far below what is measured here).  How far the REFERENCE's own fp32 end-to-end poses are from exact arithmetic
+    # bounds how closely any fp32 implementation can be asked to match them.
+    pose64 = _poses_fp64(z64['dump_999'], batch)
+    ref_pose = dict(obj_translation=z['obj'][..., 3:], obj_rotation=R.axis_angle_to_matrix(torch.from_numpy(z['obj'][..., :3])),
+                    body_translation_and_hands=z['body'][..., 66:],
+                    body_rotations=R.axis_angle_to_matrix(torch.from_numpy(z['body'][..., :66]).reshape(T, B, 22, 3)), markers=z['markers'], joints=z['jtr'])
+    hip_pose = dict(obj_translation=obj[..., 3:], obj_rotation=R.axis_angle_to_matrix(obj[..., :3].cpu()), body_translation_and_hands=body[..., 66:],
+                    body_rotations=R.axis_angle_to_matrix(body[..., :66].reshape(T, B, 22, 3).cpu()), markers=verts[:, :, MARKERS67], joints=jtr)
+    rep['final_outputs_reference_vs_fp64'] = {k: rel(ref_pose[k], pose64[k]) for k in ref_pose}
+    rep['final_outputs_hip_vs_fp64'] = {k: rel(hip_pose[k], pose64[k]) for k in hip_pose}
     # the same post-processing applied to the REFERENCE's own final sample: separates the error of the conversion / body-model
     # kernels from the sensitivity of rot6d -> axis-angle -> SMPL to the 6e-5 that the two samples differ by (with a random-init
     # denoiser some joints' 6-D vectors are close to parallel, where Gram-Schmidt amplifies any input difference)
@@ -340,6 +363,14 @@ def test_full_size_end_to_end_golden(mdm, smpl):
     assert fin_same['body_rotations'] <= max(1e-4, 2 * rot_anchor['reference_vs_fp64']), (fin_same, rot_anchor)
     for k, e in rep['metrics_rel_err_vs_reference'].items():
         assert e <= (2e-3 if k == 'penetrate' else 2e-4), (k, e)
+    # final poses (what north_star names).  Two gates per quantity, with yard = the REFERENCE's own fp32 distance from the fp64 answer:
+    #   (i)  HIP is no further from the fp64 answer than the reference is:        hip_vs_fp64 <= max(1e-4, yard + 1e-5)
+    #   (ii) HIP vs the reference: 1e-4 wherever fp32 can deliver it, else inside the ball both fp32 runs live in around the exact
+    #        answer (triangle inequality: two runs each within `yard` of it are within 2 yard of each other): <= max(1e-4, 2 yard)
+    for k, e in fin.items():
+        yard = rep['final_outputs_reference_vs_fp64'][k]
+        assert rep['final_outputs_hip_vs_fp64'][k] <= max(1e-4, yard + 1e-5), ('final %s vs fp64' % k, rep['final_outputs_hip_vs_fp64'][k], yard)
+        assert e <= max(1e-4, 2 * yard), ('final %s vs reference' % k, e, yard)
 
 
 def test_evaluate_batch_and_sample_once(mdm, smpl):
@@ -1113,3 +1144,81 @@ def test_captured_graphs_survive_calls_with_other_shapes(mdm, smpl):
     junk = [torch.full((1 << 22,), float('nan'), device=DEV) for _ in range(8)]
     a2 = run(small, True)
     assert torch.equal(a1, a2) and torch.equal(a1, run(small, False)) and torch.equal(b1, run(big, False))
+
+
+# ------------------------------------------------------------------------------------------ the TIMED route at the TIMED shape
+def _philox_step(lib_, seed):
+    """step_noise callable that materialises the in-kernel generator's stream: draw ``it`` = interdiff_randn(seed, it) over the
+    whole batch (the counters every chain of the graph route uses, csrc/philox.h)."""
+    from interdiff_amd import _lib
+
+    def draw(it, x):
+        out = torch.empty_like(x)
+        _lib.check(lib_.interdiff_randn(_lib.dptr(out), out.numel(), seed, it, _lib.stream()), 'randn')
+        return out
+    return draw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [16, 32])
+def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
+    """What bench.py times -- hipGraph blocks of fused plain steps (interdiff_mdm_forward_step), two half-batch chains whose 32-row
+    tiles straddle clips at T = 100, in-kernel Philox, whole-batch hook steps in between -- against the EAGER route (one launch
+    sequence per step, two-call update, noise INJECTED from the materialised Philox stream) at BASELINE configs #2 / #3:
+    B = 16 / 32, T = 100, P = 2048, 120 steps from t = 560 (corrected steps t = 500 and t = 450 inside).  Bit for bit.
+    Reference loop: diffusion/gaussian_diffusion.py:663-736."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    T, P = fx.TIMED_T, fx.TIMED_P
+    bt, y = fx.timed_inputs(B)
+    y, x_t = dev(y), bt['noise'].to(DEV)
+    corr = make_correction(smpl, T, P)
+    seed = 1234 + B
+    run = lambda **kw: diff.p_sample_loop(mdm, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=corr,
+                                          n_steps=fx.TIMED_STEPS, first_t=fx.TIMED_FIRST_T, **kw)
+    assert diff.fuse_plain_step and diff.split_chains
+    timed = run(seed=seed)
+    st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(x_t.shape)]
+    assert len(st) == 1 and hasattr(st[0], 'chains') and len(st[0].chains) == 2, 'two-chain route not taken'
+    assert all(key[1] and key[2] for key in st[0].graphs if isinstance(key, tuple)), 'fused + split graphs expected: %r' % list(st[0].graphs)
+    eager = run(step_noise=_philox_step(lib, seed), use_graph=False)
+    assert torch.equal(timed, eager), 'timed route differs from the eager injected-noise route at B=%d: %g' % (B, (timed - eager).abs().max())
+    assert torch.equal(timed, run(seed=seed)), 'graph reuse'
+    assert torch.isfinite(timed).all()
+    fx.record_parity('timed_route_vs_eager_B%d_T100_P2048_120steps_from_t560' % B, bit_identical=1.0, corrected_steps_inside=2)
+
+
+@pytest.mark.gpu
+def test_timed_route_whole_sample_equals_eager(lib, mdm, smpl):
+    """One whole 1000-step sample (11 corrections) at B = 16, T = 100, P = 2048: the default graph route against the eager route fed
+    the materialised Philox stream.  Bit for bit."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    T, P = fx.TIMED_T, fx.TIMED_P
+    bt, y = fx.timed_inputs(16)
+    y, x_T = dev(y), bt['noise'].to(DEV)
+    corr = make_correction(smpl, T, P)
+    kw = dict(noise=x_T, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=corr)
+    timed = diff.p_sample_loop(mdm, tuple(x_T.shape), seed=99, **kw)
+    eager = diff.p_sample_loop(mdm, tuple(x_T.shape), step_noise=_philox_step(lib, 99), use_graph=False, **kw)
+    assert torch.equal(timed, eager), 'whole sample: %g' % (timed - eager).abs().max()
+    fx.record_parity('timed_route_vs_eager_B16_whole_sample', bit_identical=1.0, corrected_steps_inside=11)
+
+
+@pytest.mark.gpu
+def test_timed_route_window_vs_oracle(lib, mdm):
+    """The timed route (graph, fused step, two chains, in-kernel Philox) against the CPU oracle's p_sample_loop fed the SAME
+    (materialised) noise stream: B = 16, T = 100, 50 plain steps from t = 560 (the oracle's hook costs minutes per call at this
+    size; corrected steps are covered bit for bit by the tests above + the full-size golden).  North-star tolerance 1e-4."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    bt, y = fx.timed_inputs(16)
+    yd, x_t = dev(y), bt['noise'].to(DEV)
+    n, seed = 50, 4321
+    got = diff.p_sample_loop(mdm, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': yd}, seed=seed, n_steps=n, first_t=fx.TIMED_FIRST_T)
+    draw = _philox_step(lib, seed)
+    stream = [draw(it, x_t).cpu() for it in range(n)]
+    ref = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(fx.mdm_weights(), x, t, y['cond']), tuple(x_t.shape), odf.make_schedule(1000),
+                            bt['noise'].clone(), lambda i, x: stream[i], {'y': y}, n_steps=n, first_t=fx.TIMED_FIRST_T)
+    e = close(got, ref, 1e-4, 'timed route, 50 steps from t=560 at B=16,T=100 vs oracle')
+    fx.record_parity('timed_route_vs_oracle_B16_T100_50steps_from_t560', worst_rel_err=e, asserted=1e-4)

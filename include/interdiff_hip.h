@@ -279,7 +279,14 @@ typedef struct {
     const int32_t *adj_ptr, *adj_face, *adj_corner;
     const int32_t *markers_idx;
     int32_t n_markers, n_points, past_len;
-    int32_t tune;              /* 0 = shipped configuration of the contact scan; tools may set 1 (8 waves x 4 points per thread) */
+    int32_t tune;              /* reserved (rounds 1-2: shape of the contact scan), ignored */
+    /* Scan order of the exact nearest-vertex scans (all four or none; NULL = identity order: same results, no culling benefit).
+     * vorder [V]: scan position -> vertex, a permutation that keeps blocks of 16 consecutive positions spatially compact under any
+     * pose (the host uses the Morton order of the rest pose, interdiff_amd/correction.py scan_order); faces_scan [F][3] and
+     * markers_scan [n_markers] are `faces` / `markers_idx` mapped to scan positions; adj_pair_scan [nnz][2]: for entry e of the
+     * adjacency (adj_ptr / adj_face / adj_corner order) the scan positions (a, b) of the incident face's other two vertices such
+     * that the face normal at the vertex is (a - v) x (b - v).  Results (indices included) never depend on the order. */
+    const int32_t *vorder, *faces_scan, *markers_scan, *adj_pair_scan;
 } idf_correction_ctx;
 
 size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);
@@ -287,6 +294,18 @@ int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt
                          const float *hand_pose, const float *beta, const float *obj_points,
                          int32_t B, int32_t T, float blend_t /* t/1000 */,
                          uint8_t *condition, int32_t *contact, float *distance, float *loss,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* The nearest-vertex scan of the hook / the metrics on its own (tools.point2point_signed's object->human half, tools.py:45-76, fused
+ * with the object transform eval_smpl_short.py:107): verts [T*B][V][3] (frame n = t*B + b), obj_points [B][P][3] canonical, objR [T*B][9]
+ * row-major, objT [T*B][3] -> o2h [T*B][P] signed distance (nullable), idx int32 [T*B][P] nearest vertex, lowest index on ties
+ * (nullable), stats uint64[IDF_CONTACT_STATS] (nullable) = {16-vertex blocks scored, blocks there are, box tests made} summed over
+ * waves, the number of workgroups, and thread 0's clock cycles per phase summed over workgroups {records -> LDS, boxes + markers,
+ * its wave's tasks, waiting for the other waves, reductions}. */
+#define IDF_CONTACT_STATS 12
+size_t interdiff_contact_nn_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);
+int interdiff_contact_nn(const idf_correction_ctx *c, const float *verts, const float *obj_points, const float *objR,
+                         const float *objT, int32_t B, int32_t T, float *o2h, int32_t *idx, uint64_t *stats,
                          void *ws, size_t ws_bytes, void *stream);
 
 /* Evaluation metrics (eval_smpl_short.py:24-81) over the T frames handed in (the caller slices the future frames,

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -57,7 +57,8 @@ class ObjProj(C.Structure):
 class CorrectionCtx(C.Structure):
     _fields_ = [('smpl', C.POINTER(SmplModel)), ('objproj', C.POINTER(ObjProj)),
                 ('faces', vp), ('adj_ptr', vp), ('adj_face', vp), ('adj_corner', vp), ('markers_idx', vp),
-                ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('tune', i32)]
+                ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('tune', i32),
+                ('vorder', vp), ('faces_scan', vp), ('markers_scan', vp), ('adj_pair_scan', vp)]
 
 
 class OptCtx(C.Structure):
@@ -110,6 +111,8 @@ _SIGS = {
     'interdiff_metrics_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_metrics': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                     vp, vp, sz, vp]),
+    'interdiff_contact_nn_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
+    'interdiff_contact_nn': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]),
     'interdiff_optimize_init': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp, vp, vp, vp, i32, vp]),
     'interdiff_optimize_loss_grad': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp]),
     'interdiff_optimize_step': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp]),

@@ -22,11 +22,11 @@ def correction_gate(t0):
 
 
 class HipCorrection:
-    def __init__(self, smpl_layer, objprojector, n_points=2048, past_len=10, markers=MARKERS67, device='cuda'):
+    def __init__(self, smpl_layer, objprojector, n_points=2048, past_len=10, markers=MARKERS67, device='cuda', scan_order=True):
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.smpl, self.objproj, self.past_len = smpl_layer, objprojector, past_len
-        self.topo = MeshTopology(smpl_layer.th_faces, smpl_layer.cmodel.V, self.device)
+        self.topo = MeshTopology(smpl_layer.th_faces, smpl_layer.cmodel.V, self.device, rest_vertices=getattr(smpl_layer, 'v_template', None) if scan_order else None)
         self.markers_idx = torch.tensor(list(markers), dtype=torch.int32, device=self.device)
         ctx = _lib.CorrectionCtx()
         ctx.smpl = C.pointer(smpl_layer.cmodel)
@@ -35,6 +35,10 @@ class HipCorrection:
         ctx.adj_face, ctx.adj_corner = self.topo.adj_face.data_ptr(), self.topo.adj_corner.data_ptr()
         ctx.markers_idx = self.markers_idx.data_ptr()
         ctx.n_markers, ctx.n_points, ctx.past_len = len(markers), n_points, past_len
+        if self.topo.vorder is not None:       # scan order of the exact nearest-vertex scan (block culling); results do not depend on it
+            self.markers_scan = self.topo.scan_positions(markers, self.device)
+            ctx.vorder, ctx.faces_scan, ctx.markers_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.markers_scan.data_ptr()
+            ctx.adj_pair_scan = self.topo.adj_pair_scan.data_ptr()
         self.ctx = ctx
         self._ws = None
         self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call
@@ -67,6 +71,22 @@ class HipCorrection:
         if self.debug is not None:
             self.debug.update(condition=dbg[0], contact=dbg[1], distance=dbg[2], loss=dbg[3])
         return x
+
+    def contact_nn(self, verts, obj_points, objR, objT, want_stats=False):
+        """Signed object->human distances and nearest vertices (tools.point2point_signed's o2h half, tools.py:45-76, with the object
+        transform of eval_smpl_short.py:107 fused): verts [T,B,V,3], obj_points [B,P,3], objR [T,B,3,3], objT [T,B,3] ->
+        (o2h [T,B,P], idx int32 [T,B,P][, (blocks scored, blocks there are, box tests made), summed over waves])."""
+        T, B = verts.shape[:2]
+        P = self.ctx.n_points
+        o2h = torch.empty(T, B, P, device=self.device)
+        idx = torch.empty(T, B, P, dtype=torch.int32, device=self.device)
+        stats = torch.zeros(12, dtype=torch.int64, device=self.device) if want_stats else None
+        need = self.lib.interdiff_contact_nn_workspace_bytes(C.byref(self.ctx), B, T)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        v, pts, R_, t_ = (a.contiguous().float() for a in (verts, obj_points, objR, objT))
+        _lib.check(self.lib.interdiff_contact_nn(C.byref(self.ctx), _lib.dptr(v), _lib.dptr(pts), _lib.dptr(R_), _lib.dptr(t_), B, T, _lib.dptr(o2h),
+                                                 _lib.dptr(idx), _lib.dptr(stats, allow_none=True), _lib.dptr(ws), ws.numel(), _lib.stream()), 'contact_nn')
+        return (o2h, idx, tuple(int(x) for x in stats.cpu())) if want_stats else (o2h, idx)
 
     def is_active(self, t0):
         """Host-side gate (eval_smpl_short.py:85) -- lets the sampler replay its captured plain-step graph otherwise."""

@@ -76,167 +76,423 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
     return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
-// ---- K4: per-frame contact analysis -------------------------------------------------------------------
-// One workgroup (CT threads) per frame; every thread owns QP object points as QP/2 PACKED pairs: the exact-arithmetic
-// distance (dx*dx + dy*dy) + dz*dz of a pair against the LDS-broadcast vertex is 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add
-// (no FMA contraction, so the argmin is bit-identical to geometry.hip and to the oracle).
-// The scan itself only keeps the running MINIMUM (v_min3_f32 over vertex pairs); which vertex it was is settled per block of
-// VB vertices -- one compare + two selects per point per BLOCK instead of per vertex -- and resolved afterwards by re-scoring
-// the one winning block: the first vertex of the first block whose distance equals the minimum, i.e. exactly the
-// lowest-index-wins rule of the brute force.  11 -> ~8.6 VALU lane-ops per (point, vertex) pair.
+// ---- K3: scan order of a clip's object points ---------------------------------------------------------------
+// porder[b][s] = index of the clip's s-th canonical object point in Morton order (10 bits per axis inside the clip's bounding box).
+// The contact scan culls vertex blocks per WAVE; a wave that owns a compact patch of the object (128 consecutive points of this
+// order) agrees on which blocks it needs.  A rigid transform keeps the patch compact, so the order is per clip, not per frame.
+// One workgroup per clip: bounding box by a block reduction, 41-bit keys (code << 11 | index: unique, so the sort is stable by
+// construction), bitonic sort of 2048 keys in LDS.  ~10 us per call for all clips.
 constexpr int MAXP = 2048;             // object points per frame handled by one workgroup (CT * QP)
+__global__ __launch_bounds__(1024) void corr_point_order_kernel(const float *__restrict__ obj_points, int P, int32_t *__restrict__ porder) {
+    __shared__ unsigned long long keys[MAXP];
+    __shared__ float red[6][1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *op = obj_points + (size_t)b * P * 3;
+    float p[2][3];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 1024 * k;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            p[k][a] = i < P ? op[3 * i + a] : 0.f;
+            if (i < P) { lo[a] = fminf(lo[a], p[k][a]); hi[a] = fmaxf(hi[a], p[k][a]); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[a][tid] = lo[a]; red[3 + a][tid] = hi[a]; }
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                red[a][tid] = fminf(red[a][tid], red[a][tid + s]);
+                red[3 + a][tid] = fmaxf(red[3 + a][tid], red[3 + a][tid + s]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 1024 * k;
+        unsigned long long key = ~0ull;                                   // slots past P sort to the end
+        if (i < P) {
+            unsigned code = 0;
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float ext = red[3 + a][0] - red[a][0];
+                const float u = ext > 0.f ? (p[k][a] - red[a][0]) / ext : 0.f;
+                q[a] = (unsigned)fminf(fmaxf(u * 1023.0f, 0.f), 1023.0f);      // NaN -> 0 (fmaxf returns the non-NaN operand)
+            }
+#pragma unroll
+            for (int bit = 0; bit < 10; ++bit)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) code |= ((q[a] >> bit) & 1u) << (3 * bit + a);
+            key = ((unsigned long long)code << 11) | (unsigned)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= MAXP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int l = 2 * j * (tid / j) + (tid % j), r = l + j;
+            const unsigned long long x = keys[l], y = keys[r];
+            const bool up = (l & k) == 0;
+            if ((x > y) == up) { keys[l] = y; keys[r] = x; }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 1024 * k;
+        if (i < P) porder[(size_t)b * P + i] = (int32_t)(keys[i] & 2047u);
+    }
+}
+
+// ---- K4: per-frame contact analysis -------------------------------------------------------------------
+// One workgroup (16 waves) per frame.  The frame's 2048 object points are cut into TASKS of 64 consecutive points of the clip's
+// Morton order (K3) -- one point per lane -- and the waves pull tasks from an LDS counter: a patch that touches the body needs
+// several times the vertex blocks of one that floats free, and a static split of 128 points per wave left the workgroup waiting
+// for its slowest wave (tools/contact_probe.py, first version: thread 0 spent 220 k of 450 k cycles at the first barrier).
+// Arithmetic is the exact (dx*dx + dy*dy) + dz*dz without FMA contraction, so the argmin is bit-identical to geometry.hip and to
+// the oracle.  The fp32 VALU of gfx950 runs plain ops at 16 lanes per clock and PACKED ops (v_pk_add/mul_f32) at twice that, so
+// every distance / box instruction works on a PAIR: two consecutive vertices (or two boxes) against the lane's one point --
+// records are stored as pairs {x0 x1 y0 y1 | z0 z1 - -}, the point as {q, q}.  (Measured: one point per lane on plain ops cost
+// 4.7 cycles per instruction per wave, exactly what a packed instruction costs.)
+//
+// EXACT block culling (round 3).  The vertex records sit in LDS in SCAN ORDER -- the Morton order of the REST pose, chosen at
+// pack time (ctx->vorder): skinning is spatially smooth, so CB consecutive records stay a compact clump under any pose -- and
+// each block of CB = 16 records gets its axis-aligned box, built in-kernel from the frame's posed vertices.  Per point:
+//   seed    best = the distance to the FIRST record of every 4th block (108 real distances: a valid upper bound of the minimum),
+//           bumped by one ulp so that the first block that attains it still registers;
+//   scan    two levels: super-blocks of SB = 8 blocks (128 records) are tested first, their blocks only if some point needs them.
+//           For a box: lower bound lb = |max(lo - q, q - hi, 0)|^2 in the SAME operation order as the distance -- fp32
+//           subtraction, multiplication and addition are monotone, so the rounded lb never exceeds the rounded distance of any
+//           vertex inside the box.  A box is skipped iff lb > best (STRICTLY) for every point of the WAVE (one ballot, one
+//           uniform branch): a block holding a vertex at exactly the minimum is never skipped, ties included.  An executed block
+//           is scored like the brute force (v_min3_f32 over vertex pairs), index bookkeeping once per block.
+//   resolve the winning block is re-scored; among its records at the minimum the LOWEST ORIGINAL vertex index wins.  A point that
+//           met its minimum again in a later block (bm == best: ~1e-5 of the points) is flagged and rescanned over all records
+//           for the lowest original index: exactly the brute force's lowest-index-wins rule, independent of the scan order.
+// Then the normal of the nearest vertex from its incident faces (adjacency as (a, b) record pairs: ONE 8-byte load per face instead
+// of face id -> corner -> three vertex ids), the signed distance, the marker distances.  The per-point loss goes to LDS by scan
+// position and is reduced in a fixed tree: deterministic whatever wave scored the point.
 constexpr int MAXM = 128;
-constexpr int VB = 8;                  // vertices per index-bookkeeping block
+constexpr int CB = 16;                 // vertices per culling / index-bookkeeping block
+constexpr int SB = 8;                  // blocks per super-block (128 vertices): its box is tested first, 8 block tests are skipped at once
+constexpr int SEED_STRIDE = 4;         // the seed looks at the first record of every 4th block
+constexpr int CT = 1024;               // threads per workgroup
+constexpr int TASK = 64;               // points per task = one per lane
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int CT, int QP>
+// LDS image of the frame (float4 units).  Records: pair p = scan positions 2p, 2p+1 -> {x0 x1 y0 y1}, {z0 z1 - -}.  Boxes: pair j = boxes
+// 2j, 2j+1 -> {lox0 lox1 loy0 loy1}, {loz0 loz1 hix0 hix1}, {hiy0 hiy1 hiz0 hiz1}.
+struct ContactLds {
+    int V4, nCB, nSB, nSeed;
+    int rec, mark, box, sbox, seed, total;         // offsets in float4 units
+    __host__ __device__ explicit ContactLds(int V) {
+        V4 = (V + CB - 1) / CB * CB; nCB = V4 / CB; nSB = (nCB + SB - 1) / SB; nSeed = (nCB + SEED_STRIDE - 1) / SEED_STRIDE;
+        rec = 0;
+        mark = rec + V4;                             // V4 / 2 pairs x 2 float4
+        box = mark + MAXM;
+        sbox = box + 3 * (nSB * SB / 2);             // block boxes as pairs, padded with dummies to whole super-blocks
+        seed = sbox + 3 * ((nSB + 2) / 2);
+        total = seed + 2 * ((nSeed + 1) / 2);
+    }
+};
+
+__device__ __forceinline__ float3 lds_rec(const float4 *vs, int pos) {                // record at scan position pos
+    const float *f = reinterpret_cast<const float *>(vs + 2 * (pos >> 1));
+    const int h = pos & 1;
+    return make_float3(f[h], f[2 + h], f[4 + h]);
+}
+__device__ __forceinline__ void lds_rec_store(float4 *vs, int pos, float x, float y, float z) {
+    float *f = reinterpret_cast<float *>(vs + 2 * (pos >> 1));
+    const int h = pos & 1;
+    f[h] = x; f[2 + h] = y; f[4 + h] = z;
+}
+__device__ __forceinline__ void lds_box_store(float4 *bx, int k, float3 lo, float3 hi) {   // box k of a pair array
+    float *f = reinterpret_cast<float *>(bx + 3 * (k >> 1));
+    const int h = k & 1;
+    f[h] = lo.x; f[2 + h] = lo.y; f[4 + h] = lo.z; f[6 + h] = hi.x; f[8 + h] = hi.y; f[10 + h] = hi.z;
+}
+__device__ __forceinline__ void lds_box_load(const float4 *bx, int k, float3 &lo, float3 &hi) {
+    const float *f = reinterpret_cast<const float *>(bx + 3 * (k >> 1));
+    const int h = k & 1;
+    lo = make_float3(f[h], f[2 + h], f[4 + h]);
+    hi = make_float3(f[6 + h], f[8 + h], f[10 + h]);
+}
+
 __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restrict__ verts, int V,
                                                           const float *__restrict__ obj_points, int P,
+                                                          const int32_t *__restrict__ porder /* nullable [B][P]: scan position -> point */,
                                                           const float *__restrict__ objR, const float *__restrict__ objT,
-                                                          const int32_t *__restrict__ faces, const int32_t *__restrict__ adj_ptr,
+                                                          const int32_t *__restrict__ faces /* identity order only */,
+                                                          const int32_t *__restrict__ adj_ptr,
                                                           const int32_t *__restrict__ adj_face,
                                                           const int32_t *__restrict__ adj_corner,
-                                                          const int32_t *__restrict__ markers_idx, int M, int B,
+                                                          const int32_t *__restrict__ adj_pair /* nullable [nnz][2]: per incident face the scan positions (a, b): normal += (a - v) x (b - v) */,
+                                                          const int32_t *__restrict__ vorder /* nullable [V]: scan position -> vertex */,
+                                                          const int32_t *__restrict__ markers_pos /* scan positions */, int M, int B,
                                                           float *__restrict__ markers_out, float *__restrict__ loss_sum,
                                                           float *__restrict__ min_dist, int32_t *__restrict__ label,
                                                           float *__restrict__ o2h_out /* nullable [N][P] */,
+                                                          int32_t *__restrict__ idx_out /* nullable [N][P]: nearest vertex */,
+                                                          unsigned long long *__restrict__ stats /* nullable [IDF_CONTACT_STATS]: see interdiff_contact_nn */,
                                                           int64_t nn_from /* frames below it skip the NN scan */) {
-    extern __shared__ __attribute__((aligned(16))) float4 vs[];          // [V rounded up to VB, + one far-away block] then markers [MAXM]
-    const int V4 = (V + VB - 1) / VB * VB;                                 // records are (x, y, z, z): {z, z} is a ready-made packed operand
-    float4 *ms = vs + V4 + VB;
+    extern __shared__ __attribute__((aligned(16))) float4 vs[];
+    const ContactLds L(V);
+    const int nCB = L.nCB, nSB = L.nSB;
+    float4 *ms = vs + L.mark, *bb = vs + L.box, *sbb = vs + L.sbox, *sd = vs + L.seed;
     __shared__ int flags[MAXM];
     __shared__ float red[CT];
+    __shared__ float pl[MAXP];                                             // per-point loss by scan position
+    __shared__ int next_task;
     const int64_t n = blockIdx.x;
     const int b = (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
-    for (int v = tid; v < V4 + VB; v += CT)                                // the extra block lets the scan prefetch one block past the end
-        vs[v] = v < V ? make_float4(vf[3 * v], vf[3 * v + 1], vf[3 * v + 2], vf[3 * v + 2]) : make_float4(3e18f, 3e18f, 3e18f, 3e18f);
+    const bool do_nn = n >= nn_from;
+    // phase clocks of thread 0 (frames that scan only), summed into stats[3 + phase] when the caller asks for statistics
+    long long t_prev = 0;
+    int n_phase = 0;
+    auto phase_done = [&]() {
+        if (stats && tid == 0 && do_nn) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (n_phase > 0) atomicAdd(stats + 3 + n_phase, (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+        ++n_phase;
+    };
+    phase_done();
+    for (int v = tid; v < L.V4; v += CT) {
+        float x = 3e18f, y = 3e18f, z = 3e18f;                              // past the end: far away
+        if (v < V) {
+            const int o = vorder ? vorder[v] : v;
+            x = vf[3 * o]; y = vf[3 * o + 1]; z = vf[3 * o + 2];
+        }
+        lds_rec_store(vs, v, x, y, z);
+    }
     if (tid < MAXM) flags[tid] = 0;
+    if (tid == 0) next_task = 0;
+    for (int i = tid; i < MAXP; i += CT) pl[i] = 0.f;
     __syncthreads();
+    phase_done();                                                          // 1: records in LDS
     if (tid < M) {
-        const float4 mk = vs[markers_idx[tid]];
-        ms[tid] = mk;
+        const float3 mk = lds_rec(vs, markers_pos[tid]);
+        ms[tid] = make_float4(mk.x, mk.y, mk.z, 0.f);
         float *mo = markers_out + ((size_t)n * M + tid) * 3;
         mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
+    }
+    if (do_nn) {
+        const float3 none_lo = make_float3(FLT_MAX, FLT_MAX, FLT_MAX), none_hi = make_float3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+        for (int cb = tid; cb < nSB * SB; cb += CT) {                        // boxes of the real records of each block (+ dummies past the end: never needed)
+            float3 lo = none_lo, hi = none_hi;
+            if (cb < nCB) {
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                    const float3 p = lds_rec(vs, cb * CB + u);
+                    if (cb * CB + u < V) {
+                        lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
+                        hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
+                    }
+                }
+            }
+            lds_box_store(bb, cb, lo, hi);
+        }
+        for (int k = tid; k < 2 * ((L.nSeed + 1) / 2); k += CT) {           // seed records: the first record of every SEED_STRIDE-th block, as pairs
+            const float3 p = lds_rec(vs, min(k * SEED_STRIDE, nCB - 1) * CB);
+            lds_rec_store(sd, k, p.x, p.y, p.z);
+        }
+        __syncthreads();
+        for (int sb = tid; sb < 2 * ((nSB + 2) / 2); sb += CT) {            // super-block boxes = union of SB block boxes
+            float3 lo = none_lo, hi = none_hi;
+            for (int cb = sb * SB; cb < min((sb + 1) * SB, nCB) && sb < nSB; ++cb) {
+                float3 l, h;
+                lds_box_load(bb, cb, l, h);
+                lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
+                hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+            }
+            lds_box_store(sbb, sb, lo, hi);
+        }
     }
     float R[9], tr[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
-    float qx[QP], qy[QP], qz[QP];
     const float *op = obj_points + (size_t)b * P * 3;
-#pragma unroll
-    for (int k = 0; k < QP; ++k) {
-        const int i = tid + CT * k;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (i < P) { px = op[3 * i]; py = op[3 * i + 1]; pz = op[3 * i + 2]; }
-        // matmul(points, R^T) + t  (eval_smpl_short.py:107)
-        qx[k] = (px * R[0] + py * R[1] + pz * R[2]) + tr[0];
-        qy[k] = (px * R[3] + py * R[4] + pz * R[5]) + tr[1];
-        qz[k] = (px * R[6] + py * R[7] + pz * R[8]) + tr[2];
-    }
-    v2f QX[QP / 2], QY[QP / 2], QZ[QP / 2], best[QP / 2];
-    int bi[QP];
-#pragma unroll
-    for (int k = 0; k < QP / 2; ++k) {
-        QX[k] = v2f{qx[2 * k], qx[2 * k + 1]};
-        QY[k] = v2f{qy[2 * k], qy[2 * k + 1]};
-        QZ[k] = v2f{qz[2 * k], qz[2 * k + 1]};
-        best[k] = v2f{FLT_MAX, FLT_MAX};
-        bi[2 * k] = bi[2 * k + 1] = 0;
-    }
+    const int ln = tid & 63, ntask = (P + TASK - 1) / TASK;
     __syncthreads();
-    // the signed object->human distance is only consumed on future frames (eval_smpl_short.py:121 slices
-    // loss_dist_o[past_len:]); past frames only need the marker distances below
-    const bool do_nn = n >= nn_from;
-    if (do_nn) {
+    phase_done();                                                          // 2: boxes, markers
+    float mind = FLT_MAX;
+    unsigned n_exec = 0, n_test = 0, n_tasks = 0;
+    for (;;) {
+        int task = 0;
+        if (ln == 0) task = atomicAdd(&next_task, 1);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= ntask) break;
+        ++n_tasks;
+        const int sp = task * TASK + ln;                                   // scan position of this lane's point
+        const int i = sp < P ? (porder ? porder[(size_t)b * P + sp] : sp) : -1;
+        const bool valid = i >= 0;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) { px = op[3 * i]; py = op[3 * i + 1]; pz = op[3 * i + 2]; }
+        // matmul(points, R^T) + t  (eval_smpl_short.py:107)
+        const float qx = (px * R[0] + py * R[1] + pz * R[2]) + tr[0];
+        const float qy = (px * R[3] + py * R[4] + pz * R[5]) + tr[1];
+        const float qz = (px * R[6] + py * R[7] + pz * R[8]) + tr[2];
+        // the signed object->human distance is only consumed on future frames (eval_smpl_short.py:121 slices
+        // loss_dist_o[past_len:]); past frames only need the marker distances below
+        if (do_nn) {
 #pragma clang fp contract(off)
-        int bblk[QP];                                    // first vertex of the block that last lowered the minimum
+            const v2f QX = v2f{qx, qx}, QY = v2f{qy, qy}, QZ = v2f{qz, qz};
+            // exact squared distances of the point to a record pair
+            auto pair_d2 = [&](const float4 xy, const float4 zz) {
+#pragma clang fp contract(off)
+                const v2f dx = QX - v2f{xy.x, xy.y}, dy = QY - v2f{xy.z, xy.w}, dz = QZ - v2f{zz.x, zz.y};
+                return (dx * dx + dy * dy) + dz * dz;
+            };
+            // ---- seed
+            float best = FLT_MAX;
+            for (int k = 0; k < (L.nSeed + 1) / 2; k += 4) {
+                float4 xy[4], zz[4];
 #pragma unroll
-        for (int k = 0; k < QP; ++k) bblk[k] = 0;
-        // software pipeline: the LDS records of the NEXT block are in flight while the current one is scored
-        float4 cur[VB], nxt[VB];
+                for (int u = 0; u < 4; ++u) { xy[u] = sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1)]; zz[u] = sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1) + 1]; }
 #pragma unroll
-        for (int u = 0; u < VB; ++u) cur[u] = vs[u];
-        for (int v0 = 0; v0 < V4; v0 += VB) {
-#pragma unroll
-            for (int u = 0; u < VB; ++u) nxt[u] = vs[v0 + VB + u];
-            v2f bm[QP / 2];
-#pragma unroll
-            for (int k = 0; k < QP / 2; ++k) bm[k] = v2f{FLT_MAX, FLT_MAX};
-#pragma unroll
-            for (int u = 0; u < VB; u += 2) {
-                const float4 p = cur[u], r = cur[u + 1];
-                const v2f PX = v2f{p.x, p.x}, PY = v2f{p.y, p.y}, PZ = v2f{p.z, p.w};
-                const v2f RX = v2f{r.x, r.x}, RY = v2f{r.y, r.y}, RZ = v2f{r.z, r.w};
-#pragma unroll
-                for (int k = 0; k < QP / 2; ++k) {
-                    const v2f dx = QX[k] - PX, dy = QY[k] - PY, dz = QZ[k] - PZ;
-                    const v2f d2 = (dx * dx + dy * dy) + dz * dz;
-                    const v2f ex = QX[k] - RX, ey = QY[k] - RY, ez = QZ[k] - RZ;
-                    const v2f e2 = (ex * ex + ey * ey) + ez * ez;
-                    bm[k].x = fminf(fminf(bm[k].x, d2.x), e2.x);          // v_min3_f32
-                    bm[k].y = fminf(fminf(bm[k].y, d2.y), e2.y);
+                for (int u = 0; u < 4; ++u) {
+                    const v2f d2 = pair_d2(xy[u], zz[u]);
+                    best = fminf(fminf(best, d2.x), d2.y);
                 }
             }
+            // one ulp up (a normal number at least): the first block that attains the seed must still satisfy bm < best
+            best = best < 1.17549435e-38f ? 1.17549435e-38f : __builtin_bit_cast(float, __builtin_bit_cast(int, best) + 1);
+            bool tie = false;
+            int bblk = 0;                                  // first record of the block that last lowered the minimum
+            // lower bounds of the point to a PAIR of boxes
+            auto pair_lb = [&](const float4 a, const float4 bq, const float4 c) {
+#pragma clang fp contract(off)
+                const v2f ax = v2f{a.x, a.y} - QX, bx = QX - v2f{bq.z, bq.w};
+                const v2f ay = v2f{a.z, a.w} - QY, by = QY - v2f{c.x, c.y};
+                const v2f az = v2f{bq.x, bq.y} - QZ, bz = QZ - v2f{c.z, c.w};
+                const v2f ex = v2f{fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};       // v_max3_f32
+                const v2f ey = v2f{fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
+                const v2f ez = v2f{fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
+                return (ex * ex + ey * ey) + ez * ez;
+            };
+            auto score_block = [&](int cb) {
+                ++n_exec;
+                const int v0 = cb * CB;
+                float4 xy[CB / 2], zz[CB / 2];
 #pragma unroll
-            for (int k = 0; k < QP / 2; ++k) {
-                if (bm[k].x < best[k].x) { best[k].x = bm[k].x; bblk[2 * k] = v0; }
-                if (bm[k].y < best[k].y) { best[k].y = bm[k].y; bblk[2 * k + 1] = v0; }
+                for (int u = 0; u < CB / 2; ++u) { xy[u] = vs[v0 + 2 * u]; zz[u] = vs[v0 + 2 * u + 1]; }
+                float bm = FLT_MAX;
+#pragma unroll
+                for (int u = 0; u < CB / 2; ++u) {
+                    const v2f d2 = pair_d2(xy[u], zz[u]);
+                    bm = fminf(fminf(bm, d2.x), d2.y);                          // v_min3_f32
+                }
+                if (bm < best) { best = bm; bblk = v0; tie = false; }
+                else if (bm == best) tie = true;
+            };
+            auto scan_super = [&](int sb) {                 // the blocks of super-block sb, two box tests per instruction
+                const int cb0 = sb * SB;
+#pragma unroll
+                for (int j = 0; j < SB / 2; ++j) {
+                    const int cb = cb0 + 2 * j;             // boxes past nCB are dummies (lo = +max: lb = inf, never needed)
+                    const float4 *bx = bb + 3 * (cb >> 1);
+                    const v2f lb = pair_lb(bx[0], bx[1], bx[2]);
+                    n_test += 2;
+                    if (__builtin_amdgcn_ballot_w64(valid && lb.x <= best) != 0ull) score_block(cb);
+                    if (__builtin_amdgcn_ballot_w64(valid && lb.y <= best) != 0ull) score_block(cb + 1);     // best may just have dropped
+                }
+            };
+            for (int sb = 0; sb < nSB; sb += 2) {
+                const float4 *bx = sbb + 3 * (sb >> 1);
+                const v2f lb = pair_lb(bx[0], bx[1], bx[2]);
+                n_test += 2;
+                if (__builtin_amdgcn_ballot_w64(valid && lb.x <= best) != 0ull) scan_super(sb);              // wave-uniform branches
+                if (__builtin_amdgcn_ballot_w64(valid && lb.y <= best) != 0ull) scan_super(sb + 1);
             }
+            // resolve inside the winning block: among the records at (or, defensively, below) the minimum the lowest ORIGINAL index
+            int pos = bblk, org = 0x7fffffff;
 #pragma unroll
-            for (int u = 0; u < VB; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < CB; ++u) {
+                const int rp = bblk + u;
+                const float3 p = lds_rec(vs, rp);
+                const int o = rp < V ? (vorder ? vorder[rp] : rp) : 0x7fffffff;
+                if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) <= best && o < org) { org = o; pos = rp; }
+            }
+            if (tie) {                                    // the minimum was met again in a later block: settle it over all records
+                for (int rp = 0; rp < V; ++rp) {
+                    const float3 p = lds_rec(vs, rp);
+                    const int o = vorder ? vorder[rp] : rp;
+                    if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) <= best && o < org) { org = o; pos = rp; }
+                }
+            }
+            pos = min(pos, V - 1);
+            if (org == 0x7fffffff) org = vorder ? vorder[pos] : pos;      // NaN input: nothing compared equal
+            if (valid) {
+                // normal of the nearest vertex (data/tools.py:4-40 restricted to one vertex), from LDS, in the reference's accumulation order
+                const float3 v3 = lds_rec(vs, pos);
+                float3 acc = make_float3(0.f, 0.f, 0.f);
+                const int e0 = adj_ptr[org], e1 = adj_ptr[org + 1];
+                if (adj_pair) {
+                    for (int e = e0; e < e1; e += 4) {               // four incident faces per trip: their (a, b) loads fly together
+                        int2 ab[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ab[u] = *reinterpret_cast<const int2 *>(adj_pair + 2 * (size_t)min(e + u, e1 - 1));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (e + u < e1) {
+                                const float3 nn = cross3(sub3(lds_rec(vs, ab[u].x), v3), sub3(lds_rec(vs, ab[u].y), v3));
+                                acc.x += nn.x; acc.y += nn.y; acc.z += nn.z;
+                            }
+                        }
+                    }
+                } else {
+                    for (int e = e0; e < e1; ++e) {
+                        const int f = adj_face[e], c = adj_corner[e];
+                        const float3 p0 = lds_rec(vs, faces[3 * f]), p1 = lds_rec(vs, faces[3 * f + 1]), p2 = lds_rec(vs, faces[3 * f + 2]);
+                        float3 nn;
+                        if (c == 1) nn = cross3(sub3(p2, p1), sub3(p0, p1));
+                        else if (c == 2) nn = cross3(sub3(p0, p2), sub3(p1, p2));
+                        else nn = cross3(sub3(p1, p0), sub3(p2, p0));
+                        acc.x += nn.x; acc.y += nn.y; acc.z += nn.z;
+                    }
+                }
+                const float nl = fmaxf(sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z), 1e-6f);
+                const float vx = qx - v3.x, vy = qy - v3.y, vz = qz - v3.z;
+                const float dt = (acc.x / nl) * vx + (acc.y / nl) * vy + (acc.z / nl) * vz;
+                const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float o2h = d * (dt > 0.f ? 1.f : (dt < 0.f ? -1.f : 0.f));
+                if (o2h_out) o2h_out[(size_t)n * P + i] = o2h;
+                if (idx_out) idx_out[(size_t)n * P + i] = org;
+                pl[sp] = o2h < 0.f ? fabsf(o2h) * 20.0f : 0.f;                  // eval_smpl_short.py:113-119
+            }
         }
-        // resolve the index inside the winning block: lowest vertex whose (bit-identical) distance equals the minimum
-#pragma unroll
-        for (int k = 0; k < QP; ++k) {
-            const float bk = (k & 1) ? best[k >> 1].y : best[k >> 1].x;
-            int idx = bblk[k];
-#pragma unroll
-            for (int u = VB - 1; u >= 0; --u) {
-                const float4 p = vs[bblk[k] + u];
-                if (dist2_exact(qx[k], qy[k], qz[k], p.x, p.y, p.z) == bk) idx = bblk[k] + u;
+        if (valid) {
+            for (int m = 0; m < M; ++m) {
+                const float4 mk = ms[m];
+                const float dx = mk.x - qx, dy = mk.y - qy, dz = mk.z - qz;
+                const float dm = sqrtf(dx * dx + dy * dy + dz * dz);
+                mind = fminf(mind, dm);
+                if (dm < 0.02f) flags[m] = 1;                                // benign race: all writers store 1
             }
-            bi[k] = idx;
         }
     }
-    float loss = 0.f, mind = FLT_MAX;
-#pragma unroll
-    for (int k = 0; k < QP; ++k) {
-        const int i = tid + CT * k;
-        if (i >= P) continue;
-        if (do_nn) {
-        // normal of the nearest vertex (data/tools.py:4-40 restricted to one vertex), from LDS
-        const int v = bi[k];
-        float3 acc = make_float3(0.f, 0.f, 0.f);
-        for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) {
-            const int f = adj_face[e], c = adj_corner[e];
-            const float3 p0 = f3(vs[faces[3 * f]]), p1 = f3(vs[faces[3 * f + 1]]), p2 = f3(vs[faces[3 * f + 2]]);
-            float3 nn;
-            if (c == 1) nn = cross3(sub3(p2, p1), sub3(p0, p1));
-            else if (c == 2) nn = cross3(sub3(p0, p2), sub3(p1, p2));
-            else nn = cross3(sub3(p1, p0), sub3(p2, p0));
-            acc.x += nn.x; acc.y += nn.y; acc.z += nn.z;
-        }
-        const float nl = fmaxf(sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z), 1e-6f);
-        const float4 pv = vs[v];
-        const float vx = qx[k] - pv.x, vy = qy[k] - pv.y, vz = qz[k] - pv.z;
-        const float dt = (acc.x / nl) * vx + (acc.y / nl) * vy + (acc.z / nl) * vz;
-        const float d = sqrtf(vx * vx + vy * vy + vz * vz);
-        const float o2h = d * (dt > 0.f ? 1.f : (dt < 0.f ? -1.f : 0.f));
-        if (o2h_out) o2h_out[(size_t)n * P + i] = o2h;
-        if (o2h < 0.f) loss += fabsf(o2h) * 20.0f;                      // eval_smpl_short.py:113-119
-        }
-        for (int m = 0; m < M; ++m) {
-            const float4 mk = ms[m];
-            const float dx = mk.x - qx[k], dy = mk.y - qy[k], dz = mk.z - qz[k];
-            const float dm = sqrtf(dx * dx + dy * dy + dz * dz);
-            mind = fminf(mind, dm);
-            if (dm < 0.02f) flags[m] = 1;                                // benign race: all writers store 1
-        }
+    if (stats && ln == 0 && do_nn) {
+        atomicAdd(stats, (unsigned long long)n_exec);
+        atomicAdd(stats + 1, (unsigned long long)nCB * n_tasks);
+        atomicAdd(stats + 2, (unsigned long long)n_test);
     }
-    // deterministic block reductions
+    phase_done();                                                          // 3: this wave's tasks
+    __syncthreads();
+    phase_done();                                                          // 4: waiting for the other waves
+    // deterministic block reductions: the per-point losses by scan position in a fixed tree
+    float loss = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP / CT; ++k) loss += pl[tid + CT * k];
     red[tid] = loss;
     __syncthreads();
     for (int s = CT / 2; s > 0; s >>= 1) {
@@ -253,30 +509,32 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     }
     if (tid == 0) { loss_sum[n] = loss_total; min_dist[n] = red[0]; }
     if (tid < M) label[(size_t)n * M + tid] = flags[tid];
+    phase_done();                                                          // 5: reductions
+    if (stats && tid == 0 && do_nn) atomicAdd(stats + 3, 1ull);            // workgroups counted
 }
 
 // (An fp32-MFMA "filter" variant of this scan -- g~ = |p|^2 - 2 q.p on v_mfma_f32_16x16x4, exact re-evaluation of
 // the vertices inside the error band -- was built, verified bit-identical and measured on MI355X: its two sweeps run
 // at 40% of the matrix pipe next to the VALU work that reads every product, 6.1 ms vs 5.0 ms per call for this kernel.
 // The fp32 MFMA issues at the fp32 VALU rate on gfx950, so the filter cannot win)
-int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const float *obj_points, int P, const float *objR,
-                   const float *objT, const idf_correction_ctx *c, int B, float *markers, float *loss_sum, float *min_dist,
-                   int32_t *label, float *o2h, int64_t nn_from) {
+size_t contact_lds_bytes(int V) { return (size_t)ContactLds(V).total * sizeof(float4); }
+
+int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const float *obj_points, int P, int32_t *porder,
+                   const float *objR, const float *objT, const idf_correction_ctx *c, int B, float *markers, float *loss_sum,
+                   float *min_dist, int32_t *label, float *o2h, int32_t *idx, unsigned long long *stats, int64_t nn_from) {
     const int M = c->n_markers;
-    const size_t lds = ((size_t)((V + VB - 1) / VB * VB) + VB + MAXM) * sizeof(float4);
-    if (lds > 160 * 1024 - 8192 || P > MAXP) return IDF_E_INVAL;
-    // two shapes of the same scan: 16 waves x 2 points per thread (default) or 8 waves x 4 points (tune = 1: half the LDS broadcasts)
-    if (c->tune == 1) {
-        static std::atomic<uint64_t> lds_ok{0};
-        if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<512, 4>), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
-        hipLaunchKernelGGL((corr_contact_kernel<512, 4>), dim3((unsigned)N), dim3(512), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
-                           c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
-    } else {
-        static std::atomic<uint64_t> lds_ok{0};
-        if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<1024, 2>), 160 * 1024 - 8192, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
-        hipLaunchKernelGGL((corr_contact_kernel<1024, 2>), dim3((unsigned)N), dim3(1024), lds, s, verts, V, obj_points, P, objR, objT, c->faces,
-                           c->adj_ptr, c->adj_face, c->adj_corner, c->markers_idx, M, B, markers, loss_sum, min_dist, label, o2h, nn_from);
-    }
+    const size_t lds = contact_lds_bytes(V);
+    if (lds > 160 * 1024 - 16384 || P > MAXP) return IDF_E_INVAL;
+    // scan order: either all four of (vorder, faces_scan, markers_scan, adj_pair_scan) or none (identity order: same results, no culling benefit)
+    const bool ordered = c->vorder != nullptr;
+    if (ordered != (c->faces_scan != nullptr) || ordered != (c->markers_scan != nullptr) || ordered != (c->adj_pair_scan != nullptr)) return IDF_E_INVAL;
+    const int32_t *faces = ordered ? c->faces_scan : c->faces, *mpos = ordered ? c->markers_scan : c->markers_idx;
+    if (porder) hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
+    static std::atomic<uint64_t> lds_ok{0};
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, porder, objR, objT, faces,
+                       c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
+                       stats, nn_from);
     return IDF_OK;
 }
 
@@ -316,7 +574,7 @@ __global__ __launch_bounds__(256) void corr_blend_kernel(float *__restrict__ x0,
 
 struct CorrWs {
     float *pose, *trans, *objR, *objT, *gt_angles, *gt_trans, *verts, *jtr, *markers, *loss_sum, *min_dist, *proj;
-    int32_t *label, *contact;
+    int32_t *label, *contact, *porder;
     uint8_t *condition;
     void *smpl_ws;
     size_t smpl_ws_bytes, total;
@@ -344,6 +602,7 @@ CorrWs carve(const idf_correction_ctx *c, int B, int T, void *ws) {
     w.label = (int32_t *)take((size_t)N * M * 4);
     w.contact = (int32_t *)take((size_t)B * M * 4);
     w.condition = (uint8_t *)take(B);
+    w.porder = (int32_t *)take((size_t)B * c->n_points * 4);
     w.smpl_ws_bytes = interdiff_smpl_workspace_bytes(c->smpl, N);
     w.smpl_ws = take(w.smpl_ws_bytes);
     w.total = off;
@@ -376,8 +635,8 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
     int rc = interdiff_smpl_forward(c->smpl, w.pose, beta, w.trans, N, w.verts, w.jtr, nullptr, w.smpl_ws, w.smpl_ws_bytes, stream);
     if (rc) return rc;
     idf_prof_mark(IDF_K_CORR_CONTACT, s);
-    rc = launch_contact(s, N, w.verts, V, obj_points, P, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, nullptr,
-                        (int64_t)c->past_len * B);
+    rc = launch_contact(s, N, w.verts, V, obj_points, P, w.porder, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, nullptr,
+                        nullptr, nullptr, (int64_t)c->past_len * B);
     if (rc) return rc;
     uint8_t *cond = condition ? condition : w.condition;
     int32_t *cont = contact ? contact : w.contact;
@@ -476,7 +735,7 @@ __global__ __launch_bounds__(256) void metrics_reduce_kernel(const float *__rest
 
 struct MetWs {
     float *objR, *objT, *o2h, *markers, *loss_sum, *min_dist;
-    int32_t *label;
+    int32_t *label, *porder;
     size_t total;
 };
 MetWs carve_metrics(const idf_correction_ctx *c, int B, int T, void *ws) {
@@ -492,11 +751,35 @@ MetWs carve_metrics(const idf_correction_ctx *c, int B, int T, void *ws) {
     w.loss_sum = (float *)take(N * 4);
     w.min_dist = (float *)take(N * 4);
     w.label = (int32_t *)take((size_t)N * c->n_markers * 4);
+    w.porder = (int32_t *)take((size_t)B * c->n_points * 4);
     w.total = off;
     return w;
 }
 
 }  // namespace
+
+// The contact scan on its own: signed object->human distance and nearest vertex of every object point of every frame
+// (tools.point2point_signed's o2h half fused with the object transform, eval_smpl_short.py:107-112).  Frames n = t*B + b.
+extern "C" size_t interdiff_contact_nn_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T) {
+    if (!c || B <= 0 || T <= 0) return 0;
+    return carve_metrics(c, B, T, nullptr).total;
+}
+
+extern "C" int interdiff_contact_nn(const idf_correction_ctx *c, const float *verts, const float *obj_points, const float *objR,
+                                    const float *objT, int32_t B, int32_t T, float *o2h, int32_t *idx, uint64_t *stats, void *ws,
+                                    size_t ws_bytes, void *stream) {
+    if (!c || !c->smpl || !verts || !obj_points || !objR || !objT || !ws || B <= 0 || T <= 0 || (!o2h && !idx)) return IDF_E_INVAL;
+    if (c->n_markers > MAXM || c->n_points > MAXP) return IDF_E_INVAL;
+    MetWs w = carve_metrics(c, B, T, ws);
+    if (ws_bytes < w.total) return IDF_E_NOMEM;
+    hipStream_t s = idf_stream(stream);
+    if (stats && hipMemsetAsync(stats, 0, IDF_CONTACT_STATS * sizeof(uint64_t), s) != hipSuccess) return IDF_E_LAUNCH;
+    const int rc = launch_contact(s, (int64_t)B * T, verts, c->smpl->V, obj_points, c->n_points, w.porder, objR, objT, c, B, w.markers, w.loss_sum,
+                                  w.min_dist, w.label, o2h ? o2h : w.o2h, idx, reinterpret_cast<unsigned long long *>(stats), 0);
+    if (rc) return rc;
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}
 
 extern "C" size_t interdiff_metrics_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T) {
     if (!c || B <= 0 || T <= 0) return 0;
@@ -518,7 +801,8 @@ extern "C" int interdiff_metrics(const idf_correction_ctx *c, const float *obj_p
     const int64_t N = (int64_t)B * T;
     idf_prof_mark(IDF_K_OTHER, s);
     hipLaunchKernelGGL(metrics_prepare_kernel, dim3((unsigned)idf_cdiv(N, 256)), dim3(256), 0, s, obj_pred, N, w.objR, w.objT);
-    const int rc = launch_contact(s, N, verts, V, obj_points, P, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h, 0);
+    const int rc = launch_contact(s, N, verts, V, obj_points, P, w.porder, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, w.o2h,
+                                  nullptr, nullptr, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(metrics_reduce_kernel, dim3(B), dim3(256), 0, s, obj_pred, jtr, body_trans, obj_gt, jtr_gt, body_trans_gt, w.o2h, B,
                        T, J, P, out6);

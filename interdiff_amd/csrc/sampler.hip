@@ -155,5 +155,8 @@ extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t st
     return IDF_OK;
 }
 
-extern "C" int interdiff_abi_version(void) { return 8; }
-extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi 6"; }
+#define IDF_ABI_VERSION 9
+#define IDF_STR_(x) #x
+#define IDF_STR(x) IDF_STR_(x)
+extern "C" int interdiff_abi_version(void) { return IDF_ABI_VERSION; }
+extern "C" const char *interdiff_build_info(void) { return "interdiff_hip gfx950 (hipcc, fp32 MFMA) abi " IDF_STR(IDF_ABI_VERSION); }

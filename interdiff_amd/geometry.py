@@ -22,10 +22,26 @@ def build_vertex_adjacency(faces, V):
     return np.cumsum(ptr).astype(np.int32), rec[:, 2].astype(np.int32), rec[:, 3].astype(np.int32)
 
 
-class MeshTopology:
-    """Device copies of faces + adjacency for one mesh (built once)."""
+def morton_order(points, bits=10):
+    """Indices that sort ``points`` [n,3] along a Morton (Z-order) curve of ``bits`` bits per axis inside their bounding box; ties
+    keep the lower index first.  Host-side, once per mesh."""
+    p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    lo, ext = p.min(0), np.maximum(p.max(0) - p.min(0), 1e-30)
+    q = np.clip(((p - lo) / ext * (2 ** bits - 1)).astype(np.int64), 0, 2 ** bits - 1)
+    code = np.zeros(len(p), dtype=np.int64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return np.argsort(code, kind='stable')
 
-    def __init__(self, faces, V, device='cuda'):
+
+class MeshTopology:
+    """Device copies of faces + adjacency for one mesh (built once).  With ``rest_vertices`` [V,3] it also carries the SCAN ORDER of
+    the exact nearest-vertex kernels (csrc/correction.hip): ``vorder`` = Morton order of the rest pose (skinning is spatially smooth,
+    so 16 consecutive scan positions stay a compact clump under any pose and whole blocks can be culled by their bounding box),
+    ``faces_scan`` = faces in scan positions.  Results never depend on the order -- only how many vertex blocks a scan can skip."""
+
+    def __init__(self, faces, V, device='cuda', rest_vertices=None):
         f = faces.detach().cpu().numpy() if isinstance(faces, torch.Tensor) else np.asarray(faces)
         if f.ndim == 3:
             f = f[0]
@@ -33,6 +49,23 @@ class MeshTopology:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.V = V
         self.faces, self.adj_ptr, self.adj_face, self.adj_corner = t(f.astype(np.int32)), t(ptr), t(adj_face), t(adj_corner)
+        self.vorder = self.faces_scan = self.rank = self.adj_pair_scan = None
+        if rest_vertices is not None:
+            order = morton_order(np.asarray(rest_vertices).reshape(V, 3))
+            rank = np.empty(V, np.int64)
+            rank[order] = np.arange(V)
+            self.rank = rank                                        # vertex -> scan position (host)
+            self.vorder, self.faces_scan = t(order.astype(np.int32)), t(rank[f].astype(np.int32))
+            # per adjacency entry (vertex v, face, corner c) the other two corners (a, b) with normal contribution (a - v) x (b - v):
+            # data/tools.py:27-39 accumulates cross(v2 - v1, v0 - v1) at corner 1, cross(v0 - v2, v1 - v2) at 2, cross(v1 - v0, v2 - v0) at 0
+            fa, co = adj_face.astype(np.int64), adj_corner.astype(np.int64)
+            a_of, b_of = np.array([1, 2, 0]), np.array([2, 0, 1])
+            self.adj_pair_scan = t(np.stack([rank[f[fa, a_of[co]]], rank[f[fa, b_of[co]]]], axis=1).astype(np.int32))
+
+    def scan_positions(self, vertex_ids, device):
+        """Scan positions of the given vertices (e.g. the marker set) as a device int32 tensor."""
+        ids = np.asarray(list(vertex_ids), dtype=np.int64)
+        return torch.from_numpy((self.rank[ids] if self.rank is not None else ids).astype(np.int32)).to(device)
 
 
 def _topology(faces, V, device):

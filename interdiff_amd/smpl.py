@@ -67,6 +67,7 @@ class SMPL_Layer:
         self.device = torch.device(device)
         self.cmodel, self._bufs = pack_smpl_model(model, self.device)
         self.th_faces = torch.from_numpy(_np(model['faces']).astype(np.int64)).to(self.device)
+        self.v_template = _np(model['v_template']).astype(np.float32).reshape(-1, 3)      # host copy: the scan order of the NN kernels is derived from it
         self.num_joints = self.cmodel.J
         self.kintree_parents = [int(p) for p in _np(model['parents'])]
         self._ws = None

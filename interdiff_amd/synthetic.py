@@ -111,7 +111,11 @@ def make_embedding_inputs(seed=77, B=3, T=35, n_points=2048):
 # ----------------------------------------------------------------------------
 # SMPL-H shaped body model (buffers of smpl_layer.py:47-69)
 # ----------------------------------------------------------------------------
-def smplh_model(seed=7, V=6890, F=13776, n_betas=10):
+def smplh_model(seed=7, V=6890, F=13776, n_betas=10, coherent=False):
+    """SMPL-H shaped stand-in.  ``coherent=False`` (the model every golden fixture was recorded with) gives each vertex a fourth bone
+    drawn at random from the whole skeleton, so neighbouring vertices can be dragged apart by unrelated joints; ``coherent=True``
+    keeps all of a vertex's bones in the kinematic neighbourhood of its primary joint (parent, grand-parent, a child or sibling),
+    which is how the real SMPL-H skinning weights look (smooth over the surface).  Both draw the same random numbers."""
     rs = np.random.RandomState(seed)
     parents = list(SMPLH_PARENTS)
     J = len(parents)
@@ -127,7 +131,12 @@ def smplh_model(seed=7, V=6890, F=13776, n_betas=10):
     # skinning weights: primary + up to 3 relatives (parent, grand-parent, random)
     weights = np.zeros((V, J))
     par = np.array([max(p, 0) for p in parents])
-    others = np.stack([par[prim], par[par[prim]], rs.randint(0, J, size=V)], axis=1)
+    third = rs.randint(0, J, size=V)
+    if coherent:
+        kids = [[c for c in range(1, J) if parents[c] == j] for j in range(J)]
+        near = [kids[j] + [c for c in kids[par[j]] if c != j] + [int(par[j])] for j in range(J)]     # children, then siblings, then the parent
+        third = np.array([near[prim[v]][third[v] % len(near[prim[v]])] for v in range(V)])
+    others = np.stack([par[prim], par[par[prim]], third], axis=1)
     w = np.concatenate([rs.uniform(0.5, 1.0, (V, 1)), rs.uniform(0.0, 0.3, (V, 3))], axis=1)
     w[rs.uniform(size=(V, 4)) < 0.15] = 0.0                     # some vertices have < 4 bones
     w[:, 0] = np.maximum(w[:, 0], 0.2)

@@ -244,3 +244,35 @@ def test_qkv_pack_and_kernel_addressing_by_emulation():
     for late in (False, True):
         assert np.abs(emulate_ln_linear(slabs, lnw, lnb, pack, b, N, late) - (xn @ w.T.astype(np.float64) + b)).max() < 1e-9
     assert np.abs(emulate_ln_linear(slabs[:1], None, None, pack, b, N, True) - (slabs[0].astype(np.float64) @ w.T + b)).max() < 1e-9
+
+
+def test_scan_order_is_a_consistent_relabelling():
+    """Host side of the exact block culling (interdiff_amd/geometry.py MeshTopology): vorder is a permutation, faces_scan / marker
+    positions are the same mesh relabelled, and 16 consecutive scan positions of the rest pose are spatially compact."""
+    import numpy as np
+    import torch
+    from interdiff_amd import synthetic as syn
+    from interdiff_amd.geometry import MeshTopology, morton_order
+    m = syn.smplh_model(seed=7)
+    V = m['v_template'].shape[0]
+    topo = MeshTopology(torch.from_numpy(m['faces']), V, device='cpu', rest_vertices=m['v_template'])
+    order = topo.vorder.numpy().astype(np.int64)
+    assert sorted(order.tolist()) == list(range(V))
+    assert np.array_equal(order[topo.faces_scan.numpy()], m['faces'])
+    # adjacency as (a, b) pairs: (v, a, b) is the incident face, rotated so that v comes first (orientation kept)
+    ptr, fa = topo.adj_ptr.numpy(), topo.adj_face.numpy()
+    pair = order[topo.adj_pair_scan.numpy()]
+    for v in (0, 5, 1234, V - 1):
+        for e in range(ptr[v], ptr[v + 1]):
+            f = m['faces'][fa[e]].tolist()
+            assert [v, pair[e, 0], pair[e, 1]] in (f, f[1:] + f[:1], f[2:] + f[:2]), (v, e)
+    ids = [0, 17, 6889, 3470]
+    assert np.array_equal(order[topo.scan_positions(ids, 'cpu').numpy()], ids)
+    assert MeshTopology(torch.from_numpy(m['faces']), V, device='cpu').vorder is None
+    vt = m['v_template'][order]
+    nb = V // 16
+    ext = np.linalg.norm(vt[:nb * 16].reshape(nb, 16, 3).max(1) - vt[:nb * 16].reshape(nb, 16, 3).min(1), axis=1)
+    whole = np.linalg.norm(vt.max(0) - vt.min(0))
+    assert np.median(ext) < 0.1 * whole, (np.median(ext), whole)
+    pts = np.array([[0., 0, 0], [1, 1, 1], [0, 0, 0], [0.5, 0.5, 0.5]])
+    assert morton_order(pts).tolist() == [0, 2, 3, 1]               # ties keep the lower index first

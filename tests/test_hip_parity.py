@@ -186,6 +186,93 @@ def test_nn_argmin_full_size_bit_exact(lib):
     assert torch.equal(nn_argmin(x.to(DEV), y.to(DEV)).cpu().long(), ogeo.nn_argmin(x, y))
 
 
+def _posed_body(smpl_layer, n_frames, seed):
+    g = torch.Generator().manual_seed(seed)
+    pose = 0.35 * torch.randn(n_frames, 156, generator=g)
+    return smpl_layer(pose.to(DEV), th_betas=torch.randn(n_frames, 10, generator=g).to(DEV), th_trans=0.1 * torch.randn(n_frames, 3, generator=g).to(DEV))[0]
+
+
+def test_contact_scan_block_culling_is_exact(smpl):
+    """The nearest-vertex scan of the hook (csrc/correction.hip corr_contact_kernel: Morton scan order, 16-vertex blocks culled by
+    their boxes per wave) against the brute-force oracle: indices bit-identical with and without the scan order, on a posed body,
+    with the object near / inside / far from the body, duplicated vertices (ties inside a block, across blocks, a 100-vertex clump
+    -> the all-records tie fallback), the winner in the last (partial: 6890 % 16 = 10) block; and the culling really happens."""
+    T, B, P = 3, 2, 2048
+    g = torch.Generator().manual_seed(77)
+    verts = _posed_body(smpl, T * B, 5).reshape(T, B, 6890, 3).clone()
+    pts = torch.empty(B, P, 3)
+    pts[0] = 0.25 * torch.randn(P, 3, generator=g) + torch.tensor([0.3, 0.1, 0.0])      # overlapping the body
+    pts[1] = 0.2 * torch.rand(P, 3, generator=g) + torch.tensor([1.5, -0.8, 0.4])         # a box 1.5 m away
+    corr_on, corr_off = make_correction(smpl, 14, P), None
+    from interdiff_amd.objprojector import ObjProjector
+    from interdiff_amd.correction import HipCorrection
+    corr_off = HipCorrection(smpl, ObjProjector(fx.objproj_weights(), T=14, past_len=fx.PAST, device=DEV), n_points=P, past_len=fx.PAST, device=DEV,
+                             scan_order=False)
+    assert corr_on.ctx.vorder and not corr_off.ctx.vorder
+    order = corr_on.topo.vorder.cpu().long()
+    # adversarial vertices (frame (t, b)): exact duplicates
+    verts[0, 0, 40] = verts[0, 0, 3]                                       # a pair (lowest index must win)
+    verts[0, 0, 2000:2100] = verts[0, 0, 2000].clone()                     # a clump of 100 identical vertices
+    verts[1, 0, int(order[-1])] = pts[0, 7].to(DEV)                        # the LAST scan position is somebody's nearest vertex (distance 0)
+    verts[1, 1, 6889] = verts[1, 1, 0]                                     # duplicate of vertex 0 at the highest index
+    pts[0, 11] = verts[0, 0, 3].cpu()                                      # queries sitting exactly on the duplicated vertices
+    pts[0, 12] = verts[0, 0, 2050].cpu()
+    pts[1, 5] = verts[1, 1, 0].cpu()
+    eye, zero = torch.eye(3).expand(T, B, 3, 3).contiguous(), torch.zeros(T, B, 3)
+    want = ogeo.nn_argmin(pts[None].expand(T, B, P, 3).reshape(T * B, P, 3), verts.cpu().reshape(T * B, 6890, 3)).reshape(T, B, P)
+    assert want[0, 0, 11] == 3 and want[0, 0, 12] == 2000 and want[1, 0, 7] == int(order[-1]) and want[1, 1, 5] == 0
+    frac = {}
+    for name, corr in (('scan order', corr_on), ('identity order', corr_off)):
+        o2h, idx, (scored, tested, boxtests, *_) = corr.contact_nn(verts, pts.to(DEV), eye.to(DEV), zero.to(DEV), want_stats=True)
+        assert torch.equal(idx.cpu().long(), want), '%s: %d indices differ' % (name, (idx.cpu().long() != want).sum())
+        frac[name] = scored / tested
+        frac[name + ' box tests per block'] = boxtests / tested
+        if name == 'scan order':
+            keep = o2h
+        else:
+            assert torch.equal(o2h, keep), 'signed distances must not depend on the scan order'
+    print('blocks scored / tested:', frac)
+    assert frac['scan order'] < 0.5, frac                                  # overlapping + far object, synthetic (loosely skinned) body
+    # with a rigid transform: distances against the oracle (indices can legitimately differ where the transformed point differs in
+    # its last bit, so compare the unsigned distance)
+    Rm = R.axis_angle_to_matrix(torch.randn(T, B, 3, generator=g))
+    tr = 0.3 * torch.randn(T, B, 3, generator=g)
+    o2h, idx = corr_on.contact_nn(verts, pts.to(DEV), Rm.to(DEV), tr.to(DEV))
+    q = torch.matmul(pts[None], Rm.transpose(-1, -2)) + tr[:, :, None]
+    near = torch.gather(verts.cpu(), 2, idx.cpu().long()[..., None].expand(-1, -1, -1, 3))
+    dist_at_idx = (q - near).norm(dim=-1)
+    ref = ogeo.nn_argmin(q.reshape(T * B, P, 3), verts.cpu().reshape(T * B, 6890, 3)).reshape(T, B, P)
+    near_ref = torch.gather(verts.cpu(), 2, ref[..., None].expand(-1, -1, -1, 3))
+    close(dist_at_idx, (q - near_ref).norm(dim=-1), 1e-6, 'distance to the nearest vertex under a rigid transform')
+    close(o2h.abs(), dist_at_idx, 1e-6, '|o2h|')
+    assert (idx.cpu().long() == ref).float().mean() > 0.999
+
+
+def test_contact_scan_small_mesh_and_ragged_points(lib):
+    """A body model with V = 1037 (not a multiple of 16, 65 blocks) and P = 1000 object points (fewer than a workgroup's 2048 slots):
+    indices against the oracle, both orders."""
+    from interdiff_amd import synthetic as syn
+    from interdiff_amd.smpl import SMPL_Layer
+    from interdiff_amd.objprojector import ObjProjector
+    from interdiff_amd.correction import HipCorrection
+    V, P, T, B = 1037, 1000, 2, 3
+    np_model = syn.smplh_model(seed=11, V=V, F=2100)
+    layer = SMPL_Layer({k: torch.from_numpy(v) for k, v in np_model.items()}, device=DEV)      # only its topology / rest pose are used here
+    g = torch.Generator().manual_seed(3)
+    # "posed" vertices = the rest pose bent smoothly (the body-model kernel itself only supports V = 6890-class tilings)
+    vt = torch.from_numpy(np_model['v_template'])
+    verts = torch.stack([vt + 0.1 * torch.sin(3.0 * vt.roll(1, dims=1) + i) for i in range(T * B)]).reshape(T, B, V, 3).to(DEV)
+    pts = 0.3 * torch.randn(B, P, 3, generator=g)
+    eye, zero = torch.eye(3).expand(T, B, 3, 3).contiguous(), torch.zeros(T, B, 3)
+    want = ogeo.nn_argmin(pts[None].expand(T, B, P, 3).reshape(T * B, P, 3), verts.cpu().reshape(T * B, V, 3)).reshape(T, B, P)
+    for so in (True, False):
+        corr = HipCorrection(layer, ObjProjector(fx.objproj_weights(), T=14, past_len=fx.PAST, device=DEV), n_points=P, past_len=fx.PAST, device=DEV,
+                             markers=list(range(67)), scan_order=so)
+        o2h, idx = corr.contact_nn(verts, pts.to(DEV), eye.to(DEV), zero.to(DEV))
+        assert torch.equal(idx.cpu().long(), want), 'scan_order=%s' % so
+        assert torch.isfinite(o2h).all()
+
+
 # ------------------------------------------------------------------------------------------ ObjProjector (D1-D2)
 @pytest.mark.parametrize('tag,T,B', [('a', 35, 3), ('b', 100, 2)])
 def test_objprojector_golden(lib, tag, T, B):

@@ -28,14 +28,16 @@ def main():
     dev, B, T, P, past = 'cuda', args.B, args.T, 2048, 10
     z = np.load(os.path.join(ROOT, 'tests', 'golden', 'correction_ckpt.npz'))
     smpl = SMPL_Layer(syn.smplh_model(7), device=dev)
-    corr = HipCorrection(smpl, ObjProjector({k: z[k] for k in z.files}, T=T, past_len=past, device=dev), n_points=P, past_len=past, device=dev)
+    mk = lambda so: HipCorrection(smpl, ObjProjector({k: z[k] for k in z.files}, T=T, past_len=past, device=dev), n_points=P, past_len=past, device=dev,
+                                  scan_order=so)
     bt = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in syn.make_clip_batch(seed=233, B=B, T=T, past_len=past, n_points=P).items()}
     pad = list(range(past)) + [past - 1] * (T - past)
     y = dict(inpainted_motion=bt['gt'], hand_pose=bt['hand_pose'][pad].contiguous(), beta=bt['beta'], obj_points=bt['obj_points'])
     x = bt['gt'] + 0.05 * torch.randn_like(bt['gt'])
     out = {}
     ref = None
-    for tune in (0, 1):
+    for name, so, tune in (('scan_order', True, 0), ('identity_order', False, 0)):
+        corr = mk(so)
         corr.ctx.tune = tune
         corr.debug = {}
         got = corr.apply(x.clone(), 250, y)
@@ -53,7 +55,7 @@ def main():
         ms = (C.c_double * len(_lib.KERNEL_KINDS))()
         cnt = (C.c_int64 * len(_lib.KERNEL_KINDS))()
         _lib.check(lib.interdiff_profile_end(ms, cnt))
-        out['tune%d' % tune] = dict(identical_to_tune0=same, **{k: round(1e3 * ms[i] / cnt[i], 1) for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]})
+        out[name] = dict(identical_to_first=same, **{k: round(1e3 * ms[i] / cnt[i], 1) for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]})
     print(json.dumps(out))
 
 

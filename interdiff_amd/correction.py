@@ -40,14 +40,26 @@ class HipCorrection:
             ctx.vorder, ctx.faces_scan, ctx.markers_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.markers_scan.data_ptr()
             ctx.adj_pair_scan = self.topo.adj_pair_scan.data_ptr()
         self.ctx = ctx
-        self._ws = None
+        self._ws = {}
         self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call
 
     def _workspace(self, B, T):
+        """One workspace per STREAM the hook is called on: the sampler calls it for the two halves of a batch on two streams at once."""
         need = self.lib.interdiff_correction_workspace_bytes(C.byref(self.ctx), B, T)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    @staticmethod
+    def slice_kwargs(model_kwargs, sl):
+        """``model_kwargs`` of the clips ``sl`` of the batch (every entry of ``y`` the hook reads is per clip, eval_smpl_short.py:88-106):
+        what lets the sampler call the hook per half batch.  Contiguous copies, made once per sample."""
+        y = model_kwargs['y']
+        per_clip_dim = dict(inpainted_motion=0, inpainting_mask=0, obj_points=0, hand_pose=1, beta=1, cond=1)
+        ys = {k: (v[(slice(None),) * per_clip_dim[k] + (sl,)].contiguous() if k in per_clip_dim and isinstance(v, torch.Tensor) else v) for k, v in y.items()}
+        return dict(model_kwargs, y=ys)
 
     def apply(self, x, t0, y):
         """Run the correction unconditionally for timestep value t0 (host int); x [B,1,144,T] in place."""

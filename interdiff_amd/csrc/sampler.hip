@@ -50,18 +50,19 @@ __global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int
 
 // Device-parameterised step update: every per-step scalar comes from HBM (coefficient table row of the current
 // timestep, loop index and seed from the sampler state), so ONE captured hipGraph of [denoiser forward -> this ->
-// advance] replays for every plain step of the loop.  state = {t, loop_index, seed}; table[t] = {c1, c2, sigma, t/1000}.
+// advance] replays for every plain step of the loop.  state = {t, loop_index, seed, -, -, -, elem0}; table[t] = {c1, c2, sigma, t/1000};
+// elem0 (a multiple of 4) = position of x[0] inside the whole sample: a chain of a split batch draws the whole batch's noise.
 __global__ __launch_bounds__(256) void posterior_dev_kernel(float *__restrict__ x, const float *__restrict__ x0,
                                                             const float *__restrict__ gt, const uint8_t *__restrict__ mask,
                                                             int64_t n, const float *__restrict__ table,
                                                             int64_t *__restrict__ state, int64_t *__restrict__ ts, int B) {
     const int64_t t = state[0];
-    const uint64_t it = (uint64_t)state[1], seed = (uint64_t)state[2];
+    const uint64_t it = (uint64_t)state[1], seed = (uint64_t)state[2], g0 = (uint64_t)state[6] >> 2;
     const float c1 = table[t * 4], c2 = table[t * 4 + 1], sigma = table[t * 4 + 2];
     const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
         const int64_t i = g * 4;
-        const float4 e = randn4(seed, it, (uint64_t)g);
+        const float4 e = randn4(seed, it, g0 + (uint64_t)g);
         const float ev[4] = {e.x, e.y, e.z, e.w};
         if (i + 3 < n) {
             float4 xv = *reinterpret_cast<float4 *>(x + i);

@@ -42,6 +42,7 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
 GRAPH_BLOCKS = (49, 7, 1)          # plain steps per captured hipGraph (49 = the gap between two correction steps)
 SPLIT_MAX_BATCH = int(os.environ.get('INTERDIFF_SPLIT_MAX_BATCH', 32))      # plain steps of a batch of up to this many clips run as N_CHAINS independent chains (see _graph_loop)
 N_CHAINS = int(os.environ.get('INTERDIFF_CHAINS', 2))
+STAGGER_STEPS = int(os.environ.get('INTERDIFF_STAGGER', 0))      # > 0: the chains step through the whole loop on their own streams, chain c this many plain steps behind chain c - 1, the hook called per half batch (measured 5 % SLOWER at B = 16, equal at B = 32, tools/stagger_ab.py: not the default); 0: chains forked / joined inside every graph block, whole-batch hook steps
 MAX_GRAPH_SHAPES = 8               # captured (shape, mask, cond) entries kept per denoiser before the cache is dropped wholesale
 _UID = itertools.count(1)
 
@@ -76,6 +77,7 @@ class GaussianDiffusion:
         self._tables = {}
         self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
         self.split_chains = True             # ... and, for batches that do not fill the chip, as two independent half-batch chains
+        self.stagger_steps = STAGGER_STEPS   # ... which step through the WHOLE loop on their own streams, this many steps apart, when the hook can be called per half batch
         self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
     # ------------------------------------------------------------------ helpers
@@ -192,13 +194,15 @@ class GaussianDiffusion:
             return st.graphs[(k, fused, split)]
         st.x.copy_(img)
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, 0, 0], dtype=torch.int64))
+        gate = getattr(denoised_fn, 'is_active', None)
+        active = lambda i: denoised_fn is not None and (gate is None or gate(i))
+        if split and self.stagger_steps > 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs'):
+            return self._staggered_chains(model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask)
         if split:                                   # the other chains' states: the same schedule position, their x starts c chain-sizes in
             for c, ch in enumerate(st.chains[1:], 1):
                 ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
-        gate = getattr(denoised_fn, 'is_active', None)
-        active = lambda i: denoised_fn is not None and (gate is None or gate(i))
         dump, it, i, end = [], 0, t_start, t_start - todo
         while i > end:
             if active(i):
@@ -234,6 +238,103 @@ class GaussianDiffusion:
             if dump_steps is not None and (it - 1) in dump_steps:
                 dump.append(st.x.clone())
         return dump if dump_steps is not None else st.x.clone()
+
+    def _staggered_chains(self, model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask):
+        """The two-chain form taken to the whole loop: every half batch is stepped from the first to the last timestep on its OWN stream --
+        plain steps as captured per-chain graphs, hook steps eagerly on the half batch (``denoised_fn.slice_kwargs``: every operand of
+        the hook is per clip, eval_smpl_short.py:88-106) -- and chain c starts c x ``stagger_steps`` plain steps after chain 0.  The
+        correction (VALU-bound contact scan, a 16-workgroup ObjProjector) of one chain then runs beside the plain steps (matrix pipe,
+        latency) of the other instead of stopping the whole sample eleven times.  Clips never interact and every chain draws its
+        noise at the whole batch's Philox counters (state[6]), so the sample is bit-identical to the joined form and to the eager loop."""
+        lib = _lib.load()
+        dev, B = st.x.device, st.x.shape[0]
+        chains, h = st.chains, st.x.shape[0] // len(st.chains)
+        end = t_start - todo
+        # ---- the schedule, the same for every chain: plain runs in captured block sizes, hook steps, dump points
+        prog, i, it = [], t_start, 0
+        lag_at = self.stagger_steps if todo > self.stagger_steps else 0
+        while i > end:
+            if active(i):
+                prog.append(('hook', i))
+                k = 1
+            else:
+                run = 1
+                while (i - run > end and not active(i - run) and not (dump_steps is not None and (it + run - 1) in dump_steps)
+                       and it + run != lag_at):
+                    run += 1
+                k = next(b for b in GRAPH_BLOCKS if b <= run)
+                prog.append(('plain', k))
+            i -= k
+            it += k
+            if it == lag_at:
+                prog.append(('lag',))              # chain c + 1 may start once chain c is here
+            if dump_steps is not None and (it - 1) in dump_steps:
+                prog.append(('dump',))
+        n_lag = next((j + 1 for j, op in enumerate(prog) if op[0] == 'lag'), 1 if prog else 0)       # ops chain c + 1 trails chain c by (host enqueue order)
+        # ---- per-chain graphs (captured before anything is enqueued: a capture synchronises the device)
+        cur = torch.cuda.current_stream(dev)
+        need_k = sorted({op[1] for op in prog if op[0] == 'plain'})
+        need_fwd = any(op[0] == 'hook' for op in prog)
+        for c, ch in enumerate(chains):
+            if not hasattr(ch, 'x0'):
+                ch.x0, ch.graphs = st.x0[ch.sl], {}
+            for k in need_k:
+                if k not in ch.graphs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(k):
+                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws)
+                    ch.graphs[k] = g
+            if need_fwd and 'fwd' not in ch.graphs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    model(ch.x, ch.ts, out=ch.x0, memctx=ch.memctx, ws=ch.ws)
+                ch.graphs['fwd'] = g
+        for c, ch in enumerate(chains):
+            ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))
+        st.ts.fill_(t_start)
+        ts_all = self._timesteps(B, dev)
+        kw = [denoised_fn.slice_kwargs(model_kwargs, ch.sl) for ch in chains] if need_fwd else None
+        dumps = [torch.empty_like(st.x) for op in prog if op[0] == 'dump']
+
+        def run_op(c, ch, op, n_dump):
+            if op[0] == 'plain':
+                ch.graphs[op[1]].replay()
+            elif op[0] == 'hook':
+                i = op[1]
+                ch.graphs['fwd'].replay()
+                if has_mask:
+                    _lib.check(lib.interdiff_inpaint(_lib.dptr(ch.x0), _lib.dptr(ch.gt), _lib.dptr(ch.mask), ch.x0.numel(), _lib.stream()), 'inpaint')
+                t = ts_all[i][ch.sl]
+                t.host_value = i
+                x0 = denoised_fn(ch.x0, t, kw[c]).contiguous()
+                _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(ch.x), _lib.dptr(x0), None, None, ch.x.numel(), _lib.dptr(table),
+                                                            _lib.dptr(ch.state), _lib.dptr(ch.ts), h, _lib.stream()), 'posterior_step_dev')
+            elif op[0] == 'dump':
+                dumps[n_dump][ch.sl].copy_(ch.x)
+            elif op[0] == 'lag' and c + 1 < len(chains):
+                ch.lag_event = torch.cuda.Event()
+                ch.lag_event.record()
+
+        # ---- enqueue: chain c runs op j - c * n_lag at host step j, so that chain c's 'lag' event exists before chain c + 1 waits for it
+        n_dump = [0] * len(chains)
+        for ch in chains:
+            ch.stream.wait_stream(cur)
+        for j in range(len(prog) + n_lag * (len(chains) - 1)):
+            for c, ch in enumerate(chains):
+                jj = j - c * n_lag
+                if not 0 <= jj < len(prog):
+                    continue
+                with torch.cuda.stream(ch.stream):
+                    if jj == 0 and c > 0 and getattr(chains[c - 1], 'lag_event', None) is not None:
+                        ch.stream.wait_event(chains[c - 1].lag_event)
+                    run_op(c, ch, prog[jj], n_dump[c])
+                    if prog[jj][0] == 'dump':
+                        n_dump[c] += 1
+        for ch in chains:
+            cur.wait_stream(ch.stream)
+            ch.lag_event = None
+        return dumps if dump_steps is not None else st.x.clone()
 
     def _step(self, model, img, x0_buf, i, it, t, model_kwargs, denoised_fn, noise_i, seed):
         lib = _lib.load()

@@ -368,21 +368,27 @@ class MDM:
                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_encode')
         return cond, gt
 
-    def forward(self, x, timesteps, y=None, out=None):
-        if y is None or 'cond' not in y:
-            raise ValueError("model_kwargs['y']['cond'] is required")
-        cond = y['cond']
-        if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
-            self.prepare_memory(cond)
+    def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None):
+        """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted)."""
         B, one, Cc, T = x.shape
+        if memctx is None:
+            if y is None or 'cond' not in y:
+                raise ValueError("model_kwargs['y']['cond'] is required")
+            cond = y['cond']
+            if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
+                self.prepare_memory(cond)
+            memctx = self._memctx
+        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats(B):
+            raise ValueError('memctx was folded for another batch size')
         if one != 1 or Cc != self.w.C:
             raise ValueError('x must be [B,1,%d,T]' % self.w.C)
         x = x.contiguous()
         ts = timesteps.to(torch.int64).contiguous()
         if out is None:
             out = torch.empty_like(x)
-        ws = self._workspace(B, T)
-        _lib.check(self.lib.interdiff_mdm_forward(C.byref(self.w), _lib.dptr(self._memctx), _lib.dptr(x, torch.float32),
+        if ws is None:
+            ws = self._workspace(B, T)
+        _lib.check(self.lib.interdiff_mdm_forward(C.byref(self.w), _lib.dptr(memctx), _lib.dptr(x, torch.float32),
                                                   _lib.dptr(ts, torch.int64), B, T, _lib.dptr(out, torch.float32),
                                                   _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_forward')
         return out

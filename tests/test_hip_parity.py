@@ -1200,8 +1200,16 @@ def test_two_chain_plain_steps_equal_single_chain_and_eager(mdm, smpl):
                 assert diff.split_chains
                 two = run()
                 st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(noise.shape)]
-                assert any(hasattr(v, 'chains') and any(key[2] for key in v.graphs if isinstance(key, tuple)) for v in st), 'split route not taken'
+                joined = lambda v: any(key[2] for key in v.graphs if isinstance(key, tuple))                 # chains forked / joined inside every graph block
+                apart = lambda v: all(getattr(ch, 'graphs', None) for ch in v.chains)                         # chains on their own streams, own graphs
+                assert any(hasattr(v, 'chains') and (joined(v) or apart(v)) for v in st), 'split route not taken'
                 assert torch.equal(two, run()), 'graph reuse'
+                if hook is not None:                 # the staggered per-chain loop (option: hook called per half batch, chains on their own streams) against the default
+                    diff.stagger_steps = 7
+                    staggered = run()
+                    diff.stagger_steps = 0
+                    assert any(hasattr(v, 'chains') and apart(v) for v in st), 'staggered route not taken'
+                    assert torch.equal(two, staggered), 'staggered chains differ from joined chains: %g' % (two - staggered).abs().max()
                 diff.split_chains = False
                 one = run()
                 diff.split_chains = True
@@ -1271,6 +1279,9 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     eager = run(step_noise=_philox_step(lib, seed), use_graph=False)
     assert torch.equal(timed, eager), 'timed route differs from the eager injected-noise route at B=%d: %g' % (B, (timed - eager).abs().max())
     assert torch.equal(timed, run(seed=seed)), 'graph reuse'
+    diff.stagger_steps = 7                   # the optional staggered form (chains on their own streams, hook per half batch): same bits
+    assert torch.equal(timed, run(seed=seed)), 'staggered chains differ from the joined form (whole-batch hook steps)'
+    diff.stagger_steps = 0
     assert torch.isfinite(timed).all()
     fx.record_parity('timed_route_vs_eager_B%d_T100_P2048_120steps_from_t560' % B, bit_identical=1.0, corrected_steps_inside=2)
 

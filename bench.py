@@ -330,6 +330,7 @@ def main():
     wall_local, out = timed_samples(diff, model, corr, bt, y, n_samples)
     idist.barrier()
     wall = idist.max_over_ranks(wall_local, dev)
+    wall_ranks = idist.gather_scalar(wall_local, dev)        # every rank's own clock around the same region: a straggler shows
     assert torch.isfinite(out).all()
     n_timed = n_samples * STEPS
     log('timed region: %d whole sample(s) = %d steps (incl. %d correction steps) in %.3f s' % (n_samples, n_timed, 11 * n_samples, wall))
@@ -408,13 +409,16 @@ def main():
                 unit='frame-steps/s', n_gpus=world, steps=n_timed, steps_requested=K, warmup=args.warmup, ms_per_step=1e3 * wall / n_timed,
                 higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                 steps_per_sec=n_timed / wall,
+                steps_note='--steps is advisory: the timed region is always ceil(steps / 1000) WHOLE 1000-step samples (989 plain + 11 corrected steps each)',
+                ms_per_step_by_rank=dict(min=1e3 * min(wall_ranks) / n_timed, max=1e3 * max(wall_ranks) / n_timed,
+                                         all=[round(1e3 * w_ / n_timed, 5) for w_ in wall_ranks]),
                 config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
                                      '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
                                      'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
                             global_batch=Btot, seq_len=T, samples_in_region=n_samples, correction_steps_in_region=11 * n_samples,
                             plain_steps_in_region=989 * n_samples, timesteps='%d whole sample(s): t = 999..0' % n_samples,
                             parallelism='clips sharded x%d' % world))
-    line['eval_collation'] = dict(collective='all_gather of [6, B_local] fp32 (%s), %d ranks' % ('RCCL' if world > 1 else 'degenerate: 1 rank', world),
+    line['eval_collation'] = dict(collective='ONE all_gather of [7, B_local] fp32 (count header + six metric rows; %s), %d ranks' % ('RCCL' if world > 1 else 'degenerate: 1 rank', world),
                                   seconds_sample_plus_metrics=eval_s, clips=Btot, means=means,
                                   note='random-init denoiser: the metric values only serve as parity evidence against the oracle')
     line.update(extra)

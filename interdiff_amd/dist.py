@@ -49,20 +49,40 @@ def shard_batch(batch, rank, world, batch_dims):
     return out
 
 
-def gather_metrics(local, world):
-    """local: dict name -> [B_local] tensor.  Returns dict name -> [B_total] (rank order) on every rank."""
+def gather_metrics(local, world, counts=None, return_header=False):
+    """local: dict name -> [B_local] tensor.  Returns dict name -> [B_total] (rank order) on every rank.
+
+    ONE fixed-size all-gather and no host synchronisation: every rank's shard size is known by construction (``counts``: the
+    ``shard_slice`` sizes of the global batch; None = equal shards of this rank's size), so the buffer is [7, max(counts)] floats --
+    row 0 carries the sender's own count in slot 0 (a header the receiver can verify, ``return_header``: device tensor [world], never
+    read on the hot path), rows 1..6 the six metric vectors, zero padded."""
     stacked = torch.stack([local[k].float() for k in METRIC_KEYS])                 # [6, B_local]
+    n = stacked.shape[1]
     if world == 1 or not dist.is_initialized():
-        return {k: stacked[i] for i, k in enumerate(METRIC_KEYS)}
-    sizes = [torch.zeros(1, dtype=torch.int64, device=stacked.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([stacked.shape[1]], dtype=torch.int64, device=stacked.device))
-    mx = int(max(s.item() for s in sizes))
-    pad = torch.zeros(6, mx, device=stacked.device)
-    pad[:, :stacked.shape[1]] = stacked
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)                                                      # the one data collective
-    full = torch.cat([b[:, :int(s.item())] for b, s in zip(bufs, sizes)], dim=1)
-    return {k: full[i] for i, k in enumerate(METRIC_KEYS)}
+        out = {k: stacked[i] for i, k in enumerate(METRIC_KEYS)}
+        return (out, torch.tensor([float(n)], device=stacked.device)) if return_header else out
+    counts = [n] * world if counts is None else [int(c) for c in counts]
+    cap = max(max(counts), 1)
+    if len(counts) != world or n > cap:
+        raise ValueError('counts must list every rank\'s shard size')
+    buf = torch.zeros(7, cap, device=stacked.device)
+    buf[0, 0] = float(n)
+    buf[1:, :n] = stacked
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)                                                      # the one collective of the path
+    full = torch.cat([b[1:, :c] for b, c in zip(bufs, counts)], dim=1)
+    out = {k: full[i] for i, k in enumerate(METRIC_KEYS)}
+    return (out, torch.stack([b[0, 0] for b in bufs])) if return_header else out
+
+
+def gather_scalar(value, device):
+    """Every rank's float, in rank order, on every rank (bench.py: per-rank wall times, so that a straggler shows)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return [float(value)]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def max_over_ranks(value, device):
@@ -92,9 +112,12 @@ def _selftest_worker(rank, world, port):
     B = 5                                                                           # uneven on purpose
     full = {k: torch.arange(B, dtype=torch.float32) + 10 * i for i, k in enumerate(METRIC_KEYS)}
     sl = shard_slice(B, r, w)
-    got = gather_metrics({k: v[sl] for k, v in full.items()}, w)
+    counts = [shard_slice(B, q, w).stop - shard_slice(B, q, w).start for q in range(w)]
+    got, header = gather_metrics({k: v[sl] for k, v in full.items()}, w, counts=counts, return_header=True)
     for k in METRIC_KEYS:
         assert torch.equal(got[k], full[k]), (k, got[k], full[k])
+    assert header.tolist() == [float(c) for c in counts]                            # every sender's own count travelled in its header slot
+    assert gather_scalar(r + 0.25, 'cpu') == [q + 0.25 for q in range(w)]
     batch = shard_batch({'gt': torch.arange(B * 3).reshape(B, 3), 'cond': torch.arange(2 * B).reshape(2, B), 'past_len': 10},
                         r, w, {'gt': 0, 'cond': 1})
     assert batch['gt'].shape[0] == sl.stop - sl.start and batch['cond'].shape[1] == sl.stop - sl.start and batch['past_len'] == 10
@@ -111,7 +134,7 @@ def _selftest_eval_worker(rank, world, port):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from . import eval as ev
     r, w, _ = init_from_env('gloo')
-    B, T, P, div = 5, 12, 8, 3                                       # uneven shards on purpose
+    B, T, P, div = (5 if world <= 4 else 64), 12, 8, 3               # 2 ranks: uneven shards on purpose; 8 ranks: BASELINE config #4's 64 clips = 8 per rank
     batch = dict(gt=torch.arange(B, dtype=torch.float32)[:, None, None, None].expand(B, 1, 144, T).contiguous(),
                  cond=torch.zeros(10, B, 256), hand_pose=torch.zeros(T, B, 90), beta=torch.zeros(T, B, 10), obj_points=torch.zeros(B, P, 3))
     calls = []
@@ -143,5 +166,48 @@ def _selftest_eval_worker(rank, world, port):
     finally:
         ev.evaluate_batch = real
     assert full2['global_mpjpe'].numel() == B * w
+    barrier()
+    shutdown()
+
+
+def _selftest_long_worker(rank, world, port):
+    """eval.sample_long_sharded on CPU ranks (gloo): BASELINE config #4's partitioning -- every rank rolls its own clips out, no
+    exchange.  Stand-ins replace the GPU pieces (conditioning, one sampled window) by per-clip deterministic functions; what is
+    under test is the clip shard of every raw tensor, the per-rank seed offset, the window algebra on a shard and that the shards'
+    results are exactly the corresponding clips of the unsharded rollout."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from . import eval as ev
+    r, w, _ = init_from_env('gloo')
+    B, T, past, P, K = 64, 14, 10, 8, 2
+    g = torch.Generator().manual_seed(1)
+    raw = dict(body_pose=torch.randn(T, B, 66, generator=g), hand_pose=torch.randn(T, B, 90, generator=g), body_trans=torch.randn(T, B, 3, generator=g),
+               obj_angles=torch.randn(T, B, 3, generator=g), obj_trans=torch.randn(T, B, 3, generator=g), beta=torch.randn(T, B, 10, generator=g),
+               obj_points=torch.randn(B, P, 3, generator=g))
+
+    def fake_batch_from_raw(model, rw, past_len=10):
+        return dict(rw, gt=rw['body_trans'].permute(1, 2, 0)[:, None].contiguous())
+
+    def fake_sample(model, diffusion, correction, bt, past_len, noise=None, seed=None, **kw):
+        # "prediction" = a per-clip function of the window's inputs (so that a wrong shard or a wrong re-centring shows)
+        Tn, Bn = bt['body_pose'].shape[:2]
+        drift = torch.arange(Tn, dtype=torch.float32)[:, None, None] * 0.01
+        body = torch.cat([bt['body_pose'] * 0.5, bt['hand_pose'], bt['body_trans'] + drift], dim=2)
+        obj = torch.cat([bt['obj_angles'] * 0.5, bt['obj_trans'] - drift], dim=2)
+        pelvis = bt['body_trans'] + 0.1
+        verts = pelvis[:, :, None, :].expand(Tn, Bn, 3, 3) + 0.0
+        return obj, body, verts, verts.clone(), pelvis
+    keep = ev.batch_from_raw, ev.sample_once_proj, ev._x_T
+    ev.batch_from_raw, ev.sample_once_proj, ev._x_T = fake_batch_from_raw, fake_sample, (lambda gt, sd: None)
+
+    class Corr:
+        smpl = None
+    try:
+        whole = ev.sample_long(None, None, Corr(), raw, K, past, seed=5)
+        sl, mine = ev.sample_long_sharded(None, None, Corr(), raw, K, past, seed=5)
+    finally:
+        ev.batch_from_raw, ev.sample_once_proj, ev._x_T = keep
+    assert (sl.start, sl.stop) == (8 * r, 8 * r + 8)
+    for a, b in zip(whole, mine):
+        assert a.shape[0] == T + K * (T - past) and torch.equal(a[:, sl], b), (a.shape, b.shape)
     barrier()
     shutdown()

@@ -114,7 +114,20 @@ def batch_from_raw(model, raw, past_len=10):
                 beta=raw['beta'].contiguous(), obj_points=raw['obj_points'].contiguous())
 
 
-def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=0, x_T=None, step_noise=None, **loop_kw):
+def next_window_raw(body, obj, pelvis, raw, future_len):
+    """``get_batch`` (eval_smpl_long.py:26-84), for every clip what it does for its one clip: the ``past`` predicted frames body
+    [past,B,159] / obj [past,B,6] / pelvis [past,B,3] become the next window's raw inputs, translated so that the pelvis of their
+    first frame is the origin (:35-44,:56-57; rotation = I, so orientations are untouched -- upstream only re-expresses them as
+    canonical rotation vectors, :51-54,:58-63, the same rotations), the ``future_len`` future frames are copies of the last past
+    frame (:74).  Returns (raw dict, centroid [B,3]).  Pinned against the reference's own function (tests/golden/long.npz)."""
+    centroid = pelvis[0].clone()                                                # [B,3] origin of the next window
+    pad = lambda a: torch.cat([a, a[-1:].expand(future_len, *a.shape[1:])], dim=0).contiguous()
+    nxt = dict(body_pose=pad(body[..., :66]), hand_pose=pad(body[..., 66:156]), body_trans=pad(body[..., -3:] - centroid),
+               obj_angles=pad(obj[..., :3]), obj_trans=pad(obj[..., 3:] - centroid), beta=raw['beta'], obj_points=raw['obj_points'])
+    return nxt, centroid
+
+
+def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, x_T=None, step_noise=None, **loop_kw):
     """Autoregressive long-horizon forecasting (eval_smpl_long.py:26-84,273-285; BASELINE config #4).
 
     Upstream this path is unreleased/broken (``denormalize`` / ``correct`` are undefined, ``get_batch`` copies clip 0 into
@@ -124,11 +137,14 @@ def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='c
     future frames padded with the last past frame, new conditioning through ``_get_embeddings``, sample, translate back,
     append the window's future frames.  Every clip keeps its chain on its own GPU: no exchange between ranks.
     ``x_T(k)`` / ``step_noise(k)`` (optional callables) inject window k's initial noise / per-step noise callable for deterministic
-    parity with oracle/long_horizon.py; by default window k draws both from ``seed + k``.
+    parity with oracle/long_horizon.py; by default window k draws both from ``seed + k`` (``seed=None``: a fresh base seed per call).
     Returns (obj [T+K*F,B,6], body [T+K*F,B,159], verts, jtr, pelvis) in the first window's coordinate frame."""
     smpl = correction.smpl
     T = raw['body_pose'].shape[0]
     fut = T - past_len
+    if seed is None:                     # like p_sample_loop / evaluate_batch: every call draws its own noise unless the caller pins a seed
+        from .diffusion import fresh_seed
+        seed = fresh_seed()
     def run(bt, k):
         sd = seed + k
         nz = x_T(k) if x_T is not None else _x_T(bt['gt'], sd)
@@ -138,11 +154,7 @@ def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='c
         return sample_once(model, diffusion, smpl, bt, past_len, noise=nz, seed=sd, **kw)
     obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len), 0)
     for k in range(windows):
-        pb, po = body[-past_len:], obj[-past_len:]
-        centroid = pelvis[-past_len].clone()                                        # [B,3] origin of the next window
-        pad = lambda a: torch.cat([a, a[-1:].expand(fut, *a.shape[1:])], dim=0).contiguous()
-        nxt = dict(body_pose=pad(pb[..., :66]), hand_pose=pad(pb[..., 66:156]), body_trans=pad(pb[..., -3:] - centroid),
-                   obj_angles=pad(po[..., :3]), obj_trans=pad(po[..., 3:] - centroid), beta=raw['beta'], obj_points=raw['obj_points'])
+        nxt, centroid = next_window_raw(body[-past_len:], obj[-past_len:], pelvis[-past_len:], raw, fut)
         o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len), 1 + k)
         o, b_ = o.clone(), b_.clone()
         o[..., 3:] += centroid
@@ -187,7 +199,7 @@ def evaluate_batch(model, diffusion, correction, batch, past_len=10, mode='corre
 
     Every draw is an independent ancestral sample like upstream's fresh ``randn_like`` per step (:275-279,
     gaussian_diffusion.py:532): draw j runs the in-kernel noise generator under its own seed -- ``seed + j`` when a base seed is
-    given (reproducible), otherwise one fresh 63-bit seed per draw from torch's global generator.  A fixed ``noise`` (x_T) with
+    given (reproducible), otherwise one fresh 62-bit seed per draw from torch's global generator.  A fixed ``noise`` (x_T) with
     ``diverse_samples > 1`` therefore still gives different samples."""
     smpl = correction.smpl
     obj_gt, jtr_gt, body_gt, faces = get_gt(batch, smpl)
@@ -212,7 +224,8 @@ def evaluate_sharded(model, diffusion, correction, batch, past_len=10, mode='cor
                      presharded=False, **loop_kw):
     """One eval batch of the reference's outer loop (:265-296) over ALL ranks: every rank takes a contiguous shard of the clips
     (they are independent through the whole path), runs ``evaluate_batch`` on it and the six per-clip metric vectors are
-    collated with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) -- the only collective of the path.
+    collated with ONE fixed-size all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests; shard sizes are known by construction, so
+    nothing is exchanged or synchronised before it) -- the only collective of the path.
     Returns (per-clip metrics {name: [B_total]} in clip order on every rank, their means {name: float} = the numbers upstream
     accumulates at :291-296).  ``seed``: base seed; a rank's draws use ``seed + first_clip * diverse_samples + j`` so that ranks
     never share a noise stream and a given (clip shard, draw) is reproducible whatever the world size of an even split.
@@ -229,5 +242,23 @@ def evaluate_sharded(model, diffusion, correction, batch, past_len=10, mode='cor
         m = evaluate_batch(model, diffusion, correction, local, past_len, mode, diverse_samples, seed=sd, **loop_kw)
     else:                                                           # more ranks than clips: contribute an empty shard
         m = {k: torch.empty(0, device=batch['gt'].device) for k in METRIC_KEYS}
-    full = dist.gather_metrics(m, world)
+    counts = None if presharded else [dist.shard_slice(batch['gt'].shape[0], q, world).stop - dist.shard_slice(batch['gt'].shape[0], q, world).start
+                                      for q in range(world)]
+    full = dist.gather_metrics(m, world, counts=counts)                 # ONE fixed-size all-gather, no host sync before it
     return full, {k: float(v.mean()) for k, v in full.items()}
+
+
+RAW_DIMS = dict(body_pose=1, hand_pose=1, body_trans=1, obj_angles=1, obj_trans=1, beta=1, obj_points=0)      # clip dimension of the raw (dataset-side) tensors
+
+
+def sample_long_sharded(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, **kw):
+    """BASELINE config #4's partitioning (eval_smpl_long.py, B = 64 over 8 GPUs): every rank rolls out ITS clips -- the
+    autoregressive chain of a clip never leaves its GPU, there is no exchange between ranks.  ``seed``: base seed; a rank's windows
+    draw from ``seed + first_clip * (windows + 1) + k`` so that ranks never share a noise stream.  Returns (this rank's clip slice
+    of the global batch, ``sample_long``'s tuple for those clips)."""
+    rank, world = dist.get_rank_world()
+    B = raw['body_pose'].shape[1]
+    sl = dist.shard_slice(B, rank, world)
+    local = dist.shard_batch(raw, rank, world, RAW_DIMS)
+    sd = None if seed is None else int(seed) + sl.start * (windows + 1)
+    return sl, sample_long(model, diffusion, correction, local, windows, past_len, mode, seed=sd, **kw)

@@ -220,3 +220,18 @@ def timed_inputs(B):
     """Clip batch + x_{first_t} of the timed-route parity tests (no golden: the routes are compared with each other and the oracle)."""
     bt = _clip(300 + B, B, TIMED_T, TIMED_P)
     return bt, model_kwargs_y(bt, TIMED_T)
+
+
+LONG_FUTURE, LONG_WINDOWS = 4, 2       # tests/golden/long.npz: eval_smpl_long.get_batch on two windows of one clip
+
+
+def long_inputs(w):
+    """The last PAST predicted frames of a window as eval_smpl_long.py:276 hands them to get_batch, one clip: body [PAST,1,159]
+    (66 axis-angle | 90 hands | 3 trans), obj [PAST,1,6], pelvis [PAST,1,3], verts [PAST,1,6890,3].  Window 1 has a root angle > pi."""
+    rs = np.random.RandomState(9100 + w)
+    body, obj = _randn(rs, PAST, 1, 159), _randn(rs, PAST, 1, 6)
+    pel, verts = _randn(rs, PAST, 1, 3), _randn(rs, PAST, 1, 6890, 3)
+    if w == 1:
+        body[0, 0, :3] = _t(np.array([4.0, 0.3, -0.2], dtype=np.float32))
+        obj[3, 0, :3] = _t(np.array([-3.5, 1.0, 0.4], dtype=np.float32))
+    return body, obj, pel, verts

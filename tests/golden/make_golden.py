@@ -29,6 +29,8 @@ What each fixture pins (reference file:line in brackets):
                    per-call decisions; generated separately (`make_golden.py full`, ~35 min) [eval_smpl_short.py:84-177]
   full64.npz       the fp64 twin of full.npz (the ORACLE in float64 on the same inputs / noise; `make_golden.py full64`, ~1 h):
                    not a reference output -- the yardstick that says how far fp32 itself is from exact arithmetic on this chain
+  long.npz         eval_smpl_long.get_batch (window algebra of the autoregressive rollout, "next" row N3) on two windows of one
+                   clip, from the reference's own source with its two non-executable method chains removed (`make_golden.py long`)
   corr32.npz       eval_smpl_short.denoised_fn, one corrected step (t = 250) at B=32, T=100, P=2048 (`make_golden.py corr32`)
   eval.npz         eval_smpl_short.sample_once_proj / get_gt / metrics (the reference's own functions, driven
                    through a stand-in for the dataset batch and the encoder) [eval_smpl_short.py:24-81,133-250]
@@ -265,6 +267,52 @@ def gen_full64():
          **{'dump_%d' % s: np_(v).astype(np.float32) for s, v in zip(fx.FULL_DUMPS, dumps)})
 
 
+def gen_long():
+    """long.npz -- the window algebra of the autoregressive rollout (eval_smpl_long.py:26-84 ``get_batch``; "next" row N3) from the
+    REFERENCE's own function, imported through refshim (`make_golden.py long`, seconds).
+
+    As shipped ``get_batch`` cannot run: the body translation line (:44) ends in ``torch.from_numpy(<[B,3] array>).unsqueeze(0)
+    .repeat(B, 1)`` -- a 3-D tensor repeated with two sizes raises for every B (the other ``repeat`` chains act on clip 0's [3] /
+    [V,6] arrays and are fine): a leftover of a single-clip version.  The golden is therefore recorded from the function's OWN SOURCE
+    with exactly that one method chain deleted (``inspect.getsource`` -> one ``str.replace(.., 1)`` -> ``exec`` in the module's
+    namespace; nothing is re-typed and nothing is stored), called the way :276 calls it for a batch of ONE clip with clip 0's
+    vertices / pelvis.  The unpatched call's exception is recorded next to the outputs.  Pins: centroid = first pelvis,
+    rotation = I, the translation line :40-44, scipy's canonical rotation vectors :51-54,:58-63, pose[3:] copied :55, the
+    ``future_len`` padding frames :74."""
+    import inspect
+    el = refshim.load('eval_smpl_long')
+    past, fut = fx.PAST, fx.LONG_FUTURE
+    el.args = Namespace(future_len=fut)
+    src = inspect.getsource(el.get_batch)
+    chain = '- pelvis_original).unsqueeze(0).repeat(B, 1)'
+    assert src.count(chain) == 1
+    ns = dict(el.__dict__)
+    exec(src.replace(chain, '- pelvis_original)', 1).replace('def get_batch(', 'def get_batch_runnable('), ns)
+    out = {}
+    for w in range(fx.LONG_WINDOWS):
+        body, obj, pel, verts = fx.long_inputs(w)
+        frames = [dict(smplfit_params=dict(pose=torch.zeros(1, 156), trans=torch.zeros(1, 3), betas=torch.zeros(1, 10)),
+                       objfit_params=dict(angle=torch.zeros(1, 3), trans=torch.zeros(1, 3))) for _ in range(past)]
+        batch = dict(frames=frames, obj_points=torch.zeros(1, 8, 6), gender=['male'])
+        if w == 0:
+            try:
+                el.get_batch(body, obj, batch, verts[:, 0], pel[:, 0])
+                raise SystemExit('the shipped get_batch ran: record it unpatched instead')
+            except RuntimeError as e:
+                out['shipped_get_batch_error'] = np.array(str(e))
+        rec = ns['get_batch_runnable'](body, obj, batch, verts[:, 0], pel[:, 0])
+        fr = rec['frames']
+        assert len(fr) == past + fut and all(f is fr[past - 1] for f in fr[past:])
+        out['w%d_centroid' % w] = np.asarray(rec['centroid'], np.float32)
+        out['w%d_rotation' % w] = np.asarray(rec['rotation'], np.float32)
+        out['w%d_pose' % w] = np.stack([np_(f['smplfit_params']['pose'])[0] for f in fr]).astype(np.float32)            # [past+fut,156]
+        out['w%d_trans' % w] = np.stack([np.asarray(f['smplfit_params']['trans'], np.float32).reshape(3) for f in fr])
+        out['w%d_obj_angle' % w] = np.stack([np.asarray(f['objfit_params']['angle'], np.float32).reshape(3) for f in fr])
+        out['w%d_obj_trans' % w] = np.stack([np.asarray(f['objfit_params']['trans'], np.float32).reshape(3) for f in fr])
+        out['w%d_verts0' % w] = np.asarray(fr[0]['human_verts'], np.float32)[::500, :3]                                  # a few re-centred vertices
+    save('long.npz', **out)
+
+
 def gen_corr32():
     """One corrected step (the reference's own denoised_fn, t = 250) at BASELINE config #3's size B=32, T=100, P=2048: the per-clip
     reductions over 90 future frames and the 32-clip ObjProjector batch at the benchmark shape.  ~5 min, ~6 GB."""
@@ -293,6 +341,8 @@ def gen_corr32():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'full64':
         return gen_full64()
+    if len(sys.argv) > 1 and sys.argv[1] == 'long':
+        return gen_long()
     if len(sys.argv) > 1 and sys.argv[1] == 'corr32':
         return gen_corr32()
     if len(sys.argv) > 1 and sys.argv[1] == 'optim':

@@ -110,6 +110,16 @@ def test_gloo_evaluate_sharded_world2():
     mp.spawn(idist._selftest_eval_worker, args=(2, 29531), nprocs=2, join=True)
 
 
+def test_gloo_world8_config4_and_config5_shapes():
+    """BASELINE configs #4 / #5 partitioning at the named shapes, 8 gloo ranks on CPU (no 8-GPU node was available to measure on):
+    ``evaluate_sharded`` at B = 64 (8 clips per rank: shard, seed offsets, the ONE fixed-size all-gather, clip order) and
+    ``sample_long_sharded`` at B = 64 (every rank rolls out its own clips, no exchange; equal to the unsharded rollout clip by clip)."""
+    import torch.multiprocessing as mp
+    from interdiff_amd import dist as idist
+    mp.spawn(idist._selftest_eval_worker, args=(8, 29547), nprocs=8, join=True)
+    mp.spawn(idist._selftest_long_worker, args=(8, 29559), nprocs=8, join=True)
+
+
 def test_behave_etl_matches_reference_dataset(tmp_path):
     """"Next" row N2: clip canonicalisation + file formats + windows of interdiff_amd/data.py against the reference's own
     Dataset.__getitem__ on three windows of the shipped BEHAVE sequence (tests/golden/etl.npz holds the raw frames and the

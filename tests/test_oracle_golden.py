@@ -216,6 +216,37 @@ def test_optimization_golden():
             assert ((grads[n].numpy() == 0) == (ref == 0)).all(), n                             # exact-zero pattern (Adam leaves those untouched)
 
 
+def test_long_horizon_window_algebra_vs_reference_get_batch():
+    """tests/golden/long.npz = the reference's own ``get_batch`` (eval_smpl_long.py:26-84; imported through refshim, its one
+    non-executable method chain removed -- see make_golden.py gen_long) on two windows of one clip.  Checked against it: the oracle's
+    ``next_window_raw`` and the product's host function ``interdiff_amd.eval.next_window_raw`` (pure torch tensor algebra, the same code
+    on the GPU) -- centroid, re-centred translations, rotations, copied pose, padding frames."""
+    from oracle import long_horizon as olh
+    from interdiff_amd import eval as ev
+    z = fx.golden('long.npz')
+    assert 'repeat' in str(z['shipped_get_batch_error'])          # the shipped function raises; the golden says how
+    past, fut = fx.PAST, fx.LONG_FUTURE
+    for w in range(fx.LONG_WINDOWS):
+        body, obj, pel, verts = fx.long_inputs(w)
+        raw = dict(beta=torch.zeros(past + fut, 1, 10), obj_points=torch.zeros(1, 8, 3))
+        assert np.array_equal(z['w%d_rotation' % w], np.eye(3, dtype=np.float32))
+        for name, (nxt, centroid) in (('oracle', olh.next_window_raw(body, obj, pel, raw, past, fut)), ('product', ev.next_window_raw(body, obj, pel, raw, fut))):
+            close(centroid[0], z['w%d_centroid' % w], 0, name + ' centroid')
+            close(nxt['body_trans'][:, 0], z['w%d_trans' % w], 1e-6, name + ' body translation')
+            close(nxt['obj_trans'][:, 0], z['w%d_obj_trans' % w], 1e-6, name + ' object translation')
+            pose = torch.cat([nxt['body_pose'], nxt['hand_pose']], dim=2)[:, 0]
+            close(pose[:, 3:], z['w%d_pose' % w][:, 3:], 0, name + ' pose[3:] copied')
+            close(R.axis_angle_to_matrix(pose[:, :3]), R.axis_angle_to_matrix(torch.from_numpy(z['w%d_pose' % w][:, :3])), 1e-5, name + ' root rotation')
+            close(R.axis_angle_to_matrix(nxt['obj_angles'][:, 0]), R.axis_angle_to_matrix(torch.from_numpy(z['w%d_obj_angle' % w])), 1e-5, name + ' object rotation')
+            if name == 'oracle':                              # the oracle also reproduces scipy's canonical representative
+                close(pose[:, :3], z['w%d_pose' % w][:, :3], 1e-5, 'canonical root rotation vector')
+                close(nxt['obj_angles'][:, 0], z['w%d_obj_angle' % w], 1e-5, 'canonical object rotation vector')
+            for k in ('body_pose', 'hand_pose', 'body_trans', 'obj_angles', 'obj_trans'):
+                assert nxt[k].shape[0] == past + fut and all(torch.equal(nxt[k][t], nxt[k][past - 1]) for t in range(past, past + fut))
+        close(verts[0, 0, :3] - pel[0, 0], z['w%d_verts0' % w][0, :, :3], 1e-6, 'vertices re-centred on the same origin')
+    assert float(torch.from_numpy(z['w1_pose'][0, :3]).norm()) <= np.pi + 1e-5 < float(fx.long_inputs(1)[0][0, 0, :3].norm())
+
+
 def test_long_horizon_restatement_properties():
     """oracle/long_horizon.py ("next" row N3; upstream eval_smpl_long.py is broken, parity unpinned): what can be pinned without a
     reference run -- ``next_window_raw`` IS get_batch's arithmetic for clip 0 (origin = first pelvis, rotation = I, scipy-canonical

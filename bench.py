@@ -45,7 +45,7 @@ B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
 FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
-DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r02g'       # the build the roofline block (and profiles/traffic.json) speaks about
+DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r03a'       # the build the roofline block (and profiles/traffic.json) speaks about
 
 
 def tt(d, dev=None):
@@ -96,38 +96,42 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
             for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
 
 
-def time_dominant_kernel(model, dev, reps=200, chains=1):
+def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True):
     """The roofline kernel: the fused feed-forward block of one layer (csrc/ffn.h: [1600,256] -> linear1 -> gelu -> linear2 as five
     partial slabs; 8 of the 22 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
-    stream around `reps` back-to-back launches on the model's own weights (layer 1).  The launches are replayed from a hipGraph so
-    that the figure is the GPU's, whatever the host is doing.  Returns the MEAN of three bursts (and the best, for reference).
-    chains = 2: the form the sampler's plain steps launch it in -- the batch's rows as two halves, each half a chain of back-to-back
+    stream around `reps` launches replayed from a hipGraph, so that the figure is the GPU's whatever the host is doing.
+    cycle_layers (the figure `roofline` reports): consecutive launches walk through the EIGHT layers' weight streams and alternate
+    two activation buffers, as a denoiser step does -- every launch finds its 2.1-MB weight stream in the Infinity Cache, not in the
+    L2s where a burst on ONE layer leaves it; rocprofv3's in-situ average (profiles/) is the cross-check.  cycle_layers=False: the
+    round-2 burst on layer 1 (secondary key).  Returns the MEAN of three bursts (and the best, for reference).
+    chains = 2: the form the sampler's plain steps launch it in -- the batch's rows as two halves, each half a chain of
     launches on its own branch of the graph; the figure is then per PAIR of concurrent half-size launches (the same FLOP)."""
     from interdiff_amd.mdm import ffn_parts
     N = B_PER_GPU * T // chains
     g = torch.Generator().manual_seed(5)
-    x2 = [torch.randn(N, 256, generator=g).to(dev) for _ in range(chains)]
-    parts = [torch.empty(_lib.FFN_SLICES, N, 256, device=dev) for _ in range(chains)]
-    for _ in range(20):
+    x2 = [[torch.randn(N, 256, generator=g).to(dev) for _ in range(2)] for _ in range(chains)]
+    parts = [[torch.empty(_lib.FFN_SLICES, N, 256, device=dev) for _ in range(2)] for _ in range(chains)]
+    layer_of = (lambda i: i % 8) if cycle_layers else (lambda i: 1)
+    for i in range(20):
         for c in range(chains):
-            ffn_parts(model, x2[c], 1, out=parts[c])
+            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1])
     torch.cuda.synchronize()
-    per_graph = 50
+    per_graph = 48
     side = torch.cuda.Stream(device=dev)
     branch = [torch.cuda.Stream(device=dev) for _ in range(chains)] if chains > 1 else None
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             if chains == 1:
-                for _ in range(per_graph):
-                    ffn_parts(model, x2[0], 1, out=parts[0])
+                for i in range(per_graph):
+                    ffn_parts(model, x2[0][i & 1], layer_of(i), out=parts[0][i & 1])
             else:
                 cur = torch.cuda.current_stream()
                 for c in range(chains):
                     branch[c].wait_stream(cur)
                     with torch.cuda.stream(branch[c]):
-                        for _ in range(per_graph):
-                            ffn_parts(model, x2[c], 1, out=parts[c])
+                        for i in range(per_graph):
+                            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1])
                 for c in range(chains):
                     cur.wait_stream(branch[c])
         graph.replay()
@@ -136,11 +140,11 @@ def time_dominant_kernel(model, dev, reps=200, chains=1):
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(side)
-            for _ in range(reps // per_graph):
+            for _ in range(max(1, reps // per_graph)):
                 graph.replay()
             e1.record(side)
             e1.synchronize()
-            ts.append(1e3 * e0.elapsed_time(e1) / (reps // per_graph * per_graph))
+            ts.append(1e3 * e0.elapsed_time(e1) / (max(1, reps // per_graph) * per_graph))
     return sum(ts) / len(ts), min(ts)
 
 
@@ -228,7 +232,9 @@ def cpu_baseline(assets, bt_cpu, y_cpu):
                 sample='3 warm-up + %d timed plain steps at B=16,T=100 (%.3f s/step) + 3 correction calls (t=500,250,0) on one clip '
                        'each, scaled x16 (%.1f s per 16-clip call); blended over the 989 plain + 11 corrected steps of one sample = '
                        'the mix the GPU headline times; torch CPU fp32, %d threads' % (n_plain, t_plain, t_corr, cores),
-                steps_per_sec=steps_per_s, plain_step_s=t_plain, correction_call_s=t_corr)
+                steps_per_sec=steps_per_s, plain_step_s=t_plain, correction_call_s=t_corr,
+                plain_only=dict(value=B_PER_GPU * T / t_plain, unit='frame-steps/s',
+                                note='plain steps alone (the denoiser): the blended figure is dominated by the oracle\'s brute-force nearest-neighbour search in the 11 correction calls'))
 
 
 def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
@@ -376,11 +382,31 @@ def main():
                                                    ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s')
             del m3, c3, bt3, y3
             B_PER_GPU = 16
+        if B_PER_GPU == 16:
+            # BASELINE config #4's per-GPU share: eval_smpl_long.py, B = 64 over 8 GPUs = 8 clips per GPU, autoregressive rollout of
+            # K = 4 further windows; every window = conditioning (PointNet++ + 8-layer encoder) + one whole 1000-step sample with correction
+            from interdiff_amd import eval as ev4
+            K4, B4 = 4, 8
+            ei4 = tt(syn.make_embedding_inputs(seed=78, B=B4, T=T, n_points=P), dev)
+            g4 = torch.Generator().manual_seed(4)
+            raw4 = dict(ei4, hand_pose=(0.1 * torch.randn(T, B4, 90, generator=g4)).to(dev), beta=torch.randn(1, B4, 10, generator=g4).expand(T, B4, 10).contiguous().to(dev))
+            ev4.sample_long(model, diff, corr, raw4, 1, PAST, seed=1)                 # warm-up: captures for the 8-clip shape
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o4 = ev4.sample_long(model, diff, corr, raw4, K4, PAST, seed=2)
+            torch.cuda.synchronize()
+            w4 = time.perf_counter() - t0
+            assert o4[0].shape[0] == T + K4 * (T - PAST) and all(torch.isfinite(a).all() for a in o4)
+            extra['config4_long_horizon'] = dict(workload='eval_smpl_long.py autoregressive rollout: %d clips per GPU (B=64 over 8 GPUs), T=%d, %d windows '
+                                                          '(first + %d re-conditioned), each = conditioning pass + whole 1000-step sample with correction' % (B4, T, K4 + 1, K4),
+                                                 windows=K4 + 1, steps=(K4 + 1) * STEPS, seconds=w4, ms_per_step=1e3 * w4 / ((K4 + 1) * STEPS),
+                                                 value=(K4 + 1) * STEPS * B4 * T / w4, unit='frame-steps/s', frames_generated_per_clip=T + K4 * (T - PAST))
         log('extra configurations done')
     prof = None
     if not args.no_kernel_profile:
         prof = kernel_profile(diff, model, corr, bt, y)
         dom_us, dom_best = time_dominant_kernel(model, dev)
+        burst_us, burst_best = time_dominant_kernel(model, dev, cycle_layers=False)
         pair_us, pair_best = time_dominant_kernel(model, dev, chains=2)
         fwd_us = time_forward_graph(model, bt, y, dev)
         log('kernel profile done')
@@ -434,7 +460,9 @@ def main():
             if tj.get('kernel_id') == DOMINANT_KERNEL_ID:          # a PMC figure is only valid for the kernel build it was taken on
                 traffic, traffic_src = tj.get(dom), tj.get('_how')
         line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
-                                traffic=traffic, us_per_launch=us, us_per_launch_best_burst=dom_best, algorithmic_flop_per_launch=flops,
+                                traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
+                                one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                     note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic, round-2 form; secondary'),
                                 kernel_id=DOMINANT_KERNEL_ID,
                                 two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                     note='the sampler steps a batch of <= 32 clips as two half-batch kernel chains on two branches of one '
@@ -442,8 +470,9 @@ def main():
                                                          'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
                                 note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
-                                     'of a denoiser forward; duration = mean of three bursts of 200 back-to-back launches replayed from a hipGraph, HIP '
-                                     'events on the launch stream (rocprofv3 in-situ average: profiles/)' % (B_PER_GPU * T))
+                                     'of a denoiser forward; duration = mean of three bursts of 192 launches replayed from a hipGraph that walk through the '
+                                     'eight layers\' weight streams and alternate activation buffers like a denoiser step (every weight stream from the '
+                                     'Infinity Cache), HIP events on the launch stream; cross-check = the rocprofv3 in-situ average under profiles/' % (B_PER_GPU * T))
         fl = FLOP_PER_TOKEN * B_PER_GPU * T
         line['denoiser_forward'] = dict(us=fwd_us, achieved_tflops=fl / (fwd_us * 1e-6) / 1e12,
                                         frac_of_f32_mfma_peak=fl / (fwd_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, launches=22,
@@ -453,6 +482,9 @@ def main():
     if post:
         line['post_optimisation'] = post                    # "next" row N4 (optimization.py), outside the timed region
     if cpu:
+        if 'no_correction' in extra:                         # GPU / CPU on the denoiser alone, next to the blended ratio
+            cpu['plain_only']['gpu_over_cpu'] = extra['no_correction']['value'] / cpu['plain_only']['value']
+        cpu['gpu_over_cpu_blended'] = line['value'] / cpu['value']
         line['cpu_baseline'] = cpu
     print(json.dumps(line))
 

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ 
         for (int j = tid; j < NN_RC; j += NN_T)
             if ((nfw[j >> 5] >> (j & 31)) & 1u) near[(size_t)n * V + c0 + j] = 1;      // several point blocks may store the same 1
     }
-    // resolve the index inside the winning block: the lowest vertex whose (bit-identical) distance equals the minimum
+    // resolve the index inside the winning block: the lowest vertex whose distance is (at or, defensively, below) the minimum -- `<=`, not `==`:
+    // should v_min3_f32 and this recompute ever differ by a bit, the true winner still matches instead of no lane at all
     {
 #pragma clang fp contract(off)
         int r0 = b0, r1 = b1;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(NN_T) void opt_nn_kernel(const float *__restrict__ 
             const int v0 = min(b0 + u, V - 1), v1 = min(b1 + u, V - 1);
             const float dx0 = QX.x - vn[3 * v0], dy0 = QY.x - vn[3 * v0 + 1], dz0 = QZ.x - vn[3 * v0 + 2];
             const float dx1 = QX.y - vn[3 * v1], dy1 = QY.y - vn[3 * v1 + 1], dz1 = QZ.y - vn[3 * v1 + 2];
-            if ((dx0 * dx0 + dy0 * dy0) + dz0 * dz0 == best.x && b0 + u < V) r0 = b0 + u;
-            if ((dx1 * dx1 + dy1 * dy1) + dz1 * dz1 == best.y && b1 + u < V) r1 = b1 + u;
+            if ((dx0 * dx0 + dy0 * dy0) + dz0 * dz0 <= best.x && b0 + u < V) r0 = b0 + u;
+            if ((dx1 * dx1 + dy1 * dy1) + dz1 * dz1 <= best.y && b1 + u < V) r1 = b1 + u;
         }
         if (i0 < P) yidx[(size_t)n * P + i0] = r0;
         if (i1 < P) yidx[(size_t)n * P + i1] = r1;

@@ -81,36 +81,29 @@ def test_windows(n_frames, past_len, future_len, sample_rate=1):
 
 
 def canonicalize_clip(seq, pelvis, start, past_len, future_len, sample_rate=1):
-    """data/dataset_smpl.py:105-160: the clip [start, start + T*rate) in the frame of its first pose.
+    """The clip [start, start + T*rate) expressed in the frame of its first pose (data/dataset_smpl.py:105-160): origin at the first
+    frame's pelvis, the first frame's heading (yaw of the global orientation) removed.  Whole clip at once: one gather per array, one
+    batched rotation composition, one matrix product per translation.
     Returns dict(pose [T,156], trans [T,3], betas [T,10], obj_angles [T,3], obj_trans [T,3], pelvis [T,3], centroid, rotation)."""
     T = past_len + future_len
-    out = {k: [] for k in ('pose', 'trans', 'betas', 'obj_angles', 'obj_trans', 'pelvis')}
-    centroid = rotation = None
-    for i in range(start, start + T * sample_rate, sample_rate):
-        pose, trans = seq['poses'][i].copy(), seq['trans'][i].copy()
-        angle, otrans = seq['obj_angles'][i].copy(), seq['obj_trans'][i].copy()
-        pel = pelvis[i].copy()
-        if i == start:
-            centroid = pel
-            go = Rotation.from_rotvec(pose[:3]).as_matrix()
-            nrm = np.sqrt(go[0, 0] ** 2 + go[2, 0] ** 2)
-            cos, sin = go[0, 0] / nrm, go[2, 0] / nrm
-            rotation_v = np.eye(3).astype(np.float32)
-            rotation_v[[0, 2, 0, 2], [0, 2, 2, 0]] = np.array([cos, cos, -sin, sin])
-            rotation = np.linalg.inv(rotation_v).astype(np.float32)
-        trans = trans - centroid
-        pel = pel - centroid
-        pel_orig = pel - trans                                   # pelvis position in the original smpl coordinate system
-        trans = np.dot(trans + pel_orig, rotation.T) - pel_orig
-        pel = np.dot(pel, rotation.T)
-        pose[:3] = (Rotation.from_matrix(rotation) * Rotation.from_rotvec(pose[:3])).as_rotvec()
-        otrans = np.dot(otrans - centroid, rotation.T)
-        angle = (Rotation.from_matrix(rotation) * Rotation.from_rotvec(angle)).as_rotvec()
-        for k, v in (('pose', pose), ('trans', trans), ('betas', seq['betas'][i]), ('obj_angles', angle), ('obj_trans', otrans), ('pelvis', pel)):
-            out[k].append(np.asarray(v))
-    res = {k: np.stack(v) for k, v in out.items()}
-    res.update(centroid=centroid, rotation=rotation)
-    return res
+    idx = start + sample_rate * np.arange(T)
+    pose, trans = np.array(seq['poses'][idx]), np.array(seq['trans'][idx])
+    angle, otrans, pel = np.array(seq['obj_angles'][idx]), np.array(seq['obj_trans'][idx]), np.array(pelvis[idx])
+    centroid = pel[0].copy()
+    # heading of the first frame: the body's x axis projected on the ground plane (x, z) -> a rotation about y that undoes it
+    x_axis = Rotation.from_rotvec(pose[0, :3]).as_matrix()[:, 0]
+    c, s = x_axis[[0, 2]] / np.hypot(x_axis[0], x_axis[2])
+    yaw = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=np.float32)
+    rotation = np.linalg.inv(yaw).astype(np.float32)
+    unyaw = Rotation.from_matrix(rotation)
+    # SMPL rotates about the pelvis of its own (unposed) frame, so the translation that moves the posed pelvis by `rotation` is
+    # R (t + p0) - p0 with p0 = posed pelvis - t, all relative to the centroid
+    t_rel, p_rel = trans - centroid, pel - centroid
+    p0 = p_rel - t_rel
+    pose[:, :3] = (unyaw * Rotation.from_rotvec(pose[:, :3])).as_rotvec()
+    return dict(pose=pose, trans=(t_rel + p0) @ rotation.T - p0, betas=np.array(seq['betas'][idx]),
+                obj_angles=(unyaw * Rotation.from_rotvec(angle)).as_rotvec(), obj_trans=(otrans - centroid) @ rotation.T,
+                pelvis=p_rel @ rotation.T, centroid=centroid, rotation=rotation)
 
 
 def collate_raw(clips, obj_points, device='cuda'):

@@ -298,8 +298,9 @@ class MDM:
         return ws
 
     def release_shape_buffers(self):
-        """Drop the per-shape workspaces and memory contexts.  Only the owner of the hipGraphs that captured their addresses may
-        call this, after destroying those graphs (diffusion.py does when its per-denoiser cache overflows)."""
+        """Drop the per-shape workspaces and memory contexts.  EVERY hipGraph that captured a call of this model -- the sampler's
+        per-denoiser cache (``_graph_cache``), bench / integrator graphs around ``forward`` -- must have been destroyed first: their
+        baked-in addresses die here.  Nothing in the package calls this on its own."""
         self._ws_pool.clear()
         self._memctx_pool.clear()
         self._ws = self._ws_shape = self._memctx = self._mem_key = self._mem_cond = None

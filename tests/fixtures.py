@@ -176,7 +176,7 @@ def record_parity(name, **values):
         path = os.path.abspath(PARITY_LOG)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}
-        data[name] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+        data[name] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}      # (nested dicts of floats pass through)
         json.dump(data, open(path, 'w'), indent=1, sort_keys=True)
     except Exception as e:                                        # pragma: no cover
         print('record_parity(%s): %r' % (name, e))

@@ -800,17 +800,32 @@ def test_optimize_loss_and_gradients_golden(phys):
     g = fx.golden('optim.npz')
     opt = phys
     inp = [a.cuda() for a in fx.optim_inputs()]
+    # fp64 twin: the oracle's calc_loss + autograd in float64 at the SAME iterates -- how far the reference's own fp32 gradients are
+    # from exact arithmetic (sums over 20 670 vertex coordinates, sign(verts - verts_gt) of near-zero differences) is the yardstick
+    d64 = lambda v: v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v
+    model64, inp64 = {k: d64(v) for k, v in fx.smpl_model().items()}, [d64(a) for a in fx.optim_inputs()]
+    rep = {}
     for k, ii in enumerate(fx.OPT_ITERS):
         params = {n: torch.from_numpy(g['before_' + n][k]).cuda() for n in oo.PARAM_ORDER}
         parts, grads = opt.loss_and_grads(params, *inp, ii)
         np.testing.assert_allclose(parts.cpu().numpy(), g['losses'][k], atol=6e-5, rtol=1e-4)       # printed with 4 decimals
         if k == 0:
             continue
+        _, g64 = oo.loss_and_grads(model64, {n: torch.from_numpy(g['before_' + n][k]).double() for n in oo.PARAM_ORDER}, *inp64, ii)
         for n in oo.PARAM_ORDER:
-            ref, got = g['grad_' + n][k], grads[n].cpu().numpy()
-            # gradients are sums over 20670 vertex coordinates in a different order than autograd's: 5e-4 of the largest entry
-            assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, (n, k, np.abs(got - ref).max(), np.abs(ref).max())
+            ref, got, exact = g['grad_' + n][k], grads[n].cpu().numpy(), g64[n].numpy()
+            scale = np.abs(exact).max()
+            e = dict(hip_vs_reference=float(np.abs(got - ref).max() / scale), hip_vs_fp64=float(np.abs(got - exact).max() / scale),
+                     reference_vs_fp64=float(np.abs(ref - exact).max() / scale))
+            rep['iter%d_%s' % (ii, n)] = e
+            # gates (largest-entry relative), yard = the reference's own fp32 distance from the fp64 gradient: against the REFERENCE
+            # north_star's 1e-4 wherever fp32 can deliver it, else inside the ball both fp32 runs live in around the exact gradient
+            # (2 yard); against fp64 no further than the reference is plus that parity allowance (triangle inequality)
+            yard = e['reference_vs_fp64']
+            assert e['hip_vs_reference'] <= max(1e-4, 2 * yard), (n, ii, e)
+            assert e['hip_vs_fp64'] <= 1.1 * yard + 1e-4, (n, ii, e)
             assert ((got == 0) == (ref == 0)).all(), (n, k)       # exact zeros (identity hand joints) stay exactly zero
+    fx.record_parity('post_optimisation_gradients_vs_reference_and_fp64', **{k: v for k, v in rep.items()})
 
 
 @pytest.mark.gpu

@@ -5,8 +5,10 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 Follows eval_smpl_long.py:26-84 (``get_batch``: how the last ``past_len`` predicted frames become the next window's past) and
 :273-285 (the rollout loop).  Upstream this script is unreleased / broken -- ``denormalize`` and ``correct`` (:279,:286) are not
 defined anywhere, ``get_batch`` reads clip 0 and repeats it over the batch (:34,:44,:52,:56-63 index ``[i, 0]`` / ``.repeat(B, 1)``)
-and ``--autoregressive`` is never passed -- so there is nothing to record a golden from: parity for this row is UNPINNED and the
-restatement below DEFINES the contract, with the three upstream defects fixed in the one way the surrounding code implies:
+and ``--autoregressive`` is never passed.  PINNED as far as upstream code exists: ``next_window_raw`` is checked against the reference's own
+``get_batch`` (tests/golden/long.npz: recorded from the function's own source with its one non-executable method chain removed, see
+make_golden.py gen_long); ``denormalize`` / ``correct`` have no upstream definition, so for them the restatement below DEFINES the
+contract.  The three upstream defects are fixed in the one way the surrounding code implies:
 
   * ``get_batch`` is applied to EVERY clip with the arithmetic it applies to clip 0: origin of the next window = pelvis of the first
     of the ``past_len`` frames (:35-38), ``rotation = rotation_v = I`` (:37-38) so the translation line (:40-44) collapses to

@@ -543,16 +543,25 @@ __global__ __launch_bounds__(128) void corr_reduce_kernel(const float *__restric
                                                           const int32_t *__restrict__ label, int B, int T, int past, int P, int M,
                                                           uint8_t *__restrict__ condition, int32_t *__restrict__ contact,
                                                           float *__restrict__ distance_out, float *__restrict__ loss_out) {
+    // the per-frame values are fetched by all threads at once (one memory round trip instead of T dependent ones: the serial loop
+    // cost 60 us per call) and summed by thread 0 from LDS in the reference's order, frame by frame: the same bits as before
+    extern __shared__ float fr[];                         // [T] loss sums | [T] minimum distances
     const int b = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < T; t += 128) {
+        fr[t] = loss_sum[(size_t)t * B + b];
+        fr[T + t] = min_dist[(size_t)t * B + b];
+    }
     if (tid < M) {
         int c = 0;
-        for (int t = past; t < T; ++t) c += label[((size_t)t * B + b) * M + tid];
+#pragma unroll 16
+        for (int t = past; t < T; ++t) c += label[((size_t)t * B + b) * M + tid];           // independent loads: sixteen in flight
         contact[(size_t)b * M + tid] = c;
     }
+    __syncthreads();
     if (tid == 0) {
         float ls = 0.f, ds = 0.f;
-        for (int t = past; t < T; ++t) ls += loss_sum[(size_t)t * B + b] / (float)P;      // mean over points, then frames
-        for (int t = 0; t < T; ++t) ds += min_dist[(size_t)t * B + b];
+        for (int t = past; t < T; ++t) ls += fr[t] / (float)P;                             // mean over points, then frames
+        for (int t = 0; t < T; ++t) ds += fr[T + t];
         const float loss = ls / (float)(T - past), dist = ds / (float)T;
         condition[b] = !((loss < 0.002f) && (dist < 0.02f));
         if (distance_out) distance_out[b] = dist;
@@ -641,7 +650,7 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
     uint8_t *cond = condition ? condition : w.condition;
     int32_t *cont = contact ? contact : w.contact;
     idf_prof_mark(IDF_K_CORR_REDUCE, s);
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3(B), dim3(128), 0, s, w.loss_sum, w.min_dist, w.label, B, T, c->past_len, P, M, cond,
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3(B), dim3(128), 2 * (size_t)T * sizeof(float), s, w.loss_sum, w.min_dist, w.label, B, T, c->past_len, P, M, cond,
                        cont, distance, loss);
     rc = interdiff_objprojector_sample(c->objproj, w.gt_angles, w.gt_trans, w.markers, cont, B, w.proj, stream);
     if (rc) return rc;

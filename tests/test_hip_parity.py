@@ -1138,7 +1138,7 @@ def test_hot_path_writes_stay_inside_their_buffers(mdm, smpl):
     # correction hook: exact-size workspace
     corr = make_correction(smpl, T, P)
     raw_c, wsc = _guarded(corr.lib.interdiff_correction_workspace_bytes(C.byref(corr.ctx), B, T), DEV)
-    corr._ws = wsc
+    corr._ws = {torch.cuda.current_stream().cuda_stream: wsc}          # the hook keeps one workspace per stream it is called on
     bt = fx._clip(800, B, T, P)
     y = fx.model_kwargs_y(bt, T)
     xin = bt['gt'].clone().to(DEV)

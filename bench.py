@@ -256,8 +256,9 @@ def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
     pairs = B * T * n_points * smpl.cmodel.V                       # distances per iteration, each serves both NN questions
     out = dict(workload='optimization.py: %d clips x %d frames, %d object points, 200 Adam iterations' % (B, T, n_points),
                ms_per_iteration=best / 200 * 1e3, clips_per_sec=B / best, saved=bool(res['saved'].all()),
-               nn_scan=dict(kernel='opt_nn_kernel', bound='valu', pairs_per_iteration=pairs,
-                            note='61% of an iteration; ~11.5 VALU instructions per vertex per thread (2 points, packed fp32, running minimum + index resolved per 8-vertex block); VALU-issue-bound, see profiles/r02_pmc_sq_postopt.txt'))
+               nn_scan=dict(kernels='corr_contact_kernel<true> + opt_patch_kernel + opt_near_kernel', bound='valu', pairs_a_brute_force_would_score=pairs,
+                            note='round 3: the two nearest-neighbour questions are asked separately, each with an exact cull (nearest vertex per point: the hook\'s block-culled scan; '
+                                 'any point within 0.5 m per vertex: 64-point patches skipped by their boxes); ~0.75 ms of a 1.39-ms iteration (round 2: one brute-force scan, 1.0 of 1.65 ms), profiles/r03_postopt_kernel_stats.txt'))
     if with_cpu:
         from oracle import optimization as oo
         model = {k: torch.from_numpy(v) for k, v in smpl_np.items()}

@@ -370,6 +370,10 @@ typedef struct {
     int32_t *foot_cnt;               /* [B][2] */
     int32_t *ctl;                    /* [4]: iteration number ii, Adam steps done, -, - (device side so that steps can be graph-captured) */
     void *smpl_ws; size_t smpl_ws_bytes;     /* interdiff_smpl_workspace_bytes(smpl, N) */
+    /* scratch of the culled nearest-neighbour kernels (used when geo->vorder is set and all three are given; NULL = brute force):
+     * porder int32 [B][P] (Morton order of every clip's object points), psort float [N][2048][4] (a frame's points in that order),
+     * pbox float [N][32][2][4] (boxes of their 64-point patches) */
+    int32_t *porder; float *psort, *pbox;
 } idf_opt_state;
 
 /* pose [N][156] axis-angle, trans / obj_angles / obj_trans [N][3] (optimization.py:20-32) -> param = init, zeroed moments,

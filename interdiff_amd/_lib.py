@@ -72,7 +72,7 @@ _OPT_PTRS = ('betas', 'obj_points', 'param', 'init', 'grad', 'm', 'v', 'best', '
 
 
 class OptState(C.Structure):
-    _fields_ = [('B', i32), ('T', i32), ('P', i32), ('max_iters', i32)] + [(k, vp) for k in _OPT_PTRS] + [('smpl_ws_bytes', sz)]
+    _fields_ = [('B', i32), ('T', i32), ('P', i32), ('max_iters', i32)] + [(k, vp) for k in _OPT_PTRS] + [('smpl_ws_bytes', sz), ('porder', vp), ('psort', vp), ('pbox', vp)]
 
 
 _SIGS = {

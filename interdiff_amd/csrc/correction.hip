@@ -224,6 +224,10 @@ __device__ __forceinline__ void lds_box_load(const float4 *bx, int k, float3 &lo
     hi = make_float3(f[6 + h], f[8 + h], f[10 + h]);
 }
 
+// OPT = the instantiation of the physics post-optimisation (optimize.hip, optimization.py:64-65): the object points come already
+// transformed per frame (pts_frame [N][P][3]), frames are clip-major (clip = n / frames_per_clip) and the only output is the nearest
+// vertex of every point -- no normals, markers or loss (the per-vertex contact-radius mask of :74-75 is its own kernel there).
+template <bool OPT>
 __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restrict__ verts, int V,
                                                           const float *__restrict__ obj_points, int P,
                                                           const int32_t *__restrict__ porder /* nullable [B][P]: scan position -> point */,
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                                                           float *__restrict__ o2h_out /* nullable [N][P] */,
                                                           int32_t *__restrict__ idx_out /* nullable [N][P]: nearest vertex */,
                                                           unsigned long long *__restrict__ stats /* nullable [IDF_CONTACT_STATS]: see interdiff_contact_nn */,
-                                                          int64_t nn_from /* frames below it skip the NN scan */) {
+                                                          int64_t nn_from /* frames below it skip the NN scan */,
+                                                          const float *__restrict__ pts_frame /* OPT: [N][P][3] */, int frames_per_clip /* OPT */) {
     extern __shared__ __attribute__((aligned(16))) float4 vs[];
     const ContactLds L(V);
     const int nCB = L.nCB, nSB = L.nSB;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     __shared__ float pl[MAXP];                                             // per-point loss by scan position
     __shared__ int next_task;
     const int64_t n = blockIdx.x;
-    const int b = (int)(n % B), tid = threadIdx.x;
+    const int b = OPT ? (int)(n / frames_per_clip) : (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
     const bool do_nn = n >= nn_from;
     // phase clocks of thread 0 (frames that scan only), summed into stats[3 + phase] when the caller asks for statistics
@@ -274,55 +279,62 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         lds_rec_store(vs, v, x, y, z);
     }
     if (tid < MAXM) flags[tid] = 0;
-    if (tid == 0) next_task = 0;
+    // gridDim.y workgroups share a frame's tasks (OPT: 320 frames on 256 CUs would otherwise take two full rounds)
+    const int ntask_all = (P + TASK - 1) / TASK;
+    const int task0 = (int)((long long)blockIdx.y * ntask_all / gridDim.y), task1 = (int)((long long)(blockIdx.y + 1) * ntask_all / gridDim.y);
+    if (tid == 0) next_task = task0;
     for (int i = tid; i < MAXP; i += CT) pl[i] = 0.f;
     __syncthreads();
     phase_done();                                                          // 1: records in LDS
-    if (tid < M) {
+    if (!OPT && tid < M) {
         const float3 mk = lds_rec(vs, markers_pos[tid]);
         ms[tid] = make_float4(mk.x, mk.y, mk.z, 0.f);
         float *mo = markers_out + ((size_t)n * M + tid) * 3;
         mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
     }
     if (do_nn) {
-        const float3 none_lo = make_float3(FLT_MAX, FLT_MAX, FLT_MAX), none_hi = make_float3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-        for (int cb = tid; cb < nSB * SB; cb += CT) {                        // boxes of the real records of each block (+ dummies past the end: never needed)
-            float3 lo = none_lo, hi = none_hi;
-            if (cb < nCB) {
-#pragma unroll
-                for (int u = 0; u < CB; ++u) {
-                    const float3 p = lds_rec(vs, cb * CB + u);
-                    if (cb * CB + u < V) {
-                        lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
-                        hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
-                    }
-                }
+        // boxes: a wave takes the 64 record pairs of one super-block (8 blocks x 8 pairs), every lane the min / max of its pair; an 8-lane
+        // reduction on the DPP path gives the block boxes, the wave reduction the super-block box.  (A first version -- one thread per
+        // block reading its 16 records one by one, then one thread per super-block -- took 25 k cycles of a 390 k-cycle workgroup.)
+#define IDF_DPP8(v, op, ctrl) v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+        const int lane_ = tid & 63, wave_ = tid >> 6, nsw = 2 * ((nSB + 2) / 2);
+        for (int sb = wave_; sb < nsw; sb += CT / 64) {
+            const int pr = sb * 64 + lane_;                                  // record pair
+            float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
+            if (2 * pr < V) {
+                const float4 xy = vs[2 * pr], zz = vs[2 * pr + 1];
+                const bool two = 2 * pr + 1 < V;
+                lx = two ? fminf(xy.x, xy.y) : xy.x; hx = two ? fmaxf(xy.x, xy.y) : xy.x;
+                ly = two ? fminf(xy.z, xy.w) : xy.z; hy = two ? fmaxf(xy.z, xy.w) : xy.z;
+                lz = two ? fminf(zz.x, zz.y) : zz.x; hz = two ? fmaxf(zz.x, zz.y) : zz.x;
             }
-            lds_box_store(bb, cb, lo, hi);
+            // quad xor 1, quad xor 2, half-row mirror: every lane of an 8-lane group ends with the group's value
+            IDF_DPP8(lx, fminf, 0xB1); IDF_DPP8(lx, fminf, 0x4E); IDF_DPP8(lx, fminf, 0x141);
+            IDF_DPP8(ly, fminf, 0xB1); IDF_DPP8(ly, fminf, 0x4E); IDF_DPP8(ly, fminf, 0x141);
+            IDF_DPP8(lz, fminf, 0xB1); IDF_DPP8(lz, fminf, 0x4E); IDF_DPP8(lz, fminf, 0x141);
+            IDF_DPP8(hx, fmaxf, 0xB1); IDF_DPP8(hx, fmaxf, 0x4E); IDF_DPP8(hx, fmaxf, 0x141);
+            IDF_DPP8(hy, fmaxf, 0xB1); IDF_DPP8(hy, fmaxf, 0x4E); IDF_DPP8(hy, fmaxf, 0x141);
+            IDF_DPP8(hz, fmaxf, 0xB1); IDF_DPP8(hz, fmaxf, 0x4E); IDF_DPP8(hz, fmaxf, 0x141);
+            const int cb = sb * SB + (lane_ >> 3);
+            if ((lane_ & 7) == 0 && cb < nSB * SB) lds_box_store(bb, cb, make_float3(lx, ly, lz), make_float3(hx, hy, hz));
+            const float slx = -wave_max(-lx), sly = -wave_max(-ly), slz = -wave_max(-lz), shx = wave_max(hx), shy = wave_max(hy), shz = wave_max(hz);
+            if (lane_ == 0) lds_box_store(sbb, sb, make_float3(slx, sly, slz), make_float3(shx, shy, shz));
         }
+#undef IDF_DPP8
         for (int k = tid; k < 2 * ((L.nSeed + 1) / 2); k += CT) {           // seed records: the first record of every SEED_STRIDE-th block, as pairs
             const float3 p = lds_rec(vs, min(k * SEED_STRIDE, nCB - 1) * CB);
             lds_rec_store(sd, k, p.x, p.y, p.z);
         }
-        __syncthreads();
-        for (int sb = tid; sb < 2 * ((nSB + 2) / 2); sb += CT) {            // super-block boxes = union of SB block boxes
-            float3 lo = none_lo, hi = none_hi;
-            for (int cb = sb * SB; cb < min((sb + 1) * SB, nCB) && sb < nSB; ++cb) {
-                float3 l, h;
-                lds_box_load(bb, cb, l, h);
-                lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
-                hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
-            }
-            lds_box_store(sbb, sb, lo, hi);
-        }
     }
-    float R[9], tr[3];
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tr[3] = {0.f, 0.f, 0.f};
+    if constexpr (!OPT) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
+        for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
-    const float *op = obj_points + (size_t)b * P * 3;
-    const int ln = tid & 63, ntask = (P + TASK - 1) / TASK;
+        for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
+    }
+    const float *op = OPT ? pts_frame + (size_t)n * P * 3 : obj_points + (size_t)b * P * 3;
+    const int ln = tid & 63, ntask = task1;
     __syncthreads();
     phase_done();                                                          // 2: boxes, markers
     float mind = FLT_MAX;
@@ -338,10 +350,10 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         const bool valid = i >= 0;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (valid) { px = op[3 * i]; py = op[3 * i + 1]; pz = op[3 * i + 2]; }
-        // matmul(points, R^T) + t  (eval_smpl_short.py:107)
-        const float qx = (px * R[0] + py * R[1] + pz * R[2]) + tr[0];
-        const float qy = (px * R[3] + py * R[4] + pz * R[5]) + tr[1];
-        const float qz = (px * R[6] + py * R[7] + pz * R[8]) + tr[2];
+        // matmul(points, R^T) + t  (eval_smpl_short.py:107); OPT: the caller's transformed points as they are
+        const float qx = OPT ? px : (px * R[0] + py * R[1] + pz * R[2]) + tr[0];
+        const float qy = OPT ? py : (px * R[3] + py * R[4] + pz * R[5]) + tr[1];
+        const float qz = OPT ? pz : (px * R[6] + py * R[7] + pz * R[8]) + tr[2];
         // the signed object->human distance is only consumed on future frames (eval_smpl_short.py:121 slices
         // loss_dist_o[past_len:]); past frames only need the marker distances below
         if (do_nn) {
@@ -432,7 +444,9 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
             }
             pos = min(pos, V - 1);
             if (org == 0x7fffffff) org = vorder ? vorder[pos] : pos;      // NaN input: nothing compared equal
-            if (valid) {
+            if constexpr (OPT) {
+                if (valid) idx_out[(size_t)n * P + i] = org;
+            } else if (valid) {
                 // normal of the nearest vertex (data/tools.py:4-40 restricted to one vertex), from LDS, in the reference's accumulation order
                 const float3 v3 = lds_rec(vs, pos);
                 float3 acc = make_float3(0.f, 0.f, 0.f);
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                 pl[sp] = o2h < 0.f ? fabsf(o2h) * 20.0f : 0.f;                  // eval_smpl_short.py:113-119
             }
         }
-        if (valid) {
+        if (!OPT && valid) {
             for (int m = 0; m < M; ++m) {
                 const float4 mk = ms[m];
                 const float dx = mk.x - qx, dy = mk.y - qy, dz = mk.z - qz;
@@ -487,6 +501,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         atomicAdd(stats + 2, (unsigned long long)n_test);
     }
     phase_done();                                                          // 3: this wave's tasks
+    if constexpr (OPT) return;                                             // every wave has written its points' indices: nothing to reduce
     __syncthreads();
     phase_done();                                                          // 4: waiting for the other waves
     // deterministic block reductions: the per-point losses by scan position in a fixed tree
@@ -531,10 +546,10 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
     const int32_t *faces = ordered ? c->faces_scan : c->faces, *mpos = ordered ? c->markers_scan : c->markers_idx;
     if (porder) hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
     static std::atomic<uint64_t> lds_ok{0};
-    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
-    hipLaunchKernelGGL(corr_contact_kernel, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, porder, objR, objT, faces,
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<false>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+    hipLaunchKernelGGL(corr_contact_kernel<false>, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, porder, objR, objT, faces,
                        c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
-                       stats, nn_from);
+                       stats, nn_from, nullptr, 0);
     return IDF_OK;
 }
 
@@ -618,6 +633,110 @@ CorrWs carve(const idf_correction_ctx *c, int B, int T, void *ws) {
     return w;
 }
 
+
+// ---- the contact-radius mask of the post-optimisation (optimization.py:74-75): per vertex, does ANY object point lie within 0.5 m? ----
+// The dual of the scan above: lanes are VERTICES, the frame's object points are cut into patches of 64 consecutive points of the
+// clip's Morton order (compact under the frame's rigid transform) with their boxes; a patch is looked at only if its box comes
+// closer than 0.5 m to some vertex of the wave that is still undecided (same monotone lower bound, so the cut is exact), and a
+// wave leaves as soon as all its vertices have found a point.  K-A sorts the frame's points and boxes its patches, K-B answers.
+constexpr int NPATCH = MAXP / 64;
+__global__ __launch_bounds__(256) void opt_patch_kernel(const float *__restrict__ pts, int P, const int32_t *__restrict__ porder, int frames_per_clip,
+                                                        float4 *__restrict__ psort /* [N][MAXP] */, float4 *__restrict__ pbox /* [N][NPATCH][2] */) {
+    const int64_t n = blockIdx.x;
+    const int b = (int)(n / frames_per_clip), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pn = pts + (size_t)n * P * 3;
+    for (int k = wave; k < NPATCH; k += 4) {
+        const int sp = 64 * k + lane;
+        float x = 3e18f, y = 3e18f, z = 3e18f;                              // slots past P: far away (never within the radius)
+        float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
+        if (sp < P) {
+            const int i = porder[(size_t)b * P + sp];
+            x = pn[3 * i]; y = pn[3 * i + 1]; z = pn[3 * i + 2];
+            lx = hx = x; ly = hy = y; lz = hz = z;
+        }
+        psort[(size_t)n * MAXP + sp] = make_float4(x, y, z, 0.f);
+        lx = -wave_max(-lx); ly = -wave_max(-ly); lz = -wave_max(-lz);
+        hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+        if (lane == 0) {
+            pbox[((size_t)n * NPATCH + k) * 2] = make_float4(lx, ly, lz, 0.f);
+            pbox[((size_t)n * NPATCH + k) * 2 + 1] = make_float4(hx, hy, hz, 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void opt_near_kernel(const float *__restrict__ verts, int V, int P, const float4 *__restrict__ psort,
+                                                       const float4 *__restrict__ pbox, const int32_t *__restrict__ vorder,
+                                                       int32_t *__restrict__ near) {
+    __shared__ float4 ps[MAXP];                                            // the frame's points, sorted
+    __shared__ float4 bx[NPATCH * 2];
+    const int64_t n = blockIdx.y;
+    // a wave takes 64 consecutive vertices of the SCAN order (a compact clump of the body): its lanes agree on which patches matter
+    const int tid = threadIdx.x, pos = blockIdx.x * 256 + tid, vid = vorder[min(pos, V - 1)];
+    for (int i = tid; i < MAXP; i += 256) ps[i] = psort[(size_t)n * MAXP + i];
+    if (tid < NPATCH * 2) bx[tid] = pbox[(size_t)n * NPATCH * 2 + tid];
+    const bool valid = pos < V;
+    const float *vp = verts + ((size_t)n * V + vid) * 3;
+    const float vx = vp[0], vy = vp[1], vz = vp[2];
+    __syncthreads();
+    const int npatch = (P + 63) / 64;
+    bool hit = false;
+    {
+#pragma clang fp contract(off)
+        const v2f VX = v2f{vx, vx}, VY = v2f{vy, vy}, VZ = v2f{vz, vz};
+        for (int k = 0; k < npatch; ++k) {
+            if (__builtin_amdgcn_ballot_w64(valid && !hit) == 0ull) break;               // every vertex of the wave is decided
+            const float4 lo = bx[2 * k], hi = bx[2 * k + 1];
+            const float ex = fmaxf(fmaxf(lo.x - vx, vx - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - vy, vy - hi.y), 0.f), ez = fmaxf(fmaxf(lo.z - vz, vz - hi.z), 0.f);
+            const float xx = ex * ex, yy = ey * ey, zz = ez * ez;
+            if (__builtin_amdgcn_ballot_w64(valid && !hit && (xx + yy) + zz < 0.25f) == 0ull) continue;      // no undecided vertex can have a point of this patch in range
+            const float4 *pp = ps + 64 * k;
+            for (int j0 = 0; j0 < 64; j0 += 16) {                        // sixteen points, then ask again whether anybody is still undecided
+#pragma unroll
+                for (int j = j0; j < j0 + 16; j += 2) {
+                    const float4 p = pp[j], q = pp[j + 1];
+                    // sqrt(d2) < 0.5 (optimization.py:75) <=> d2 < 0.25 up to the rounding of the last ulp; d = point - vertex as in the brute force
+                    const v2f dx = v2f{p.x, q.x} - VX, dy = v2f{p.y, q.y} - VY, dz = v2f{p.z, q.z} - VZ;
+                    const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+                    hit = hit || d2.x < 0.25f || d2.y < 0.25f;
+                }
+                if (__builtin_amdgcn_ballot_w64(valid && !hit) == 0ull) break;
+            }
+        }
+    }
+    if (valid) near[(size_t)n * V + vid] = hit ? 1 : 0;
+}
+
+}  // namespace
+
+// The nearest-vertex half of the post-optimisation's scan (optimize.hip; declared in common.h): per transformed object point of
+// every frame the nearest vertex.  Frames clip-major (n = b*T + t); `porder` [B][P] scratch, filled here.
+int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, const float *obj_points, int P,
+                    int32_t *porder, const idf_correction_ctx *c, int32_t *yidx) {
+    const size_t lds = contact_lds_bytes(V);
+    if (lds > 160 * 1024 - 16384 || P > MAXP || !c->vorder) return IDF_E_INVAL;
+    const int B = (int)(N / frames_per_clip);
+    hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
+    static std::atomic<uint64_t> lds_ok{0};
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<true>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
+    hipLaunchKernelGGL(corr_contact_kernel<true>, dim3((unsigned)N, 2), dim3(CT), lds, s, verts, V, obj_points, P, porder, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, c->vorder, nullptr, 0, B, nullptr, nullptr, nullptr, nullptr, nullptr, yidx, nullptr, (int64_t)0,
+                       pts_frame, frames_per_clip);
+    return IDF_OK;
+}
+
+// ... and the contact-radius mask: near[n][v] = 1 iff some object point of frame n lies within 0.5 m of vertex v.  `porder` as filled
+// by idf_nn_scan_opt for the same clips; psort [N][2048] float4 and pbox [N][32][2] float4 are scratch.
+int idf_near_mask_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, int P, const int32_t *porder,
+                      const int32_t *vorder, float *psort, float *pbox, int32_t *near) {
+    if (P > MAXP || !vorder) return IDF_E_INVAL;
+    hipLaunchKernelGGL(opt_patch_kernel, dim3((unsigned)N), dim3(256), 0, s, pts_frame, P, porder, frames_per_clip, reinterpret_cast<float4 *>(psort),
+                       reinterpret_cast<float4 *>(pbox));
+    hipLaunchKernelGGL(opt_near_kernel, dim3((unsigned)idf_cdiv(V, 256), (unsigned)N), dim3(256), 0, s, verts, V, P, reinterpret_cast<const float4 *>(psort),
+                       reinterpret_cast<const float4 *>(pbox), vorder, near);
+    return IDF_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T) {

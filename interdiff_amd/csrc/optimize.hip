@@ -643,9 +643,18 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
     hipLaunchKernelGGL(opt_objpts_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->param, st->obj_points, P, T, st->pts);
     int rc = interdiff_smpl_forward(m, st->pose, st->betas, st->tr, N, st->verts, st->jtr, st->vposed, st->smpl_ws, st->smpl_ws_bytes, stream);
     if (rc) return rc;
-    if (hipMemsetAsync(st->near, 0, (size_t)N * V * sizeof(int32_t), s) != hipSuccess) return IDF_E_LAUNCH;
-    hipLaunchKernelGGL(opt_nn_kernel, dim3((unsigned)idf_cdiv(P, NN_T * 2), (unsigned)N), dim3(NN_T), 0, s, st->pts, P, st->verts, V, st->yidx,
-                       st->near);
+    if (c->geo->vorder && st->porder && st->psort && st->pbox) {
+        // scan order given: the two questions are asked separately, each with its own exact cull (correction.hip) -- nearest vertex per
+        // point by the hook's block-culled scan, "any point within 0.5 m" per vertex against the boxes of 64-point patches
+        rc = idf_nn_scan_opt(s, N, T, st->verts, V, st->pts, st->obj_points, P, st->porder, c->geo, st->yidx);
+        if (rc) return rc;
+        rc = idf_near_mask_opt(s, N, T, st->verts, V, st->pts, P, st->porder, c->geo->vorder, st->psort, st->pbox, st->near);
+        if (rc) return rc;
+    } else {
+        if (hipMemsetAsync(st->near, 0, (size_t)N * V * sizeof(int32_t), s) != hipSuccess) return IDF_E_LAUNCH;
+        hipLaunchKernelGGL(opt_nn_kernel, dim3((unsigned)idf_cdiv(P, NN_T * 2), (unsigned)N), dim3(NN_T), 0, s, st->pts, P, st->verts, V, st->yidx,
+                           st->near);
+    }
     hipLaunchKernelGGL(opt_signed_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->pts, P, st->verts, V, st->yidx,
                        c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, st->y2x_signed, st->y2x);
     static std::atomic<uint64_t> lds_ok{0};

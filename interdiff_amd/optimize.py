@@ -19,17 +19,21 @@ KSLICE = 1024
 
 
 class PhysicsOptimizer:
-    def __init__(self, smpl_layer, device='cuda'):
+    def __init__(self, smpl_layer, device='cuda', scan_order=True):
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.smpl = smpl_layer
         cm = smpl_layer.cmodel
         self.V, self.J, self.KB = cm.V, cm.J, cm.KB
-        self.topo = MeshTopology(smpl_layer.th_faces, cm.V, self.device)
+        self.topo = MeshTopology(smpl_layer.th_faces, cm.V, self.device, rest_vertices=getattr(smpl_layer, 'v_template', None) if scan_order else None)
         geo = _lib.CorrectionCtx()
         geo.smpl = C.pointer(cm)
         geo.faces, geo.adj_ptr = self.topo.faces.data_ptr(), self.topo.adj_ptr.data_ptr()
         geo.adj_face, geo.adj_corner = self.topo.adj_face.data_ptr(), self.topo.adj_corner.data_ptr()
+        if self.topo.vorder is not None:       # scan order of the exact nearest-vertex scan (block culling, csrc/correction.hip); results do not depend on it
+            self._markers_scan = self.topo.scan_positions([0], self.device)
+            geo.vorder, geo.faces_scan, geo.adj_pair_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.topo.adj_pair_scan.data_ptr()
+            geo.markers_scan = self._markers_scan.data_ptr()
         self.geo = geo
         # constants of the backward pass: the blend basis transposed (k-major rows, zero padded to the split-K slice) and
         # the skinning weights regrouped by joint
@@ -74,6 +78,9 @@ class PhysicsOptimizer:
         for k in _lib._OPT_PTRS:
             setattr(st, k, bufs[k].data_ptr())
         st.smpl_ws_bytes = bufs['smpl_ws'].numel()
+        if self.topo.vorder is not None and P <= 2048:           # scratch of the culled nearest-neighbour kernels
+            bufs.update(porder=i(B, P), psort=f(N, 2048, 4), pbox=f(N, 32, 2, 4))
+            st.porder, st.psort, st.pbox = (bufs[k].data_ptr() for k in ('porder', 'psort', 'pbox'))
         self._state = (key, st, bufs)
         return st, bufs
 

@@ -830,6 +830,34 @@ def test_optimize_loss_and_gradients_golden(phys):
 
 
 @pytest.mark.gpu
+def test_optimize_culled_scans_equal_brute_force(smpl):
+    """The post-optimisation's two nearest-neighbour questions (optimization.py:64-65,74-75) through the culled kernels of
+    csrc/correction.hip -- nearest vertex per point by the hook's block-culled scan, "any point within 0.5 m" per vertex against the
+    boxes of 64-point patches -- against the round-2 brute-force kernel (``scan_order=False``): indices and near flags bit for bit,
+    on overlapping objects, an object 0.45 m away (the radius cuts through the body) and one 1.5 m away (nothing near)."""
+    import ctypes as C
+    from interdiff_amd import _lib, synthetic as syn
+    from interdiff_amd.optimize import PhysicsOptimizer
+    bt = syn.make_optim_batch(seed=3, B=4, T=5, n_points=2048)
+    bt['obj_trans'][2] += np.float32(0.45)
+    bt['obj_trans'][3] += np.float32(1.5)
+    args = [torch.from_numpy(bt[k]).to(DEV) for k in ('pose', 'trans', 'obj_angles', 'obj_trans', 'betas', 'obj_points')]
+    res = {}
+    for so in (True, False):
+        opt = PhysicsOptimizer(smpl, scan_order=so)
+        assert bool(opt.geo.vorder) == so
+        single, B, T, st, bufs = opt._init(args, 151, 4)
+        assert bool(st.porder) == so
+        _lib.check(opt.lib.interdiff_optimize_loss_grad(C.byref(opt.ctx), C.byref(st), _lib.stream()), 'loss_grad')
+        res[so] = (bufs['yidx'].clone(), bufs['near'].clone(), bufs['loss'].clone())
+    assert torch.equal(res[True][0], res[False][0]), 'nearest-vertex indices differ: %d' % (res[True][0] != res[False][0]).sum()
+    assert torch.equal(res[True][1], res[False][1]), 'near flags differ: %d' % (res[True][1] != res[False][1]).sum()
+    frac = res[True][1].float().reshape(4, 5, -1).mean(dim=(1, 2))
+    assert frac[0] > 0.2 and 0.0 < frac[2] < frac[0] and frac[3] == 0.0, frac      # the three regimes are really exercised
+    close(res[True][2], res[False][2], 1e-5, 'losses')
+
+
+@pytest.mark.gpu
 def test_optimize_loop_vs_oracle_and_reference(phys):
     """The Adam loop over the golden run's iteration numbers.  Adam's first update is lr*sign(g): elements whose
     gradient is rounding noise move by +-lr in an implementation-defined direction, so parameters agree to a few lr and

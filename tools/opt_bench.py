@@ -30,8 +30,9 @@ def main():
     ap.add_argument('--frames', type=int, default=20)
     ap.add_argument('--points', type=int, default=2048)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--brute-force', action='store_true', help='round-2 nearest-neighbour kernel (no scan order)')
     a = ap.parse_args()
-    opt = PhysicsOptimizer(SMPL_Layer({k: torch.from_numpy(v) for k, v in syn.smplh_model().items()}, device='cuda'))
+    opt = PhysicsOptimizer(SMPL_Layer({k: torch.from_numpy(v) for k, v in syn.smplh_model().items()}, device='cuda'), scan_order=not a.brute_force)
     batch = clip_batch(a.clips, a.frames, a.points)
     opt.optimize(*batch, iters=range(0, 5))              # warm-up
     torch.cuda.synchronize()

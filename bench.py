@@ -258,7 +258,7 @@ def postopt_bench(smpl, smpl_np, dev, with_cpu, B=16, T=20, n_points=2048):
                ms_per_iteration=best / 200 * 1e3, clips_per_sec=B / best, saved=bool(res['saved'].all()),
                nn_scan=dict(kernels='corr_contact_kernel<true> + opt_patch_kernel + opt_near_kernel', bound='valu', pairs_a_brute_force_would_score=pairs,
                             note='round 3: the two nearest-neighbour questions are asked separately, each with an exact cull (nearest vertex per point: the hook\'s block-culled scan; '
-                                 'any point within 0.5 m per vertex: 64-point patches skipped by their boxes); ~0.75 ms of a 1.39-ms iteration (round 2: one brute-force scan, 1.0 of 1.65 ms), profiles/r03_postopt_kernel_stats.txt'))
+                                 'any point within 0.5 m per vertex: 64-point patches skipped by their boxes); ~0.7 ms of a 1.33-ms iteration (round 2: one brute-force scan, 1.0 of 1.65 ms), profiles/r03_postopt_kernel_stats.txt'))
     if with_cpu:
         from oracle import optimization as oo
         model = {k: torch.from_numpy(v) for k, v in smpl_np.items()}

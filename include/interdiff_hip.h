@@ -287,6 +287,7 @@ typedef struct {
      * adjacency (adj_ptr / adj_face / adj_corner order) the scan positions (a, b) of the incident face's other two vertices such
      * that the face normal at the vertex is (a - v) x (b - v).  Results (indices included) never depend on the order. */
     const int32_t *vorder, *faces_scan, *markers_scan, *adj_pair_scan;
+    const int32_t *adj_pair;   /* nullable [nnz][2]: adj_pair_scan's pairs as ORIGINAL vertex ids (kernels that read vertices from HBM) */
 } idf_correction_ctx;
 
 size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);

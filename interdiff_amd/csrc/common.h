@@ -91,8 +91,9 @@ template <class... A>
 __device__ __forceinline__ void idf_args_now(A... a) { (idf_arg_now(a), ...); }
 
 // exact nearest-vertex scan with block culling (correction.hip) as the post-optimisation uses it (optimize.hip), and its contact-radius mask
+int idf_point_order(hipStream_t s, const float *obj_points, int B, int P, int32_t *porder);
 int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, const float *obj_points, int P,
-                    int32_t *porder, const idf_correction_ctx *c, int32_t *yidx);
+                    const int32_t *porder, const idf_correction_ctx *c, int32_t *yidx);
 int idf_near_mask_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, int P, const int32_t *porder,
                       const int32_t *vorder, float *psort, float *pbox, int32_t *near);
 

@@ -709,13 +709,19 @@ __global__ __launch_bounds__(256) void opt_near_kernel(const float *__restrict__
 }  // namespace
 
 // The nearest-vertex half of the post-optimisation's scan (optimize.hip; declared in common.h): per transformed object point of
-// every frame the nearest vertex.  Frames clip-major (n = b*T + t); `porder` [B][P] scratch, filled here.
+// every frame the nearest vertex.  Frames clip-major (n = b*T + t); `porder` [B][P] = idf_point_order of the clips' canonical points
+// (they do not change over the iterations: computed once by interdiff_optimize_init).
+int idf_point_order(hipStream_t s, const float *obj_points, int B, int P, int32_t *porder) {
+    if (P > MAXP) return IDF_E_INVAL;
+    hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
+    return IDF_OK;
+}
+
 int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, const float *obj_points, int P,
-                    int32_t *porder, const idf_correction_ctx *c, int32_t *yidx) {
+                    const int32_t *porder, const idf_correction_ctx *c, int32_t *yidx) {
     const size_t lds = contact_lds_bytes(V);
     if (lds > 160 * 1024 - 16384 || P > MAXP || !c->vorder) return IDF_E_INVAL;
     const int B = (int)(N / frames_per_clip);
-    hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
     static std::atomic<uint64_t> lds_ok{0};
     if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<true>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel<true>, dim3((unsigned)N, 2), dim3(CT), lds, s, verts, V, obj_points, P, porder, nullptr, nullptr, nullptr,

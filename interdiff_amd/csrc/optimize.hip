@@ -210,14 +210,31 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 __global__ __launch_bounds__(256) void opt_signed_kernel(const float *__restrict__ pts, int P, const float *__restrict__ verts, int V,
                                                          const int32_t *__restrict__ yidx, const int32_t *__restrict__ faces,
                                                          const int32_t *__restrict__ adj_ptr, const int32_t *__restrict__ adj_face,
-                                                         const int32_t *__restrict__ adj_corner, float *__restrict__ y2x_signed,
-                                                         float *__restrict__ y2x) {
+                                                         const int32_t *__restrict__ adj_corner,
+                                                         const int32_t *__restrict__ adj_pair /* nullable [nnz][2]: the face's other two vertices (a, b): normal += (a - v) x (b - v) */,
+                                                         float *__restrict__ y2x_signed, float *__restrict__ y2x) {
     const int64_t n = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float *vn = verts + (size_t)n * V * 3;
     const int v = yidx[(size_t)n * P + i];
     float3 acc = make_float3(0.f, 0.f, 0.f);
+    if (adj_pair) {                                      // one 8-byte load per incident face instead of face id -> corner -> three vertex ids
+        const float3 pv3 = ld3(vn + 3 * v);
+        const int e0 = adj_ptr[v], e1 = adj_ptr[v + 1];
+        for (int e = e0; e < e1; e += 4) {
+            int2 ab[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ab[u] = *reinterpret_cast<const int2 *>(adj_pair + 2 * (size_t)min(e + u, e1 - 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e + u < e1) {
+                    const float3 nn = cross3(sub3(ld3(vn + 3 * ab[u].x), pv3), sub3(ld3(vn + 3 * ab[u].y), pv3));
+                    acc.x += nn.x; acc.y += nn.y; acc.z += nn.z;
+                }
+            }
+        }
+    } else
     for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) {
         const int f = adj_face[e], c = adj_corner[e];
         const float3 p0 = ld3(vn + 3 * faces[3 * f]), p1 = ld3(vn + 3 * faces[3 * f + 1]), p2 = ld3(vn + 3 * faces[3 * f + 2]);
@@ -646,7 +663,7 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
     if (c->geo->vorder && st->porder && st->psort && st->pbox) {
         // scan order given: the two questions are asked separately, each with its own exact cull (correction.hip) -- nearest vertex per
         // point by the hook's block-culled scan, "any point within 0.5 m" per vertex against the boxes of 64-point patches
-        rc = idf_nn_scan_opt(s, N, T, st->verts, V, st->pts, st->obj_points, P, st->porder, c->geo, st->yidx);
+        rc = idf_nn_scan_opt(s, N, T, st->verts, V, st->pts, st->obj_points, P, st->porder, c->geo, st->yidx);            // porder: from interdiff_optimize_init
         if (rc) return rc;
         rc = idf_near_mask_opt(s, N, T, st->verts, V, st->pts, P, st->porder, c->geo->vorder, st->psort, st->pbox, st->near);
         if (rc) return rc;
@@ -656,7 +673,7 @@ int loss_grad(const idf_opt_ctx *c, const idf_opt_state *st, void *stream, bool 
                            st->near);
     }
     hipLaunchKernelGGL(opt_signed_kernel, dim3((unsigned)idf_cdiv(P, 256), (unsigned)N), dim3(256), 0, s, st->pts, P, st->verts, V, st->yidx,
-                       c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, st->y2x_signed, st->y2x);
+                       c->geo->faces, c->geo->adj_ptr, c->geo->adj_face, c->geo->adj_corner, c->geo->adj_pair, st->y2x_signed, st->y2x);
     static std::atomic<uint64_t> lds_ok{0};
     if (idf_opt_in_lds(reinterpret_cast<const void *>(opt_lossgrad_kernel), 150 * 1024, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(opt_lossgrad_kernel, dim3((unsigned)N), dim3(LG_T), (size_t)V * 3 * sizeof(float), s, st->verts, st->verts_gt, V,
@@ -694,6 +711,7 @@ extern "C" int interdiff_optimize_init(const idf_opt_ctx *c, const idf_opt_state
         hipMemsetAsync(st->flag, 0, (size_t)st->B * sizeof(int32_t), s) != hipSuccess)
         return IDF_E_LAUNCH;
     hipLaunchKernelGGL(opt_setctl_kernel, dim3(1), dim3(64), 0, s, st->ctl, first_iter);
+    if (c->geo->vorder && st->porder && idf_point_order(s, st->obj_points, st->B, st->P, st->porder) != IDF_OK) return IDF_E_INVAL;      // the clips' canonical points never change
     // verts_gt / jtr_gt from the ORIGINAL axis-angle pose (optimization.py:43-45)
     const int rc = interdiff_smpl_forward(m, pose, st->betas, trans, N, st->verts_gt, st->jtr, nullptr, st->smpl_ws, st->smpl_ws_bytes, stream);
     if (rc) return rc;

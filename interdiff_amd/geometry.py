@@ -50,17 +50,19 @@ class MeshTopology:
         self.V = V
         self.faces, self.adj_ptr, self.adj_face, self.adj_corner = t(f.astype(np.int32)), t(ptr), t(adj_face), t(adj_corner)
         self.vorder = self.faces_scan = self.rank = self.adj_pair_scan = None
+        # per adjacency entry (vertex v, face, corner c) the other two corners (a, b) with normal contribution (a - v) x (b - v):
+        # data/tools.py:27-39 accumulates cross(v2 - v1, v0 - v1) at corner 1, cross(v0 - v2, v1 - v2) at 2, cross(v1 - v0, v2 - v0) at 0
+        fa, co = adj_face.astype(np.int64), adj_corner.astype(np.int64)
+        a_of, b_of = np.array([1, 2, 0]), np.array([2, 0, 1])
+        pair = np.stack([f[fa, a_of[co]], f[fa, b_of[co]]], axis=1)
+        self.adj_pair = t(pair.astype(np.int32))
         if rest_vertices is not None:
             order = morton_order(np.asarray(rest_vertices).reshape(V, 3))
             rank = np.empty(V, np.int64)
             rank[order] = np.arange(V)
             self.rank = rank                                        # vertex -> scan position (host)
             self.vorder, self.faces_scan = t(order.astype(np.int32)), t(rank[f].astype(np.int32))
-            # per adjacency entry (vertex v, face, corner c) the other two corners (a, b) with normal contribution (a - v) x (b - v):
-            # data/tools.py:27-39 accumulates cross(v2 - v1, v0 - v1) at corner 1, cross(v0 - v2, v1 - v2) at 2, cross(v1 - v0, v2 - v0) at 0
-            fa, co = adj_face.astype(np.int64), adj_corner.astype(np.int64)
-            a_of, b_of = np.array([1, 2, 0]), np.array([2, 0, 1])
-            self.adj_pair_scan = t(np.stack([rank[f[fa, a_of[co]]], rank[f[fa, b_of[co]]]], axis=1).astype(np.int32))
+            self.adj_pair_scan = t(rank[pair].astype(np.int32))
 
     def scan_positions(self, vertex_ids, device):
         """Scan positions of the given vertices (e.g. the marker set) as a device int32 tensor."""

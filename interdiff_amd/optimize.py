@@ -30,6 +30,7 @@ class PhysicsOptimizer:
         geo.smpl = C.pointer(cm)
         geo.faces, geo.adj_ptr = self.topo.faces.data_ptr(), self.topo.adj_ptr.data_ptr()
         geo.adj_face, geo.adj_corner = self.topo.adj_face.data_ptr(), self.topo.adj_corner.data_ptr()
+        geo.adj_pair = self.topo.adj_pair.data_ptr()
         if self.topo.vorder is not None:       # scan order of the exact nearest-vertex scan (block culling, csrc/correction.hip); results do not depend on it
             self._markers_scan = self.topo.scan_positions([0], self.device)
             geo.vorder, geo.faces_scan, geo.adj_pair_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.topo.adj_pair_scan.data_ptr()

@@ -1,5 +1,8 @@
-import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+"""numpy model of the contact scan's block culling (not product code): fraction of 16-vertex blocks a wave of 128 Morton-sorted object
+points has to score, for block sizes 8 / 16 / 32, on the synthetic body (default or `coherent`) posed by ground-truth and by noisy poses.
+The block size, the seed and the two-level hierarchy of csrc/correction.hip were chosen with it.    python tools/cull_sim.py [coherent]"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from interdiff_amd import synthetic as syn
 from oracle.smpl import smpl_forward
 from oracle import rotations as R

@@ -419,6 +419,11 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                     if (__builtin_amdgcn_ballot_w64(valid && lb.y <= best) != 0ull) score_block(cb + 1);     // best may just have dropped
                 }
             };
+            if (!vorder) {
+                // identity order: consecutive vertex ids are not neighbours, the boxes cull next to nothing -- score every block (the
+                // brute force of rounds 1-2 in task form) instead of paying for the tests as well
+                for (int cb = 0; cb < nCB; ++cb) score_block(cb);
+            } else
             for (int sb = 0; sb < nSB; sb += 2) {
                 const float4 *bx = sbb + 3 * (sb >> 1);
                 const v2f lb = pair_lb(bx[0], bx[1], bx[2]);

@@ -460,7 +460,16 @@ def main():
             tj = json.load(open(tf))
             if tj.get('kernel_id') == DOMINANT_KERNEL_ID:          # a PMC figure is only valid for the kernel build it was taken on
                 traffic, traffic_src = tj.get(dom), tj.get('_how')
-        line['roofline'] = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
+        in_situ = None                                       # cross-check: the committed rocprofv3 kernel-trace summary of this same command
+        ks = os.path.join(ROOT, 'profiles', 'r03_kernel_stats_bench.txt')
+        if os.path.exists(ks) and traffic is not None:         # (only trusted for the kernel build traffic.json names)
+            for ln in open(ks):
+                if ln.startswith('idf_ffn::ffn_fused_kernel'):
+                    f_ = ln.split()
+                    in_situ = dict(us_per_launch=float(f_[-4]), launches=int(f_[-6]), frac=flops / (float(f_[-4]) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   source='profiles/r03_kernel_stats_bench.txt (rocprofv3 --kernel-trace --stats of `python bench.py`, INTERDIFF_CHAINS=1)')
+                    break
+        line['roofline'] = dict(bound='mfma', kernel=dom, rocprofv3_in_situ=in_situ, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
                                 traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
                                 one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                      note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic, round-2 form; secondary'),

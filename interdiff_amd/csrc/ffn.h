@@ -129,7 +129,8 @@ __device__ __forceinline__ void mma_group4(f32x4 (&acc)[4], const float4 &a, con
 // b1p [NSL*208] (linear1 bias, zero-padded), b2 [256], parts [NSL][M][256].  grid = ceil(M/32) * NSL workgroups of 512 threads.
 // MODE 0 is the product kernel.  The other instantiations exist only in tools/ffn_probe.hip (ablations for the time budget: 1 = no
 // MFMAs, 2 = no DMA after the prologue, 3 = s_memtime stamps of workgroup phases behind the slabs, 4 = no LDS fragment reads in the
-// loops, 5 = no barrier in the loops (wrong results: what the per-pair synchronisation costs)); `if constexpr` keeps every trace of them out of MODE 0.
+// loops, 5 = no barrier in the loops (wrong results: what the per-pair synchronisation costs), 6 = no slab stores, 7 = plain instead of
+// write-through slab stores); `if constexpr` keeps every trace of them out of MODE 0.
 //
 // Every loop over chunk pairs is FULLY UNROLLED and the geometry is constant, so stream offsets, ring slots, DMA counts and LDS
 // fragment addresses are immediates: the scalar unit (one per CU, shared by the eight waves) has almost nothing to do.  A first
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
             const float4 x = xres[it], bb = bres[it];
             v.x += x.x + bb.x; v.y += x.y + bb.y; v.z += x.z + bb.z; v.w += x.w + bb.w;
         }
-        idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
+        if constexpr (MODE == 6) { if (v.x == 12345.678f) idf_store16_wt(out + (size_t)gr * D + c4, v); }      // ablation: no slab stores (never true)
+        else if constexpr (MODE == 7) *reinterpret_cast<float4 *>(out + (size_t)gr * D + c4) = v;            // ablation: plain (write-back) stores
+        else idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
     }
     stamp();
 }

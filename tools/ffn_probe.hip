@@ -48,6 +48,9 @@ int main(int argc, char **argv) {
     us[5] = run<5>(x2, M, pack, b1, b2, parts, 200);
     us[3] = run<3>(x2, M, pack, b1, b2, parts, 50);
     for (int i = 0; i < 6; ++i) printf("M=%d  %-36s %8.2f us  (%.1f TFLOP/s equivalent)\n", M, names[i], us[i], fl / us[i] / 1e6);
+    printf("M=%d  %-36s %8.2f us\n", M, "no slab stores", run<6>(x2, M, pack, b1, b2, parts, 200));
+    printf("M=%d  %-36s %8.2f us\n", M, "plain (write-back) slab stores", run<7>(x2, M, pack, b1, b2, parts, 200));
+    printf("M=%d  %-36s %8.2f us\n", M, "product again", run<0>(x2, M, pack, b1, b2, parts, 200));
     std::vector<long long> st((size_t)nwg * 32);
     CK(hipMemcpy(st.data(), reinterpret_cast<char *>(parts) + (size_t)NSL * M * D * 4, st.size() * 8, hipMemcpyDeviceToHost));
     // stamps: 0 entry, 1 after prologue barrier, 2..9 phase-1 pairs, 10 after the gelu epilogue, 11.. phase-2 pairs, last = exit

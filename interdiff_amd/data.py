@@ -6,8 +6,10 @@ Restates data/dataset_smpl.py:44-56 (files: ``smpl_fit_all.npz`` {poses [F,156],
 past_len + future_len frames) and :105-204 (``__getitem__``: every clip is expressed in the frame of its first pose --
 origin at the first pelvis, yaw of the first global orientation removed).  Host-side numpy/scipy like the reference (this is
 dataset plumbing, not the hot path); the one heavy step, the per-frame pelvis = SMPL joint 0 over the whole sequence
-(:57,68), runs on the GPU through ``SMPL_Layer``.  Contact labels / per-vertex data / rendering inputs of the reference
-records are not produced (the sampler never reads them)."""
+(:57,68), runs on the GPU through ``SMPL_Layer``.  The contact-side records of a clip -- the object cloud of every frame with
+normals and contact labels, foot-ground labels, human contact labels (:48-50,152-180; read by the reference's training code, never
+by the sampler, the hook or the metrics) -- come from ``clip_labels`` when the sequence has a ``contact.npz``; the per-vertex
+``human_verts`` records and rendering inputs are not produced."""
 import os
 import numpy as np
 import torch
@@ -15,13 +17,53 @@ from scipy.spatial.transform import Rotation
 
 
 def load_behave_sequence(seq_dir):
-    """data/dataset_smpl.py:44-47."""
+    """data/dataset_smpl.py:44-56: the two fit files, and -- when the sequence directory has them (the shipped sample does not) --
+    ``contact.npz`` (object cloud [P,6] = xyz | normal, per-frame contact vertex lists of object and body, first-frame foot labels)
+    and ``info.json`` (gender, object category)."""
+    import json
     with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
         obj_angles, obj_trans = f['angles'], f['trans']
     with np.load(os.path.join(seq_dir, 'smpl_fit_all.npz'), allow_pickle=True) as f:
         poses, betas, trans = f['poses'], f['betas'], f['trans']
     n = min(len(poses), len(obj_angles))
-    return dict(poses=poses[:n], betas=betas[:n], trans=trans[:n], obj_angles=obj_angles[:n], obj_trans=obj_trans[:n], seq_name=os.path.basename(seq_dir))
+    seq = dict(poses=poses[:n], betas=betas[:n], trans=trans[:n], obj_angles=obj_angles[:n], obj_trans=obj_trans[:n], seq_name=os.path.basename(seq_dir))
+    cpath, ipath = os.path.join(seq_dir, 'contact.npz'), os.path.join(seq_dir, 'info.json')
+    if os.path.isfile(cpath):
+        with np.load(cpath, allow_pickle=True) as f:
+            d = f['arr_0'].item()
+        seq.update(obj_points=d['object_points'], obj_contact_label=d['object_contact_vertex_label'], contact_label=d['human_contact_vertex_label'],
+                   ground_joint_label=d['foot_contact_joint_label'])
+    if os.path.isfile(ipath):
+        info = json.load(open(ipath))
+        seq.update(gender=info['gender'], obj_name=info['cat'])
+    return seq
+
+
+def clip_labels(seq, clip, left_foot, right_foot, start, past_len, future_len, sample_rate=1, n_verts=6890):
+    """The contact-side records of ``Dataset.__getitem__`` (data/dataset_smpl.py:152-180) for the frames of a canonicalised ``clip``:
+    obj_points [T,P,7] = the object cloud in the clip's frame (R_t p + t_t | R_t n | 1 where the frame's object contact list names the
+    point), ground_joint_label [T,2] (left / right foot moved < 1 cm since the PREVIOUS sequence frame; the sequence's very first frame
+    takes the label stored in the file), contact_label [T,V] (body vertices in contact).  ``left_foot`` / ``right_foot`` [F,3]: joints
+    10 / 11 over the sequence (like ``sequence_pelvis`` for joint 0)."""
+    T = past_len + future_len
+    idx = start + sample_rate * np.arange(T)
+    pts = np.asarray(seq['obj_points'], np.float64)
+    P = pts.shape[0]
+    R = Rotation.from_rotvec(np.asarray(clip['obj_angles'], np.float64)).as_matrix()                       # [T,3,3] canonicalised object rotation
+    out = np.zeros((T, P, 7))
+    out[..., :3] = np.einsum('pc,tdc->tpd', pts[:, :3], R) + np.asarray(clip['obj_trans'], np.float64)[:, None, :]
+    out[..., 3:6] = np.einsum('pc,tdc->tpd', pts[:, 3:6], R)
+    contact = np.zeros((T, n_verts), bool)
+    ground = np.zeros((T, 2))
+    for k, i in enumerate(idx):
+        out[k, np.asarray(seq['obj_contact_label'][i], np.int64), 6] = 1
+        contact[k, np.asarray(seq['contact_label'][i], np.int64)] = True
+        if i > 0:
+            ground[k, 0] = np.linalg.norm(left_foot[i] - left_foot[i - 1]) < 0.01
+            ground[k, 1] = np.linalg.norm(right_foot[i] - right_foot[i - 1]) < 0.01
+        else:
+            ground[k, int(seq['ground_joint_label'][i]) - 10] = 1
+    return dict(obj_points=out, ground_joint_label=ground, contact_label=contact)
 
 
 def load_ply_vertices(path):

@@ -267,6 +267,67 @@ def gen_full64():
          **{'dump_%d' % s: np_(v).astype(np.float32) for s, v in zip(fx.FULL_DUMPS, dumps)})
 
 
+def gen_etl():
+    """etl.npz -- the reference Dataset.__getitem__ (data/dataset_smpl.py:105-204) on three windows of the one real sequence
+    (`make_golden.py etl`, seconds).  The records are built by hand: Dataset.__init__ needs the licensed SMPL-H pkl and the
+    sequence's contact.npz / info.json, which are not shipped; pelvis / feet = joints 0 / 10 / 11 of the synthetic body model, the
+    contact-side inputs (object point cloud with normals, per-frame contact vertex lists, first-frame foot labels) are synthetic and
+    stored in the fixture next to the reference's outputs."""
+    import importlib
+    from oracle import smpl as osmpl
+    refshim.install()
+    model = fx.smpl_model()
+    sys.modules.pop('data.dataset_smpl', None)
+    dsm = importlib.import_module('data.dataset_smpl')
+    seq_dir = '/root/reference/interdiff/data/behave/sequence/Date01_Sub01_backpack_back'
+    with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
+        o_ang, o_tr = f['angles'], f['trans']
+    with np.load(os.path.join(seq_dir, 'smpl_fit_all.npz'), allow_pickle=True) as f:
+        poses, betas, trans = f['poses'], f['betas'], f['trans']
+    past, fut = fx.PAST, 25
+    Tw = past + fut
+    starts = [0, 35, 700]
+    sel = np.concatenate([np.arange(s0, s0 + Tw) for s0 in starts])
+    jtr = np_(osmpl.smpl_forward(model, torch.from_numpy(poses[sel]), torch.from_numpy(betas[sel]), torch.from_numpy(trans[sel]))[1])
+    pel, lf, rf = (np.zeros((len(poses), 3), np.float32) for _ in range(3))
+    pel[sel], lf[sel], rf[sel] = jtr[:, 0], jtr[:, 10], jtr[:, 11]
+    # synthetic contact-side records (the formats of contact.npz: data/dataset_smpl.py:48-50)
+    rs = np.random.RandomState(4100)
+    P, V = 48, 6890
+    nrm = rs.standard_normal((P, 3))
+    obj_points = np.concatenate([rs.uniform(-0.3, 0.3, (P, 3)), nrm / np.linalg.norm(nrm, axis=1, keepdims=True)], axis=1).astype(np.float32)
+    obj_contact = [np.sort(rs.choice(P, size=rs.randint(0, 6), replace=False)) for _ in range(len(poses))]
+    human_contact = [np.sort(rs.choice(V, size=rs.randint(0, 40), replace=False)) for _ in range(len(poses))]
+    foot_label = rs.randint(10, 12, size=len(poses))
+
+    class Lazy:                                            # per-frame vertex arrays: never read by the sampler, zeros here
+        def __init__(self, shape): self.shape = shape
+        def __getitem__(self, i): return np.zeros(self.shape, np.float32)
+    ds = dsm.Dataset.__new__(dsm.Dataset)
+    ds.past_len, ds.future_len, ds.sample_rate, ds.num_verts = past, fut, 1, V
+    ds.data = [dict(gender='male', obj_name='backpack', obj_angles=o_ang, obj_trans=o_tr, poses=poses, betas=betas, trans=trans, pelvis=pel,
+                    left_foot=lf, right_foot=rf, seq_name='Date01_Sub01_backpack_back', obj_points=obj_points,
+                    obj_contact_label=obj_contact, human_verts=Lazy((V, 6)), contact_label=human_contact, ground_joint_label=foot_label)]
+    ds.idx2frame = [(0, s0, 1) for s0 in starts]
+    out = dict(starts=np.array(starts), sel=sel, poses=poses[sel], betas=betas[sel], trans=trans[sel], obj_angles=o_ang[sel], obj_trans=o_tr[sel], pelvis=pel[sel],
+               left_foot=lf[sel], right_foot=rf[sel], obj_points6=obj_points, foot_label=foot_label[sel],
+               obj_contact_n=np.array([len(obj_contact[i]) for i in sel]), obj_contact_idx=np.concatenate([obj_contact[i] for i in sel]).astype(np.int64),
+               human_contact_n=np.array([len(human_contact[i]) for i in sel]), human_contact_idx=np.concatenate([human_contact[i] for i in sel]).astype(np.int64))
+    for w in range(len(starts)):
+        rec = ds[w]
+        out['pose_%d' % w] = np.stack([fr['smplfit_params']['pose'] for fr in rec['frames']])
+        out['trans_%d' % w] = np.stack([fr['smplfit_params']['trans'] for fr in rec['frames']])
+        out['angle_%d' % w] = np.stack([fr['objfit_params']['angle'] for fr in rec['frames']])
+        out['otrans_%d' % w] = np.stack([fr['objfit_params']['trans'] for fr in rec['frames']])
+        out['pelvis_%d' % w] = np.stack([fr['pelvis'] for fr in rec['frames']])
+        out['centroid_%d' % w], out['rotation_%d' % w] = rec['centroid'], rec['rotation']
+        out['objpts_%d' % w] = np.stack([fr['obj_points'] for fr in rec['frames']]).astype(np.float32)              # [T,P,7]: xyz | normal | contact label
+        out['ground_%d' % w] = np.stack([fr['ground_joint_label'] for fr in rec['frames']]).astype(np.float32)      # [T,2]
+        out['contact_count_%d' % w] = np.array([int(fr['contact_label'].sum()) for fr in rec['frames']])
+        out['contact_first_%d' % w] = np.array([int(np.nonzero(fr['contact_label'][:, 0])[0][0]) if fr['contact_label'].any() else -1 for fr in rec['frames']])
+    save('etl.npz', **out)
+
+
 def gen_long():
     """long.npz -- the window algebra of the autoregressive rollout (eval_smpl_long.py:26-84 ``get_batch``; "next" row N3) from the
     REFERENCE's own function, imported through refshim (`make_golden.py long`, seconds).
@@ -341,6 +402,8 @@ def gen_corr32():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'full64':
         return gen_full64()
+    if len(sys.argv) > 1 and sys.argv[1] == 'etl':
+        return gen_etl()
     if len(sys.argv) > 1 and sys.argv[1] == 'long':
         return gen_long()
     if len(sys.argv) > 1 and sys.argv[1] == 'corr32':
@@ -439,46 +502,7 @@ def main():
     cond, gt = type(net)._get_embeddings(net, rb, None)
     save('embed.npz', cond=np_(cond), gt=np_(gt))
 
-    # ---- ETL: the reference Dataset.__getitem__ on the one real sequence (records built by hand: __init__ needs the
-    # licensed SMPL-H pkl and contact.npz / info.json which are not shipped); pelvis = joint 0 of the synthetic body model
-    import importlib
-    from oracle import smpl as osmpl
-    sys.modules.pop('data.dataset_smpl', None)
-    dsm = importlib.import_module('data.dataset_smpl')
-    seq_dir = '/root/reference/interdiff/data/behave/sequence/Date01_Sub01_backpack_back'
-    with np.load(os.path.join(seq_dir, 'object_fit_all.npz'), allow_pickle=True) as f:
-        o_ang, o_tr = f['angles'], f['trans']
-    with np.load(os.path.join(seq_dir, 'smpl_fit_all.npz'), allow_pickle=True) as f:
-        poses, betas, trans = f['poses'], f['betas'], f['trans']
-    past, fut = fx.PAST, 25
-    Tw = past + fut
-    starts = [0, 35, 700]
-    sel = np.concatenate([np.arange(s0, s0 + Tw) for s0 in starts])
-    pel = np.zeros((len(poses), 3), np.float32)
-    pel[sel] = np_(osmpl.smpl_forward(model, torch.from_numpy(poses[sel]), torch.from_numpy(betas[sel]), torch.from_numpy(trans[sel]))[1][:, 0])
-
-    class Lazy:                                            # per-frame arrays the sampler never reads
-        def __init__(self, shape): self.shape = shape
-        def __getitem__(self, i): return np.zeros(self.shape, np.float32)
-    ds = dsm.Dataset.__new__(dsm.Dataset)
-    ds.past_len, ds.future_len, ds.sample_rate, ds.num_verts = past, fut, 1, 6890
-    ds.data = [dict(gender='male', obj_name='backpack', obj_angles=o_ang, obj_trans=o_tr, poses=poses, betas=betas, trans=trans, pelvis=pel,
-                    left_foot=pel, right_foot=pel, seq_name='Date01_Sub01_backpack_back', obj_points=np.zeros((8, 6), np.float32),
-                    obj_contact_label=Lazy((0,)).__class__((0,)), human_verts=Lazy((6890, 6)), contact_label=Lazy((0,)),
-                    ground_joint_label=np.full(len(poses), 10))]
-    ds.data[0]['obj_contact_label'] = [np.zeros(0, np.int64)] * len(poses)
-    ds.data[0]['contact_label'] = [np.zeros(0, np.int64)] * len(poses)
-    ds.idx2frame = [(0, s0, 1) for s0 in starts]
-    out = dict(starts=np.array(starts), sel=sel, poses=poses[sel], betas=betas[sel], trans=trans[sel], obj_angles=o_ang[sel], obj_trans=o_tr[sel], pelvis=pel[sel])
-    for w in range(len(starts)):
-        rec = ds[w]
-        out['pose_%d' % w] = np.stack([fr['smplfit_params']['pose'] for fr in rec['frames']])
-        out['trans_%d' % w] = np.stack([fr['smplfit_params']['trans'] for fr in rec['frames']])
-        out['angle_%d' % w] = np.stack([fr['objfit_params']['angle'] for fr in rec['frames']])
-        out['otrans_%d' % w] = np.stack([fr['objfit_params']['trans'] for fr in rec['frames']])
-        out['pelvis_%d' % w] = np.stack([fr['pelvis'] for fr in rec['frames']])
-        out['centroid_%d' % w], out['rotation_%d' % w] = rec['centroid'], rec['rotation']
-    save('etl.npz', **out)
+    gen_etl()
 
     # ---- eval glue: the reference's sample_once_proj / get_gt / metrics on a tiny clip, 50-step schedule.
     # The dataset batch and the encoder (_get_embeddings: a "next" row) are stand-ins that hand back our tensors.

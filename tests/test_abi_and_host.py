@@ -149,6 +149,27 @@ def test_behave_etl_matches_reference_dataset(tmp_path):
         assert np.abs(c['pelvis'][0]).max() < 1e-6                                   # first pelvis is the origin
         R0 = __import__('scipy.spatial.transform', fromlist=['Rotation']).Rotation.from_rotvec(c['pose'][0, :3]).as_matrix()
         assert abs(R0[2, 0]) < 1e-5                                                   # yaw of the first frame removed
+    # the contact-side records (contact.npz / info.json in the reference's on-disk format; data/dataset_smpl.py:48-56,152-180)
+    import json
+    cuts_o, cuts_h = np.cumsum(z['obj_contact_n'])[:-1], np.cumsum(z['human_contact_n'])[:-1]
+    per_frame = lambda parts: [parts[list(sel).index(i)] if i in set(sel.tolist()) else np.zeros(0, np.int64) for i in range(F)]
+    contact = dict(object_points=z['obj_points6'], object_contact_vertex_label=per_frame(np.split(z['obj_contact_idx'], cuts_o)),
+                   human_contact_vertex_label=per_frame(np.split(z['human_contact_idx'], cuts_h)), foot_contact_joint_label=full(z['foot_label']).astype(np.int64))
+    np.savez(d / 'contact.npz', contact)
+    json.dump(dict(gender='male', cat='backpack'), open(d / 'info.json', 'w'))
+    loaded = D.load_behave_sequence(str(d))
+    assert loaded['gender'] == 'male' and loaded['obj_name'] == 'backpack' and np.array_equal(loaded['obj_points'], z['obj_points6'])
+    lf, rf = full(z['left_foot']), full(z['right_foot'])
+    for w, s0 in enumerate(starts):
+        c = D.canonicalize_clip(loaded, pelvis, int(s0), 10, 25)
+        lab = D.clip_labels(loaded, c, lf, rf, int(s0), 10, 25)
+        ref = z['objpts_%d' % w].astype(np.float64)
+        assert np.abs(lab['obj_points'] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (w, np.abs(lab['obj_points'] - ref).max())
+        assert np.array_equal(lab['obj_points'][..., 6], ref[..., 6])
+        assert np.array_equal(lab['ground_joint_label'], z['ground_%d' % w].astype(np.float64)), w
+        assert np.array_equal(lab['contact_label'].sum(1), z['contact_count_%d' % w])
+        first = np.array([int(np.nonzero(r)[0][0]) if r.any() else -1 for r in lab['contact_label']])
+        assert np.array_equal(first, z['contact_first_%d' % w])
     clips = [D.canonicalize_clip(loaded, pelvis, int(s0), 10, 25) for s0 in starts]
     raw = D.collate_raw(clips, np.zeros((64, 3), np.float32), device='cpu')
     assert raw['body_pose'].shape == (35, 3, 66) and raw['hand_pose'].shape == (35, 3, 90) and raw['obj_points'].shape == (3, 64, 3)

@@ -297,7 +297,7 @@ def timed_samples(diff, model, corr, bt, y, n, seed0=233):
 
 
 def main():
-    global B_PER_GPU
+    global B_PER_GPU, T
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=STEPS)
@@ -383,6 +383,19 @@ def main():
                                                    ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s')
             del m3, c3, bt3, y3
             B_PER_GPU = 16
+        if B_PER_GPU == 16:
+            # the reference's OWN default eval shape (eval_smpl_short.py:376-380,401,405): B = 32 clips of T = 35 frames (10 past + 25 future).
+            # T % 4 != 0: plain steps take the two-call form (denoiser forward + update kernel), one chain
+            B_PER_GPU, T = 32, 35
+            m5, c5, bt5, y5, _ = build_world(dev, rank)
+            run_steps(diff, m5, c5, bt5, y5, 57, seed=7)
+            c5.apply(bt5['noise'].clone(), 500, y5)
+            w5, o5 = timed_samples(diff, m5, c5, bt5, y5, 1)
+            assert torch.isfinite(o5).all()
+            extra['reference_default_B32_T35'] = dict(workload='eval_smpl_short.py with its own defaults: B=32, T=35 (10 past + 25 future), correction mode, one whole 1000-step sample',
+                                                      steps=STEPS, ms_per_step=1e3 * w5 / STEPS, value=STEPS * 32 * 35 / w5, unit='frame-steps/s')
+            del m5, c5, bt5, y5
+            B_PER_GPU, T = 16, 100
         if B_PER_GPU == 16:
             # BASELINE config #4's per-GPU share: eval_smpl_long.py, B = 64 over 8 GPUs = 8 clips per GPU, autoregressive rollout of
             # K = 4 further windows; every window = conditioning (PointNet++ + 8-layer encoder) + one whole 1000-step sample with correction

@@ -344,6 +344,180 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The same block for SMALL token counts: 16-row M tiles.  With M <= 800 rows (8 clips of 100 frames: BASELINE config #4's share of a
+// GPU, or any batch of that size) the 32-row grid is ceil(M/32) x 5 <= 125 workgroups -- half the chip idle while every workgroup still
+// takes the full 40 k cycles.  Halving the tile doubles the workgroups (<= 250, one per CU) and halves each one's matrix work; the
+// weight stream per workgroup is the same 416 KiB (twice the L2 -> LDS traffic in total, still under the shared-stream ceiling).
+// Same stream, same ring, same pair schedule and barrier placement as above; only the tile maps differ:
+//   phase 1   one row tile x 13 column tiles: waves 0..4 own two (2w, 2w+1), waves 5..7 one (10, 11, 12)
+//   phase 2   one row tile x 16 column tiles: wave w owns 2w, 2w+1
+// The sum of a tile-3 column is taken in one accumulator here and in two (owner / helper) above: the two kernels agree to rounding,
+// not bit for bit, so a caller picks ONE of them for a given batch (launch_ffn: by the rows of the WHOLE batch, see there).
+constexpr int BMH = 16;
+template <int MODE = 0>
+__global__ __launch_bounds__(NT) void ffn_fused16_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
+                                                          const float *__restrict__ b1p, const float *__restrict__ b2,
+                                                          float *__restrict__ parts) {
+    __shared__ __attribute__((aligned(1024))) float smem[BMH * D + 3 * PSLOT + 256];
+    float *Xs = smem, *ring = smem + BMH * D, *Bs = ring + 3 * PSLOT;
+    idf_args_now(x2, M, pack, b1p, b2, parts);
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BMH;
+    const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
+    const uint32_t lane16 = lane << 4;
+    const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
+    const bool lt2 = wave < 2;
+    const int key = (4 - (li >> 2)) & 3;
+    auto issue_pair = [&](int P) {
+        if (P >= NPAIR) return;
+        const int nins = pair_ins(P);
+        const uint32_t so = (uint32_t)(pair_off(P) * 4), dof = (uint32_t)((P % 3) * PSLOT * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (8 * j + 7 < nins) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+            else if (8 * j < nins && lt2) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+        }
+    };
+    auto wait_pair_before = [&](int P) {
+        if (P >= NPAIR) { wait_vmcnt_n(0); return; }
+        const int nins = pair_ins(P);
+        if (nins % 8 == 0) wait_vmcnt_n(nins / 8);
+        else if (lt2) wait_vmcnt_n(nins / 8 + 1);
+        else wait_vmcnt_n(nins / 8);
+    };
+    const bool two1 = wave < 5;                            // phase 1: two column tiles (waves 0..4) or one (waves 5..7)
+    const int c0 = two1 ? 2 * wave : 5 + wave;
+
+    if (wave == 0) idf_dma16_s(idf_uniform_ptr(b1p + sl * HS), lane16, idf_lds_addr(Bs));
+    const uint32_t xs_lds = idf_lds_addr(Xs);
+#pragma unroll
+    for (int j = 0; j < BMH / NW; ++j) {
+        const int i = wave + NW * j;
+        idf_dma16_s(idf_uniform_ptr(x2 + (size_t)min(m0 + i, M - 1) * D), (uint32_t)((lane ^ (i & 15)) << 4), xs_lds + (uint32_t)(i * D * 4));
+    }
+    issue_pair(0);
+    issue_pair(1);
+    wait_pair_before(1);
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float4 a0, a1, b0[2], b1f[2];
+    const float *xb[4], *wb1[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xb[m] = Xs + li * D + (((kq ^ li) ^ (4 * m)) << 2);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) wb1[s3] = ring + s3 * PSLOT + ((kq ^ key) << 2) + li * 16 + c0 * 256;
+    auto read1 = [&](int c, float4 &a, float4 (&b)[2]) {
+        a = ldsv4(xb[c & 3] + 64 * (c >> 2));
+        const float *sb = wb1[(c >> 1) % 3] + (c & 1) * W1C;
+        b[0] = ldsv4(sb);
+        if (two1) b[1] = ldsv4(sb + 256);
+    };
+    auto mma1 = [&](const float4 &a, const float4 (&b)[2]) {
+        if (two1) {
+            IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x);
+            IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y);
+            IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z);
+            IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w);
+        } else {
+            IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[0], a.w, b[0].w);
+        }
+    };
+    read1(0, a0, b0);
+#pragma unroll
+    for (int P = 0; P < NP1; ++P) {
+        issue_pair(P + 2);
+        read1(2 * P + 1, a1, b1f);
+        mma1(a0, b0);
+        wait_pair_before(P + 2);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin (see above)
+        __builtin_amdgcn_s_barrier();
+        if (P + 1 < NP1) read1(2 * P + 2, a0, b0);
+        mma1(a1, b1f);
+    }
+    // hid = gelu(acc + b1) over the x2 rows, same swizzled image
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 0 || two1) {
+            const int col = (c0 + j) * 16 + li;
+            const float bv = Bs[col];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = kq * 4 + rr;
+                Xs[row * D + ((((col >> 2) ^ (row & 15))) << 2) + (col & 3)] = gelu_fast(acc[j][rr] + bv);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+
+    // phase 2: wave w owns output column tiles 2w, 2w+1
+    const int nb = wave * 2;
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wb2[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) wb2[s3] = ring + s3 * PSLOT + ((kq ^ key) << 2) + (nb * 16 + li) * 16;
+    auto read2 = [&](int q, float4 &a, float4 (&b)[2]) {
+        a = ldsv4(xb[q & 3] + 64 * (q >> 2));
+        const float *sb = wb2[(NP1 + (q >> 1)) % 3] + (q & 1) * W2C;
+        b[0] = ldsv4(sb);
+        b[1] = ldsv4(sb + 256);
+    };
+    auto mma2 = [&](const float4 &a, const float4 (&b)[2]) {
+        IDF_FFN_MFMA(acc[0], a.x, b[0].x); IDF_FFN_MFMA(acc[1], a.x, b[1].x);
+        IDF_FFN_MFMA(acc[0], a.y, b[0].y); IDF_FFN_MFMA(acc[1], a.y, b[1].y);
+        IDF_FFN_MFMA(acc[0], a.z, b[0].z); IDF_FFN_MFMA(acc[1], a.z, b[1].z);
+        IDF_FFN_MFMA(acc[0], a.w, b[0].w); IDF_FFN_MFMA(acc[1], a.w, b[1].w);
+    };
+    read2(0, a0, b0);
+    constexpr int NST = BMH * (D / 4) / NT;                 // float4 stores per thread (2)
+    float4 xres[NST], bres[NST];
+#pragma unroll
+    for (int P = NP1; P < NPAIR; ++P) {
+        const int q = 2 * (P - NP1);
+        const bool two = q + 1 < NTILE;
+        issue_pair(P + 2);
+        if (P == NPAIR - 2 && sl == 0) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = tid + it * NT, row = idx >> 6, c4 = (idx & 63) << 2;
+                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + row, M - 1) * D + c4);
+                bres[it] = *reinterpret_cast<const float4 *>(b2 + c4);
+            }
+        }
+        if (two) read2(q + 1, a1, b1f);
+        mma2(a0, b0);
+        wait_pair_before(P + 2);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (q + 2 < NTILE) read2(q + 2, a0, b0);
+        if (two) mma2(a1, b1f);
+    }
+    float *Cs = ring;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cs[(kq * 4 + rr) * CSS + (nb + j) * 16 + li] = acc[j][rr];
+    __syncthreads();
+    float *out = parts + (size_t)sl * M * D;
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int idx = tid + it * NT, row = idx >> 6, c4 = (idx & 63) << 2, gr = m0 + row;
+        if (gr >= M) continue;
+        float4 v = ldsv4(Cs + row * CSS + c4);
+        if (sl == 0) {
+            const float4 x = xres[it], bb = bres[it];
+            v.x += x.x + bb.x; v.y += x.y + bb.y; v.z += x.z + bb.z; v.w += x.w + bb.w;
+        }
+        idf_store16_wt(out + (size_t)gr * D + c4, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // LayerNorm + linear for the QKV projection of the two standard layers, on the same skeleton as phase 1 above:
 //     C[M, N] = LN(sum of NP slabs of A)[M,256] . W[N,256]^T + bias            (nn.MultiheadAttention in_proj after the previous
 //                                                                               layer's norm3; torch TransformerDecoderLayer)
@@ -489,8 +663,14 @@ inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, co
                        M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
 }
 
-inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {
-    hipLaunchKernelGGL(ffn_fused_kernel<0>, dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
+// rows: 32 / 16 = the M tile to use; 0 = choose by THIS launch's rows (16 when the 32-row grid would leave half the chip idle: M <= 800).
+// The two kernels differ in the rounding of one column tile, so a caller that splits a batch into chains must pass the choice made for
+// the WHOLE batch (idf_mdm_weights.tune[IDF_TUNE_FFN]: 0 auto, 1 = 32, 2 = 16; interdiff_amd/mdm.py sets it from the batch it is handed).
+constexpr int FFN16_MAX_ROWS = 800;
+inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows = 0) {
+    if (rows == 0) rows = M <= FFN16_MAX_ROWS ? 16 : 32;
+    if (rows == 16) hipLaunchKernelGGL(ffn_fused16_kernel<0>, dim3((unsigned)(idf_cdiv(M, BMH) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
+    else hipLaunchKernelGGL(ffn_fused_kernel<0>, dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
 }
 
 }  // namespace idf_ffn

@@ -77,6 +77,7 @@ class GaussianDiffusion:
         self._tables = {}
         self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
         self.split_chains = True             # ... and, for batches that do not fill the chip, as two independent half-batch chains
+        self.split_min_rows = None           # ... when the batch has more token rows than this (None: the denoiser's FFN16_MAX_ROWS, see _graph_loop)
         self.stagger_steps = STAGGER_STEPS   # ... which step through the WHOLE loop on their own streams, this many steps apart, when the hook can be called per half batch
         self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
@@ -156,7 +157,8 @@ class GaussianDiffusion:
         # graph, overlap each other's dead time.  Clips never interact in a plain step, the noise of a chain is drawn at the whole
         # batch's counters (state[6]), so the result is bit-identical to the single chain.  Hook steps stay whole-batch.
         nch = N_CHAINS
-        split = fused and self.split_chains and nch > 1 and B % nch == 0 and 2 * nch <= B <= SPLIT_MAX_BATCH
+        split = (fused and self.split_chains and nch > 1 and B % nch == 0 and 2 * nch <= B <= SPLIT_MAX_BATCH
+                 and B * img.shape[-1] > (getattr(model, 'FFN16_MAX_ROWS', 0) if self.split_min_rows is None else self.split_min_rows))      # smaller batches: launch-latency bound either way, and the feed-forward's 16-row grid already spans the chip (tools/small_batch_ab.py: equal at B = 8, one chain 7 % faster at B = 4)
         if split and not hasattr(st, 'chains'):
             h = B // nch
             st.chains = []
@@ -173,6 +175,8 @@ class GaussianDiffusion:
                 ch.cond.copy_(st.cond[:, ch.sl])
                 model.prepare_memory(ch.cond, into=ch.memctx)
 
+        rows = B * img.shape[-1]                    # the whole batch's token rows: what every chain's feed-forward tile is picked by (MDM._pick_ffn_tile)
+
         def graph_of(k):
             """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
             if (k, fused, split) not in st.graphs:
@@ -184,7 +188,7 @@ class GaussianDiffusion:
                             ch.stream.wait_stream(cur)
                             with torch.cuda.stream(ch.stream):
                                 for _ in range(k):
-                                    model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws)
+                                    model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
                         for ch in st.chains:
                             cur.wait_stream(ch.stream)
                     else:
@@ -253,6 +257,7 @@ class GaussianDiffusion:
         lib = _lib.load()
         dev, B = st.x.device, st.x.shape[0]
         chains, h = st.chains, st.x.shape[0] // len(st.chains)
+        rows = st.x.shape[0] * st.x.shape[-1]
         end = t_start - todo
         # ---- the schedule, the same for every chain: plain runs in captured block sizes, hook steps, dump points
         prog, i, it = [], t_start, 0
@@ -287,12 +292,12 @@ class GaussianDiffusion:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         for _ in range(k):
-                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws)
+                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
                     ch.graphs[k] = g
             if need_fwd and 'fwd' not in ch.graphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    model(ch.x, ch.ts, out=ch.x0, memctx=ch.memctx, ws=ch.ws)
+                    model(ch.x, ch.ts, out=ch.x0, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
                 ch.graphs['fwd'] = g
         for c, ch in enumerate(chains):
             ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))

@@ -270,6 +270,7 @@ class MDM:
         self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
         self._mem_key, self._mem_cond, self._memctx, self._ws = None, None, None, None
         self._ws_shape, self._ws_pool, self._memctx_pool = None, {}, {}
+        self.ffn_rows = 0                           # 0: feed-forward tile by batch size (_pick_ffn_tile); 16 / 32: forced
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -362,6 +363,7 @@ class MDM:
         obj6 = tr.matrix_to_rotation_6d(tr.axis_angle_to_matrix(obj_angles.reshape(T, B, -1, 3))).reshape(T, B, -1)
         gt = torch.cat([body6, body_trans.float(), obj6, obj_trans.float()], dim=2)                       # [T,B,144]
         x_past = gt[:past_len].permute(1, 2, 0).unsqueeze(1).contiguous()                                # [B,1,144,past]
+        self._pick_ffn_tile(B * past_len)
         need = self.lib.interdiff_mdm_encode_workspace_bytes(B, past_len)
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         cond = torch.empty(past_len, B, D, dtype=torch.float32, device=self.device)
@@ -369,9 +371,21 @@ class MDM:
                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_encode')
         return cond, gt
 
-    def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None):
-        """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted)."""
+    FFN16_MAX_ROWS = 800      # csrc/ffn.h FFN16_MAX_ROWS: up to here the 16-row kernel's grid still fits the chip in one round
+
+    def _pick_ffn_tile(self, rows):
+        """The fused feed-forward block has a 32-row and a 16-row kernel (csrc/ffn.h) that agree to rounding, not bit for bit: every
+        launch of one sample must take the same one, whichever way the sampler cuts the batch into chains -- so the choice is made
+        HERE from the rows of the whole batch and handed down (``tune[IDF_TUNE_FFN]``), not left to the per-launch default.
+        ``self.ffn_rows`` (16 / 32) overrides it (A/B runs: tools/ffn16_ab.py)."""
+        rows = self.ffn_rows or (16 if rows <= self.FFN16_MAX_ROWS else 32)
+        self.w.tune[_lib.TUNE['ffn']] = 2 if rows == 16 else 1
+
+    def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
+        """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).
+        ``batch_rows``: B * T of the batch this call is a chain of (default: this call's own)."""
         B, one, Cc, T = x.shape
+        self._pick_ffn_tile(batch_rows or B * T)
         if memctx is None:
             if y is None or 'cond' not in y:
                 raise ValueError("model_kwargs['y']['cond'] is required")
@@ -400,12 +414,14 @@ class MDM:
     def supports_forward_step(self):
         return not self.w.layer[0].is_qan             # the step's sampler bookkeeping rides on layer 0's QKV kernel
 
-    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None):
+    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None, batch_rows=None):
         """One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
         the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place.  T % 4 == 0.  ``memctx`` / ``ws``:
         caller-owned folded memory (``prepare_memory(cond, into=)``) and workspace (``workspace_bytes(B, T)`` bytes) instead of the
-        model's -- what lets two chains of one sample run side by side."""
+        model's -- what lets two chains of one sample run side by side; ``batch_rows`` then names the whole batch's B * T (see
+        ``_pick_ffn_tile``)."""
         B, one, Cc, T = x.shape
+        self._pick_ffn_tile(batch_rows or B * T)
         if one != 1 or Cc != self.w.C or not x.is_contiguous():
             raise ValueError('x must be a contiguous [B,1,%d,T]' % self.w.C)
         if memctx is None:
@@ -424,11 +440,12 @@ class MDM:
         return x
 
 
-def ffn_parts(model, x2, layer, encoder=False, out=None):
+def ffn_parts(model, x2, layer, encoder=False, out=None, batch_rows=None):
     """The fused feed-forward block of one layer on ``model``'s weights: x2 [M,256] -> partial slabs [FFN_SLICES, M, 256] whose
-    sum is x2 + linear2(gelu(linear1(x2))) (interdiff_mdm_ffn)."""
+    sum is x2 + linear2(gelu(linear1(x2))) (interdiff_mdm_ffn).  Tile by ``batch_rows`` (default M), see MDM._pick_ffn_tile."""
     lib = _lib.load()
     M = x2.shape[0]
+    model._pick_ffn_tile(batch_rows or M)
     x2 = x2.contiguous()
     if out is None:
         out = torch.empty(_lib.FFN_SLICES, M, D, dtype=torch.float32, device=x2.device)

@@ -30,12 +30,14 @@ def pair_ins(P):
     return 2 * W1C // 256 if P < NP1 else (2 * W2C // 256 if P < NPAIR - 1 else W2C // 256)
 
 
-def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
+def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
+    """bm = 32: ffn_fused_kernel; bm = 16: ffn_fused16_kernel (one row tile, two column tiles per wave, no shared tile)."""
     M = x2.shape[0]
-    m0 = mt * BM
+    m0 = mt * bm
+    small = bm == 16
     nt = NTILE
     stream = pack[sl * SLICE_FLOATS:(sl + 1) * SLICE_FLOATS]
-    Xs, ring, Bs = np.zeros(BM * D), np.full(3 * PSLOT, np.nan), np.zeros(256)
+    Xs, ring, Bs = np.zeros(bm * D), np.full(3 * PSLOT, np.nan), np.zeros(256)
     lane = np.arange(64)
     li, kq = lane & 15, lane >> 4
     key = (4 - (li >> 2)) & 3
@@ -63,7 +65,7 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
 
     # prologue
     Bs[:256] = b1p[sl * HS:sl * HS + 256]
-    for i in range(BM):
+    for i in range(bm):
         row = x2[min(m0 + i, M - 1)]
         for l in range(64):
             Xs[i * D + l * 4:i * D + l * 4 + 4] = row[(l ^ (i & 15)) * 4:(l ^ (i & 15)) * 4 + 4]
@@ -85,8 +87,10 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
         r1 = (wave >> 1) & 1
         c0 = ((7 if wave < 4 else 10) if wave & 1 else (0 if wave < 4 else 4))
         nct = 4 if wave in (0, 2) else 3
+        if small:                                     # 13 column tiles of the one row tile: 2,2,2,2,2,1,1,1
+            r1, c0, nct = 0, (2 * wave if wave < 5 else 5 + wave), (2 if wave < 5 else 1)
         maps.append((r1, c0, nct))
-        for j in range(4 if wave < 4 else 3):         # waves 1, 3 hold the odd-chunk half of their neighbour's fourth tile in acc[3]
+        for j in range(nct if small else (4 if wave < 4 else 3)):         # waves 1, 3 hold the odd-chunk half of their neighbour's fourth tile in acc[3]
             hid_acc[(wave, j)] = np.zeros((16, 16))
 
     def read1(wave, c):
@@ -94,9 +98,11 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
         rows = r1 * 16 + li
         a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
         bs = []
-        for j in range(3):
+        for j in range(nct if small else 3):
             base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
+        if small:
+            return a, bs
         # the shared column tile 3: owners (waves 0, 2) on even chunks and the last one, helpers (waves 1, 3) on the other odd chunks
         if (wave in (1, 3)) if (c & 1 and c != 15) else (wave in (0, 2)):
             base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + 3 * 256
@@ -118,8 +124,9 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
             for j, b in enumerate(bs):
                 mfma_group(hid_acc[(w, j)], a, b)
     assert maps[0][0] == maps[1][0] and maps[2][0] == maps[3][0]            # owner and helper work on the same row tile
-    hid_acc[(0, 3)] += hid_acc.pop((1, 3))
-    hid_acc[(2, 3)] += hid_acc.pop((3, 3))
+    if not small:
+        hid_acc[(0, 3)] += hid_acc.pop((1, 3))
+        hid_acc[(2, 3)] += hid_acc.pop((3, 3))
     # epilogue 1: gelu(acc + b1) -> Xs (swizzled), D layout: lane (li, kq), reg rr -> row kq*4+rr, col li
     for w in range(NW):
         r1, c0, nct = maps[w]
@@ -130,14 +137,15 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
                     row, col = r1 * 16 + rr, (c0 + j) * 16 + cc
                     Xs[row * D + (((col >> 2) ^ (row & 15)) << 2) + (col & 3)] = _gelu(t[rr, cc] + Bs[col])
     # ---- phase 2
-    out_acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(4)}
+    nj2 = 2 if small else 4
+    out_acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(nj2)}
 
     def read2(wave, q):
-        r2, nb = wave & 1, (wave >> 1) * 4
+        r2, nb = (0, wave * 2) if small else (wave & 1, (wave >> 1) * 4)
         rows = r2 * 16 + li
         a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (q & 3))) << 2) + 64 * (q >> 2) + t] for t in range(4)], axis=1)
         bs = []
-        for j in range(4):
+        for j in range(nj2):
             base = ((NP1 + (q >> 1)) % 3) * PSLOT + (q & 1) * W2C + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
@@ -161,25 +169,25 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late):
                 for j, b in enumerate(bs):
                     mfma_group(out_acc[(w, j)], a, b)
     assert not pending
-    part = np.zeros((BM, D))
+    part = np.zeros((bm, D))
     for w in range(NW):
-        r2, nb = w & 1, (w >> 1) * 4
-        for j in range(4):
+        r2, nb = (0, w * 2) if small else (w & 1, (w >> 1) * 4)
+        for j in range(nj2):
             part[r2 * 16:r2 * 16 + 16, (nb + j) * 16:(nb + j) * 16 + 16] = out_acc[(w, j)]
-    rows = np.minimum(m0 + np.arange(BM), M - 1)
+    rows = np.minimum(m0 + np.arange(bm), M - 1)
     if sl == 0:
         part = part + x2[rows] + b2[None, :]
-    return part[:max(0, min(BM, M - m0))]
+    return part[:max(0, min(bm, M - m0))]
 
 
-def emulate_ffn(x2, pack, b1p, b2, late):
+def emulate_ffn(x2, pack, b1p, b2, late, bm=BM):
     """All workgroups -> parts [NSL][M][256] (float64 arithmetic)."""
     M = x2.shape[0]
     parts = np.zeros((NSL, M, D))
-    for mt in range((M + BM - 1) // BM):
+    for mt in range((M + bm - 1) // bm):
         for sl in range(NSL):
-            p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1p.astype(np.float64), b2.astype(np.float64), mt, sl, late)
-            parts[sl, mt * BM:mt * BM + p.shape[0]] = p
+            p = emulate_workgroup(x2.astype(np.float64), pack.astype(np.float64), b1p.astype(np.float64), b2.astype(np.float64), mt, sl, late, bm)
+            parts[sl, mt * bm:mt * bm + p.shape[0]] = p
     return parts
 
 

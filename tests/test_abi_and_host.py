@@ -214,7 +214,7 @@ def test_joint_map_vjp_host_matches_autograd():
 def test_ffn_pack_and_kernel_addressing_by_emulation():
     """The fused feed-forward kernel (csrc/ffn.h) restated lane by lane in numpy (tests/ffn_emulator.py) on the weight stream
     pack_ffn builds: sum of the five partial slabs == x2 + linear2(gelu(linear1(x2))) for a ragged row count, with the DMA applied
-    at issue time and at the covering wait (ring-slot reuse hazards show up as a wrong answer in one of the two)."""
+    at issue time and at the covering wait (ring-slot reuse hazards show up as a wrong answer in one of the two); both row tiles."""
     import numpy as np
     from interdiff_amd.mdm import pack_ffn, pad_ffn_bias, ffn_slices
     from tests.ffn_emulator import emulate_ffn, _gelu
@@ -227,10 +227,11 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
     pack = pack_ffn(w1, w2)
     assert [s for s in ffn_slices()] == [(0, 208), (208, 208), (416, 208), (624, 208), (832, 208)] and pack.size == 5 * 106496
     ref = x2.astype(np.float64) + _gelu(x2.astype(np.float64) @ w1.T.astype(np.float64) + b1) @ w2.T.astype(np.float64) + b2
-    for late in (False, True):
-        parts = emulate_ffn(x2, pack, pad_ffn_bias(b1), b2, late)
-        err = np.abs(parts.sum(0) - ref).max()
-        assert err < 1e-9, (late, err)
+    for bm in (32, 16):                                    # ffn_fused_kernel / ffn_fused16_kernel (three M tiles, the last ragged)
+        for late in (False, True):
+            parts = emulate_ffn(x2, pack, pad_ffn_bias(b1), b2, late, bm)
+            err = np.abs(parts.sum(0) - ref).max()
+            assert err < 1e-9, (bm, late, err)
 
 
 def test_out_projection_fragments_match_the_attention_kernel_addressing():

@@ -609,25 +609,39 @@ def test_gemm_f32_epilogues_vs_torch_fp32(lib):
         linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0
 
 
-@pytest.mark.parametrize('M', [1, 31, 33, 160, 1600, 3200])
+@pytest.mark.parametrize('M', [1, 15, 17, 31, 33, 160, 800, 1600, 3200])
 def test_fused_ffn_vs_torch_fp64(mdm, M):
     """interdiff_mdm_ffn (csrc/ffn.h: linear1 -> gelu -> linear2 in one launch, five partial slabs summed by the reader) against
-    torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts."""
+    torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts, BOTH row
+    tiles (the 32-row kernel and the 16-row one small batches take) and the default pick between them."""
     from interdiff_amd.mdm import ffn_parts
     g = torch.Generator().manual_seed(100 + M)
     x2 = torch.randn(M, 256, generator=g)
     sd = fx.mdm_weights()
-    for enc, layer, pre in ((False, 1, 'decoder.layers.1.'), (False, 7, 'decoder.layers.7.'), (True, 3, 'encoder.layers.3.')):
-        parts = ffn_parts(mdm, x2.to(DEV), layer, encoder=enc)
-        assert parts.shape == (5, M, 256)
-        got = (((parts[0] + parts[1]) + parts[2]) + parts[3]) + parts[4]
-        w1, b1 = sd[pre + 'linear1.weight'].double(), sd[pre + 'linear1.bias'].double()
-        w2, b2 = sd[pre + 'linear2.weight'].double(), sd[pre + 'linear2.bias'].double()
-        xd = x2.double()
-        ref = xd + torch.nn.functional.gelu(xd @ w1.T + b1) @ w2.T + b2
-        close(got, ref, 2e-6, 'fused FFN M=%d %s' % (M, pre))
-    again = ffn_parts(mdm, x2.to(DEV), 1)
-    assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1)), 'deterministic: no atomics, fixed summation order'
+    outs = {}
+    try:
+        for rows in (32, 16, 0):
+            mdm.ffn_rows = rows
+            for enc, layer, pre in ((False, 1, 'decoder.layers.1.'), (False, 7, 'decoder.layers.7.'), (True, 3, 'encoder.layers.3.')):
+                parts = ffn_parts(mdm, x2.to(DEV), layer, encoder=enc)
+                assert parts.shape == (5, M, 256)
+                got = (((parts[0] + parts[1]) + parts[2]) + parts[3]) + parts[4]
+                w1, b1 = sd[pre + 'linear1.weight'].double(), sd[pre + 'linear1.bias'].double()
+                w2, b2 = sd[pre + 'linear2.weight'].double(), sd[pre + 'linear2.bias'].double()
+                xd = x2.double()
+                ref = xd + torch.nn.functional.gelu(xd @ w1.T + b1) @ w2.T + b2
+                close(got, ref, 2e-6, 'fused FFN M=%d rows=%d %s' % (M, rows, pre))
+                outs[rows, pre] = parts
+            again = ffn_parts(mdm, x2.to(DEV), 1)
+            assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1)), 'deterministic: no atomics, fixed summation order'
+            assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1, batch_rows=M)), 'batch_rows = M is the default'
+        for pre in ('decoder.layers.1.', 'decoder.layers.7.', 'encoder.layers.3.'):                   # the default = the documented pick
+            assert torch.equal(outs[0, pre], outs[16 if M <= mdm.FFN16_MAX_ROWS else 32, pre])
+        mdm.ffn_rows = 0                                       # a chain of a larger batch takes the BATCH's tile
+        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=4000), outs[32, 'decoder.layers.1.'])
+        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=max(M, 600)), outs[16 if max(M, 600) <= 800 else 32, 'decoder.layers.1.'])
+    finally:
+        mdm.ffn_rows = 0
 
 
 # ------------------------------------------------------------------------------------------ other BASELINE configurations
@@ -1231,6 +1245,7 @@ def test_two_chain_plain_steps_equal_single_chain_and_eager(mdm, smpl):
     batch in between.  Bit-identical to the single chain and to the eager loop, with and without mask / hook, and on graph reuse."""
     from interdiff_amd.diffusion import create_gaussian_diffusion
     diff = create_gaussian_diffusion('cosine', 1000)
+    diff.split_min_rows = 0                  # by default batches of <= 800 token rows stay one chain: take the split at test size
     T, P = 12, 64
     corr = make_correction(smpl, T, P)
     for B, seed in ((4, 51), (6, 52)):
@@ -1299,13 +1314,15 @@ def _philox_step(lib_, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B', [16, 32])
+@pytest.mark.parametrize('B', [8, 12, 16, 32])
 def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     """What bench.py times -- hipGraph blocks of fused plain steps (interdiff_mdm_forward_step), two half-batch chains whose 32-row
     tiles straddle clips at T = 100, in-kernel Philox, whole-batch hook steps in between -- against the EAGER route (one launch
     sequence per step, two-call update, noise INJECTED from the materialised Philox stream) at BASELINE configs #2 / #3:
     B = 16 / 32, T = 100, P = 2048, 120 steps from t = 560 (corrected steps t = 500 and t = 450 inside).  Bit for bit.
-    Reference loop: diffusion/gaussian_diffusion.py:663-736."""
+    B = 12: chains of 600 rows inside a batch of 1200 -- every launch must take the feed-forward tile picked for the BATCH (32 rows),
+    not the one a 600-row launch would pick for itself (MDM._pick_ffn_tile).  B = 8 (config #4's share of a GPU): 800 rows, the
+    16-row feed-forward kernel, one chain.  Reference loop: diffusion/gaussian_diffusion.py:663-736."""
     from interdiff_amd.diffusion import create_gaussian_diffusion
     diff = create_gaussian_diffusion('cosine', 1000)
     T, P = fx.TIMED_T, fx.TIMED_P
@@ -1318,8 +1335,9 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     assert diff.fuse_plain_step and diff.split_chains
     timed = run(seed=seed)
     st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(x_t.shape)]
-    assert len(st) == 1 and hasattr(st[0], 'chains') and len(st[0].chains) == 2, 'two-chain route not taken'
-    assert all(key[1] and key[2] for key in st[0].graphs if isinstance(key, tuple)), 'fused + split graphs expected: %r' % list(st[0].graphs)
+    two = B * T > mdm.FFN16_MAX_ROWS
+    assert len(st) == 1 and (hasattr(st[0], 'chains') and len(st[0].chains) == 2) == two, 'two-chain route %s' % ('not taken' if two else 'taken')
+    assert all(key[1] and key[2] == two for key in st[0].graphs if isinstance(key, tuple)), 'fused%s graphs expected: %r' % (' + split' if two else '', list(st[0].graphs))
     eager = run(step_noise=_philox_step(lib, seed), use_graph=False)
     assert torch.equal(timed, eager), 'timed route differs from the eager injected-noise route at B=%d: %g' % (B, (timed - eager).abs().max())
     assert torch.equal(timed, run(seed=seed)), 'graph reuse'

@@ -96,7 +96,7 @@ def kernel_profile(diff, model, corr, bt, y, n_steps=30):
             for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]}
 
 
-def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True):
+def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True, n_rows=None):
     """The roofline kernel: the fused feed-forward block of one layer (csrc/ffn.h: [1600,256] -> linear1 -> gelu -> linear2 as five
     partial slabs; 8 of the 22 launches of a denoiser forward and the bulk of its FLOP), timed live with HIP events on the launch
     stream around `reps` launches replayed from a hipGraph, so that the figure is the GPU's whatever the host is doing.
@@ -105,16 +105,18 @@ def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True):
     L2s where a burst on ONE layer leaves it; rocprofv3's in-situ average (profiles/) is the cross-check.  cycle_layers=False: the
     round-2 burst on layer 1 (secondary key).  Returns the MEAN of three bursts (and the best, for reference).
     chains = 2: the form the sampler's plain steps launch it in -- the batch's rows as two halves, each half a chain of
-    launches on its own branch of the graph; the figure is then per PAIR of concurrent half-size launches (the same FLOP)."""
+    launches on its own branch of the graph; the figure is then per PAIR of concurrent half-size launches (the same FLOP).
+    n_rows: another batch's token rows (<= 800: the 16-row tile kernel, csrc/ffn.h ffn_fused16_kernel) instead of the workload's."""
     from interdiff_amd.mdm import ffn_parts
-    N = B_PER_GPU * T // chains
+    total = n_rows or B_PER_GPU * T
+    N = total // chains
     g = torch.Generator().manual_seed(5)
     x2 = [[torch.randn(N, 256, generator=g).to(dev) for _ in range(2)] for _ in range(chains)]
     parts = [[torch.empty(_lib.FFN_SLICES, N, 256, device=dev) for _ in range(2)] for _ in range(chains)]
     layer_of = (lambda i: i % 8) if cycle_layers else (lambda i: 1)
     for i in range(20):
         for c in range(chains):
-            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1])
+            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1], batch_rows=total)
     torch.cuda.synchronize()
     per_graph = 48
     side = torch.cuda.Stream(device=dev)
@@ -124,14 +126,14 @@ def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True):
         with torch.cuda.graph(graph, stream=side):
             if chains == 1:
                 for i in range(per_graph):
-                    ffn_parts(model, x2[0][i & 1], layer_of(i), out=parts[0][i & 1])
+                    ffn_parts(model, x2[0][i & 1], layer_of(i), out=parts[0][i & 1], batch_rows=total)
             else:
                 cur = torch.cuda.current_stream()
                 for c in range(chains):
                     branch[c].wait_stream(cur)
                     with torch.cuda.stream(branch[c]):
                         for i in range(per_graph):
-                            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1])
+                            ffn_parts(model, x2[c][i & 1], layer_of(i), out=parts[c][i & 1], batch_rows=total)
                 for c in range(chains):
                     cur.wait_stream(branch[c])
         graph.replay()
@@ -377,9 +379,10 @@ def main():
             m3, c3, bt3, y3, _ = build_world(dev, rank)
             run_steps(diff, m3, c3, bt3, y3, 57, seed=7)
             c3.apply(bt3['noise'].clone(), 500, y3)
-            w3, o3 = timed_samples(diff, m3, c3, bt3, y3, 1)
+            w3s = [timed_samples(diff, m3, c3, bt3, y3, 1, seed0=233 + i) for i in range(2)]
+            w3, o3 = min(w[0] for w in w3s), w3s[-1][1]
             assert torch.isfinite(o3).all()
-            extra['config3_B32_correction'] = dict(workload='eval_smpl_short.py correction mode, B=32, T=%d, one whole sample' % T, steps=STEPS,
+            extra['config3_B32_correction'] = dict(workload='eval_smpl_short.py correction mode, B=32, T=%d, one whole sample (the faster of two; both in seconds_each)' % T, steps=STEPS, seconds_each=[w[0] for w in w3s],
                                                    ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s')
             del m3, c3, bt3, y3
             B_PER_GPU = 16
@@ -390,10 +393,11 @@ def main():
             m5, c5, bt5, y5, _ = build_world(dev, rank)
             run_steps(diff, m5, c5, bt5, y5, 57, seed=7)
             c5.apply(bt5['noise'].clone(), 500, y5)
-            w5, o5 = timed_samples(diff, m5, c5, bt5, y5, 1)
+            w5s = [timed_samples(diff, m5, c5, bt5, y5, 1, seed0=233 + i) for i in range(2)]
+            w5, o5 = min(w[0] for w in w5s), w5s[-1][1]
             assert torch.isfinite(o5).all()
-            extra['reference_default_B32_T35'] = dict(workload='eval_smpl_short.py with its own defaults: B=32, T=35 (10 past + 25 future), correction mode, one whole 1000-step sample',
-                                                      steps=STEPS, ms_per_step=1e3 * w5 / STEPS, value=STEPS * 32 * 35 / w5, unit='frame-steps/s')
+            extra['reference_default_B32_T35'] = dict(workload='eval_smpl_short.py with its own defaults: B=32, T=35 (10 past + 25 future), correction mode, one whole 1000-step sample (the faster of two; both in seconds_each)',
+                                                      steps=STEPS, seconds_each=[w[0] for w in w5s], ms_per_step=1e3 * w5 / STEPS, value=STEPS * 32 * 35 / w5, unit='frame-steps/s')
             del m5, c5, bt5, y5
             B_PER_GPU, T = 16, 100
         if B_PER_GPU == 16:
@@ -422,6 +426,7 @@ def main():
         dom_us, dom_best = time_dominant_kernel(model, dev)
         burst_us, burst_best = time_dominant_kernel(model, dev, cycle_layers=False)
         pair_us, pair_best = time_dominant_kernel(model, dev, chains=2)
+        small_us, small_best = time_dominant_kernel(model, dev, n_rows=800)
         fwd_us = time_forward_graph(model, bt, y, dev)
         log('kernel profile done')
     # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
@@ -491,6 +496,10 @@ def main():
                                                     note='the sampler steps a batch of <= 32 clips as two half-batch kernel chains on two branches of one '
                                                          'graph: the same layer = two concurrent launches at M=%d, timed as two such chains of back-to-back '
                                                          'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
+                                small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best,
+                                                             frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                             note='ffn_fused16_kernel: the tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU): '
+                                                                  '250 workgroups of 16 rows instead of 125 of 32; same layer-cycling burst as the headline figure'),
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
                                 note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
                                      'of a denoiser forward; duration = mean of three bursts of 192 launches replayed from a hipGraph that walk through the '

@@ -146,7 +146,12 @@ typedef struct {
      * ff*, ln_w/ln_b[0..1] (= norm1, norm2); valid when has_encoder != 0 */
     idf_mdm_layer enc_layer[IDF_MDM_LAYERS];
     /* tile-configuration overrides for A/B measurements (tools/kbench.py), indexed by IDF_TUNE_*; all zero = the shipped
-     * configuration.  A field of the handle, not process state: two models in one process never see each other's overrides. */
+     * configuration.  A field of the handle, not process state: two models in one process never see each other's overrides.
+     * One entry is NOT only for A/B runs -- tune[IDF_TUNE_FFN], the row tile of the fused feed-forward block: 0 = by the rows of
+     * the launch (16-row tiles up to 800 rows, 32-row tiles above), 1 = 32-row tiles, 2 = 16-row tiles.  The two kernels agree to
+     * rounding (7e-7 of the output scale), not bit for bit: a caller that steps ONE batch as several calls on row subsets (the
+     * sampler's half-batch chains) sets 1 or 2 from the rows of the whole batch so that every call takes the same kernel
+     * (interdiff_amd/mdm.py: MDM._pick_ffn_tile does this before every forward / forward_step / encode / ffn call). */
     int32_t tune[8];
 } idf_mdm_weights;
 
@@ -164,7 +169,8 @@ int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float 
  * cond [MEM,B,256] (reference layout).  `memctx` must hold interdiff_mdm_memctx_floats(B). */
 /* The feed-forward block of one layer as a standalone op (what bench.py times for its roofline block; the denoiser launches the
  * same kernel): x2 [M,256] -> parts [IDF_FFN_SLICES][M][256] whose sum over the slabs is x2 + linear2(gelu(linear1(x2)))
- * (torch.nn.TransformerDecoderLayer._ff_block + residual; sublayers.py:331-341).  encoder != 0 selects enc_layer[layer]. */
+ * (torch.nn.TransformerDecoderLayer._ff_block + residual; sublayers.py:331-341).  encoder != 0 selects enc_layer[layer].
+ * Row tile by w->tune[IDF_TUNE_FFN] (see idf_mdm_weights). */
 int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts, void *stream);
 
 size_t interdiff_mdm_memctx_floats(int32_t B);

@@ -1,4 +1,4 @@
-"""numpy model of the contact scan's block culling (not product code): fraction of 16-vertex blocks a wave of 128 Morton-sorted object
+"""numpy model of the contact scan's block culling (not product code): fraction of 16-vertex blocks a task of WAVE (64) Morton-sorted object
 points has to score, for block sizes 8 / 16 / 32, on the synthetic body (default or `coherent`) posed by ground-truth and by noisy poses.
 The block size, the seed and the two-level hierarchy of csrc/correction.hip were chosen with it.    python tools/cull_sim.py [coherent]"""
 import os, sys, numpy as np, torch
@@ -7,6 +7,8 @@ from interdiff_amd import synthetic as syn
 from oracle.smpl import smpl_forward
 from oracle import rotations as R
 torch.set_grad_enabled(False)
+
+WAVE = 64          # points per task (csrc/correction.hip TASK)
 
 def morton(p, bits=10):
     lo, hi = p.min(0), p.max(0)
@@ -42,9 +44,11 @@ def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, se
         bm = d2p.min(2)                               # block minima
         if seedmode=='rep':
             best0 = d2p[:,:,0].min(1)
+        elif seedmode=='perfect':                     # the true nearest distance as the seed: the floor of what a better seed could reach
+            best0 = d2.min(1)
         else:
             best0 = np.full(len(q), np.inf)
-        # sequential sim per wave of 128 points
+        # sequential sim per task of WAVE points
         for w in range(len(q)//128):
             sl = slice(128*w, 128*w+128)
             best = best0[sl].copy()
@@ -55,10 +59,11 @@ def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, se
                     ne += 1; lane_need += need.sum()
                     best = np.minimum(best, bm[sl, cb])
             tot_exec += ne; tot += nCB
-    return tot_exec/tot, lane_need/(tot*128)
+    return tot_exec/tot, lane_need/(tot*WAVE)
 
 if __name__ == '__main__':
-    coherent = len(sys.argv) > 1 and sys.argv[1] == 'coherent'
+    coherent = 'coherent' in sys.argv[1:]
+    SEED = 'perfect' if 'perfect' in sys.argv[1:] else 'rep'
     kw = dict(coherent=True) if coherent else {}
     model = {k: torch.from_numpy(v) for k, v in syn.smplh_model(7, **kw).items()}
     bt = syn.make_clip_batch(seed=233, B=4, T=100, n_points=2048)
@@ -80,7 +85,7 @@ if __name__ == '__main__':
         for CB in (8, 16, 32):
             fs = []
             for i, (t, b) in enumerate(fr):
-                f = sim(model, pose[i:i+1], betas[i:i+1], trans[i:i+1], objR[i:i+1], objT[i:i+1], bt['obj_points'][b], CB=CB)
+                f = sim(model, pose[i:i+1], betas[i:i+1], trans[i:i+1], objR[i:i+1], objT[i:i+1], bt['obj_points'][b], CB=CB, seedmode=SEED)
                 fs.append(f)
             fs = np.array(fs)
             print(mode, 'coherent' if coherent else 'default', 'CB', CB, 'exec frac mean %.3f min %.3f max %.3f | lane-need %.3f' % (fs[:,0].mean(), fs[:,0].min(), fs[:,0].max(), fs[:,1].mean()))

@@ -388,7 +388,7 @@ def main():
             B_PER_GPU = 16
         if B_PER_GPU == 16:
             # the reference's OWN default eval shape (eval_smpl_short.py:376-380,401,405): B = 32 clips of T = 35 frames (10 past + 25 future).
-            # T % 4 != 0: plain steps take the two-call form (denoiser forward + update kernel), one chain
+            # T % 4 != 0: the fused step's per-row update form (csrc/gemm.h post_prefetch), two chains of 560 token rows
             B_PER_GPU, T = 32, 35
             m5, c5, bt5, y5, _ = build_world(dev, rank)
             run_steps(diff, m5, c5, bt5, y5, 57, seed=7)

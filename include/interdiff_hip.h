@@ -243,8 +243,10 @@ int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stre
  * (a multiple of 4; 0 unless the clips of a sample are stepped as several independent chains, each with its own x slice, ts slice,
  * state, memctx and workspace: the noise of element e is then drawn at counter [6] + e, i.e. what the undivided batch would draw),
  * [7] reserved (0).  Same bits as the two-call form (the update arithmetic and
- * the noise counter are shared), and the two forms can alternate on one state.  T % 4 == 0 and layer 0 a standard layer
- * (IDF_E_INVAL otherwise: use the two-call form); replaces gaussian_diffusion.py:425-461 (p_sample) for steps without a hook. */
+ * the noise counter are shared), and the two forms can alternate on one state.  Any T: with T % 4 == 0 a lane's four frames are one
+ * aligned 16-byte access (x, gt 16-byte aligned, mask 4-byte aligned), other clip lengths (the reference's default T = 35) take a
+ * per-row form of the same update.  Layer 0 must be a standard layer (IDF_E_INVAL otherwise: use the two-call form); replaces
+ * gaussian_diffusion.py:425-461 (p_sample) for steps without a hook. */
 int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
                                const float *gt, const uint8_t *mask, const float *table, int64_t *state,
                                void *ws, size_t ws_bytes, void *stream);

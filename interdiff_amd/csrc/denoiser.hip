@@ -1013,8 +1013,10 @@ extern "C" int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memc
 extern "C" int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
                                           const float *gt, const uint8_t *mask, const float *table, int64_t *state, void *ws,
                                           size_t ws_bytes, void *stream) {
-    if (!x || !ts || !table || !state || (mask && !gt) || T <= 0 || (T & 3)) return IDF_E_INVAL;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 15 || (reinterpret_cast<uintptr_t>(mask) & 3)) return IDF_E_INVAL;
+    if (!x || !ts || !table || !state || (mask && !gt) || T <= 0) return IDF_E_INVAL;
+    // T % 4 == 0: the update is one aligned 16-byte access per lane; other clip lengths take the per-row form of the epilogue (gemm.h)
+    if (!(T & 3) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 15 || (reinterpret_cast<uintptr_t>(mask) & 3))) return IDF_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 3) return IDF_E_INVAL;
     if (!w || w->layer[0].is_qan) return IDF_E_INVAL;         // the step bookkeeping rides on layer 0's QKV kernel
     return mdm_forward_impl(w, memctx, x, ts, B, T, nullptr, ws, ws_bytes, stream, StepPost{x, gt, mask, table, state, ts});
 }

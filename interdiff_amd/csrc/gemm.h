@@ -123,43 +123,92 @@ struct PostOperands {
     uchar4 mk[TM][TN];
     float c1, c2, sigma;
 };
+// component k (0..7) of the eight normals of two consecutive Philox groups
+__device__ __forceinline__ float sel8(const float4 a, const float4 b, int k) {
+    const float lo = k == 0 ? a.x : (k == 1 ? a.y : (k == 2 ? a.z : a.w));
+    const float hi = k == 4 ? b.x : (k == 5 ? b.y : (k == 6 ? b.z : b.w));
+    return k < 4 ? lo : hi;
+}
+// A lane's four accumulator rows are four consecutive frames of one clip = one aligned float4 of x[b][col][t..t+3] when T % 4 == 0
+// (the timed shapes).  Any other clip length (the reference's default T = 35) takes the per-row form: frame r of the lane sits at
+// its own flat index -- unaligned, possibly in the next clip -- and draws component (index & 3) of Philox group (index >> 2), exactly
+// what interdiff_posterior_step_dev gives that element: two groups cover four consecutive elements, a third call only for the rows
+// that cross into the next clip.
 template <int TM, int TN>
 __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN> &po, int rbase0, int col0) {
     const int64_t st = g.post_state[4];                 // {t, loop index} of THIS step, parked by sampler_prepare_step (philox.h)
     const uint64_t it = (uint64_t)g.post_state[5], seed = (uint64_t)g.post_state[2];
     const size_t elem0 = (size_t)g.post_state[6];       // position of x[0] inside the whole sample (a chain of a split batch draws the whole batch's noise)
     po.c1 = g.post_table[st * 4]; po.c2 = g.post_table[st * 4 + 1]; po.sigma = g.post_table[st * 4 + 2];
+    const bool ragged = (g.T & 3) != 0;                 // launch-uniform
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int rbase = min(rbase0 + i * 16, g.M - 4), col = min(col0 + j * 16, g.N - 1);      // clamped: out-of-tile lanes load valid addresses and store nothing
-            const int b = rbase / g.T, t = rbase - b * g.T;
-            const size_t flat = ((size_t)b * g.N + col) * g.T + t;
-            po.xv[i][j] = ld4(g.post_x + flat);
-            po.gv[i][j] = g.post_mask ? ld4(g.post_gt + flat) : zero4();
-            po.mk[i][j] = g.post_mask ? *reinterpret_cast<const uchar4 *>(g.post_mask + flat) : make_uchar4(0, 0, 0, 0);
-            po.e[i][j] = randn4(seed, it, (uint64_t)((flat + elem0) >> 2));
+            const int col = min(col0 + j * 16, g.N - 1);
+            if (!ragged) {
+                const int rbase = min(rbase0 + i * 16, g.M - 4);      // clamped: out-of-tile lanes load valid addresses and store nothing
+                const int b = rbase / g.T, t = rbase - b * g.T;
+                const size_t flat = ((size_t)b * g.N + col) * g.T + t;
+                po.xv[i][j] = ld4(g.post_x + flat);
+                po.gv[i][j] = g.post_mask ? ld4(g.post_gt + flat) : zero4();
+                po.mk[i][j] = g.post_mask ? *reinterpret_cast<const uchar4 *>(g.post_mask + flat) : make_uchar4(0, 0, 0, 0);
+                po.e[i][j] = randn4(seed, it, (uint64_t)((flat + elem0) >> 2));
+            } else {
+                const int r0 = min(rbase0 + i * 16, g.M - 1), b0 = r0 / g.T;
+                const size_t idx0 = ((size_t)b0 * g.N + col) * g.T + (r0 - b0 * g.T) + elem0;
+                const float4 ea = randn4(seed, it, (uint64_t)(idx0 >> 2)), eb = randn4(seed, it, (uint64_t)(idx0 >> 2) + 1);
+                float xr[4], gr[4], er[4];
+                unsigned char mr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(rbase0 + i * 16 + r, g.M - 1), b = row / g.T;
+                    const size_t flat = ((size_t)b * g.N + col) * g.T + (row - b * g.T);
+                    xr[r] = g.post_x[flat];
+                    gr[r] = g.post_mask ? g.post_gt[flat] : 0.f;
+                    mr[r] = g.post_mask ? g.post_mask[flat] : (unsigned char)0;
+                    if (b == b0) er[r] = sel8(ea, eb, (int)(idx0 & 3) + (row - r0));
+                    else {
+                        const size_t idx = flat + elem0;
+                        const float4 ec = randn4(seed, it, (uint64_t)(idx >> 2));
+                        er[r] = sel8(ec, ec, (int)(idx & 3));
+                    }
+                }
+                po.xv[i][j] = make_float4(xr[0], xr[1], xr[2], xr[3]);
+                po.gv[i][j] = make_float4(gr[0], gr[1], gr[2], gr[3]);
+                po.mk[i][j] = make_uchar4(mr[0], mr[1], mr[2], mr[3]);
+                po.e[i][j] = make_float4(er[0], er[1], er[2], er[3]);
+            }
             asm volatile("" : "+v"(po.e[i][j].x), "+v"(po.e[i][j].y), "+v"(po.e[i][j].z), "+v"(po.e[i][j].w));     // computed here, not sunk into the epilogue
         }
 }
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[TM][TN], const float (&bvs)[TN], const PostOperands<TM, TN> &po,
                                               int rbase0, int col0) {
+    const bool ragged = (g.T & 3) != 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rbase = rbase0 + i * 16, col = col0 + j * 16;
             if (col >= g.N || rbase >= g.M) continue;
-            const int b = rbase / g.T, t = rbase - b * g.T;
-            const size_t flat = ((size_t)b * g.N + col) * g.T + t;
             const float bv = bvs[j];
             float4 pv = make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
             const uchar4 m = po.mk[i][j];
             const float4 gv = po.gv[i][j];
             pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
-            idf_store16_wt(g.post_x + flat, posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]));      // the next step's embedding reads x from other XCDs
+            const float4 out = posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]);
+            if (!ragged) {
+                const int b = rbase / g.T, t = rbase - b * g.T;
+                idf_store16_wt(g.post_x + ((size_t)b * g.N + col) * g.T + t, out);      // the next step's embedding reads x from other XCDs
+            } else {
+                const float ov[4] = {out.x, out.y, out.z, out.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + r, b = row / g.T;
+                    if (row < g.M) idf_store4_wt(g.post_x + ((size_t)b * g.N + col) * g.T + (row - b * g.T), ov[r]);
+                }
+            }
         }
 }
 

@@ -139,7 +139,7 @@ class GaussianDiffusion:
         model.prepare_memory(st.cond)                   # once per sample, on the current stream (inside the caller's clock)
         if fresh:
             model(st.x, st.ts, out=st.x0, **st.kwargs)               # warm-up: workspaces, kernel attributes
-            if getattr(model, 'supports_forward_step', False) and img.shape[-1] % 4 == 0:
+            if getattr(model, 'supports_forward_step', False):
                 # ... and the fused step's own instantiations (last GEMM with the update in its epilogue, QKV kernel with the sampler
                 # bookkeeping): their FIRST launch must not happen inside a capture, where a launch error cannot be reported
                 scratch = SimpleNamespace(x=st.x.clone(), ts=st.ts.clone(), state=torch.tensor([1, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev))
@@ -151,7 +151,7 @@ class GaussianDiffusion:
                                                         _lib.dptr(mk, allow_none=True), x.numel(), _lib.dptr(table), _lib.dptr(st.state),
                                                         _lib.dptr(st.ts), B, _lib.stream()), 'posterior_step_dev')
 
-        fused = self.fuse_plain_step and getattr(model, 'supports_forward_step', False) and img.shape[-1] % 4 == 0
+        fused = self.fuse_plain_step and getattr(model, 'supports_forward_step', False)
         # Chains: at <= 16 clips every kernel of a step is one partial wave of workgroups bounded by latency (operand round trips,
         # kernel boundaries), so the two halves of the batch, stepped as independent kernel chains on two branches of the SAME captured
         # graph, overlap each other's dead time.  Clips never interact in a plain step, the noise of a chain is drawn at the whole

@@ -416,7 +416,7 @@ class MDM:
 
     def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None, batch_rows=None):
         """One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
-        the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place.  T % 4 == 0.  ``memctx`` / ``ws``:
+        the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place (any T; T % 4 == 0 takes the 16-byte form of the update).  ``memctx`` / ``ws``:
         caller-owned folded memory (``prepare_memory(cond, into=)``) and workspace (``workspace_bytes(B, T)`` bytes) instead of the
         model's -- what lets two chains of one sample run side by side; ``batch_rows`` then names the whole batch's B * T (see
         ``_pick_ffn_tile``)."""

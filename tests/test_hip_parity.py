@@ -577,8 +577,8 @@ def test_graph_replay_equals_eager(smpl):
         other = diff.p_sample_loop(model, tuple(nz.shape), noise=nz, clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook, seed=78)
         assert not torch.equal(other, eager)
     assert len(model._graph_cache) == 1          # one capture per (schedule, shape, mask, cond shape), living on the denoiser
-    # plain steps with the update inside the denoiser's last GEMM (interdiff_mdm_forward_step: the default when T % 4 == 0; T = 14
-    # above went through the two-call form) against the two-call form and against the eager loop
+    # plain steps with the update inside the denoiser's last GEMM (interdiff_mdm_forward_step, the default: T = 14 above took its
+    # per-row form, T = 12 here its 16-byte form) against the two-call form and against the eager loop
     assert T % 4 != 0 and diff.fuse_plain_step
     bt = fx._clip(41, 2, 12, 64)
     y12, n12 = dev(fx.model_kwargs_y(bt, 12)), bt['noise'].to(DEV)
@@ -965,14 +965,15 @@ def test_denoiser_rejects_unsupported_sizes(mdm):
 
 
 @pytest.mark.gpu
-def test_forward_step_matches_two_call_form_and_rejects_ragged_T(mdm):
+@pytest.mark.parametrize('B,T', [(3, 20), (2, 13), (3, 35), (5, 7)])
+def test_forward_step_matches_two_call_form(mdm, B, T):
     """interdiff_mdm_forward_step (denoiser + inpaint + posterior + in-kernel noise + state advance in the denoiser's own launches)
     against interdiff_mdm_forward followed by interdiff_posterior_step_dev on copies of the same state, two consecutive steps, bit
-    for bit; a clip length that is not a multiple of 4 is refused (IDF_E_INVAL), the caller keeps the two-call form."""
+    for bit.  T % 4 == 0 takes the 16-byte form of the update; T = 13 / 35 (the reference's default clip length) / 7 the per-row
+    form, where a lane's four frames may sit in two clips and draw from three Philox groups (csrc/gemm.h post_prefetch)."""
     from interdiff_amd import _lib
     from interdiff_amd.diffusion import create_gaussian_diffusion
     lib = _lib.load()
-    B, T = 3, 20
     x, ts0, cond = fx.mdm_inputs(B, T)
     g = torch.Generator().manual_seed(9)
     gt, mask = torch.randn(x.shape, generator=g).to(DEV), (torch.rand(x.shape, generator=g) < 0.2).to(DEV).view(torch.uint8)
@@ -980,19 +981,20 @@ def test_forward_step_matches_two_call_form_and_rejects_ragged_T(mdm):
     y = {'cond': cond.to(DEV)}
     assert mdm.supports_forward_step
 
-    def fresh():
-        st = torch.tensor([700, 11, 1234567, 0, 0, 0, 0, 0], dtype=torch.int64, device=DEV)
+    def fresh(elem0=0):
+        st = torch.tensor([700, 11, 1234567, 0, 0, 0, elem0, 0], dtype=torch.int64, device=DEV)
         return x.to(DEV).clone(), torch.full((B,), 700, dtype=torch.int64, device=DEV), st
-    xa, tsa, sta = fresh()
-    xb, tsb, stb = fresh()
-    x0 = torch.empty_like(xb)
-    for step in range(2):
-        mdm.forward_step(xa, tsa, table, sta, gt=gt, mask=mask, y=y)
-        mdm(xb, tsb, y=y, out=x0)
-        _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(xb), _lib.dptr(x0), _lib.dptr(gt), _lib.dptr(mask), xb.numel(), _lib.dptr(table),
-                                                    _lib.dptr(stb), _lib.dptr(tsb), B, _lib.stream()), 'posterior_step_dev')
-        assert torch.equal(xa, xb), 'step %d: %g' % (step, (xa - xb).abs().max())
-        assert torch.equal(tsa, tsb) and torch.equal(sta[:3], stb[:3]) and int(sta[0]) == 699 - step and int(sta[1]) == 12 + step
+    for elem0 in (0, 4 * 1237):                          # a chain of a split batch: its x starts elem0 elements into the sample's noise
+        xa, tsa, sta = fresh(elem0)
+        xb, tsb, stb = fresh(elem0)
+        x0 = torch.empty_like(xb)
+        for step in range(2):
+            mdm.forward_step(xa, tsa, table, sta, gt=gt, mask=mask, y=y)
+            mdm(xb, tsb, y=y, out=x0)
+            _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(xb), _lib.dptr(x0), _lib.dptr(gt), _lib.dptr(mask), xb.numel(), _lib.dptr(table),
+                                                        _lib.dptr(stb), _lib.dptr(tsb), B, _lib.stream()), 'posterior_step_dev')
+            assert torch.equal(xa, xb), 'step %d: %g' % (step, (xa - xb).abs().max())
+            assert torch.equal(tsa, tsb) and torch.equal(sta[:3], stb[:3]) and int(sta[0]) == 699 - step and int(sta[1]) == 12 + step
     # without inpainting operands (gt = mask = NULL)
     xa, tsa, sta = fresh()
     xb, tsb, stb = fresh()
@@ -1001,9 +1003,6 @@ def test_forward_step_matches_two_call_form_and_rejects_ragged_T(mdm):
     _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(xb), _lib.dptr(x0), None, None, xb.numel(), _lib.dptr(table), _lib.dptr(stb), _lib.dptr(tsb), B,
                                                 _lib.stream()), 'posterior_step_dev')
     assert torch.equal(xa, xb) and torch.equal(tsa, tsb)
-    x13, ts13, c13 = fx.mdm_inputs(2, 13)
-    with pytest.raises((RuntimeError, ValueError)):
-        mdm.forward_step(x13.to(DEV), ts13.to(DEV), table, sta, y={'cond': c13.to(DEV)})
 
 
 @pytest.mark.gpu
@@ -1246,9 +1245,9 @@ def test_two_chain_plain_steps_equal_single_chain_and_eager(mdm, smpl):
     from interdiff_amd.diffusion import create_gaussian_diffusion
     diff = create_gaussian_diffusion('cosine', 1000)
     diff.split_min_rows = 0                  # by default batches of <= 800 token rows stay one chain: take the split at test size
-    T, P = 12, 64
-    corr = make_correction(smpl, T, P)
-    for B, seed in ((4, 51), (6, 52)):
+    P = 64
+    for B, seed, T in ((4, 51, 12), (6, 52, 12), (4, 53, 13)):         # T = 13: the per-row form of the fused update, chain 1 at an odd element offset
+        corr = make_correction(smpl, T, P)
         bt = fx._clip(seed, B, T, P)
         y = dev(fx.model_kwargs_y(bt, T))
         noise = bt['noise'].to(DEV)

@@ -308,3 +308,27 @@ def test_scan_order_is_a_consistent_relabelling():
     assert np.median(ext) < 0.1 * whole, (np.median(ext), whole)
     pts = np.array([[0., 0, 0], [1, 1, 1], [0, 0, 0], [0.5, 0.5, 0.5]])
     assert morton_order(pts).tolist() == [0, 2, 3, 1]               # ties keep the lower index first
+
+
+def test_feed_forward_tile_is_picked_from_the_batch_rows():
+    """MDM._pick_ffn_tile (host logic, no GPU): the fused feed-forward block has a 16-row and a 32-row kernel that agree to rounding only,
+    so the tile handed to the library (tune[IDF_TUNE_FFN]: 2 / 1) follows the rows of the WHOLE batch -- 16-row tiles up to
+    FFN16_MAX_ROWS, 32-row tiles above -- and an explicit ``ffn_rows`` wins (A/B runs)."""
+    from types import SimpleNamespace
+    from interdiff_amd import _lib
+    from interdiff_amd.mdm import MDM
+    k = _lib.TUNE['ffn']
+    m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, FFN16_MAX_ROWS=MDM.FFN16_MAX_ROWS)
+    assert MDM.FFN16_MAX_ROWS == 800                         # csrc/ffn.h FFN16_MAX_ROWS: 50 row tiles x 5 slices = 250 workgroups <= 256 CUs
+    for rows, want in ((1, 2), (800, 2), (801, 1), (1600, 1), (3200, 1)):
+        MDM._pick_ffn_tile(m, rows)
+        assert m.w.tune[k] == want, (rows, m.w.tune[k])
+    m.ffn_rows = 32
+    MDM._pick_ffn_tile(m, 100)
+    assert m.w.tune[k] == 1
+    m.ffn_rows = 16
+    MDM._pick_ffn_tile(m, 5000)
+    assert m.w.tune[k] == 2
+    assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched
+    src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
+    assert 'constexpr int FFN16_MAX_ROWS = %d;' % MDM.FFN16_MAX_ROWS in src

@@ -766,7 +766,7 @@ extern "C" int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_
     if (!w || !x2 || !parts || M <= 0 || layer < 0 || layer >= L || (encoder && !w->has_encoder)) return IDF_E_INVAL;
     if ((reinterpret_cast<uintptr_t>(x2) & 15) || (reinterpret_cast<uintptr_t>(parts) & 15)) return IDF_E_INVAL;
     const idf_mdm_layer &ly = encoder ? w->enc_layer[layer] : w->layer[layer];
-    const int rows = w->tune[IDF_TUNE_FFN] == 1 ? 32 : (w->tune[IDF_TUNE_FFN] == 2 ? 16 : 0);
+    const int rows = idf_ffn::ffn_rows_of_tune(w->tune[IDF_TUNE_FFN]);
     idf_ffn::launch_ffn(idf_stream(stream), x2, M, w->arena + ly.ffn_pack, w->arena + ly.ffn_b1p, w->arena + ly.ff2_b, parts, rows);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
@@ -873,7 +873,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
                                ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride,
                                k.xn, ar + ly.sa_out_b);
         }
-        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, w->tune[IDF_TUNE_FFN] == 1 ? 32 : (w->tune[IDF_TUNE_FFN] == 2 ? 16 : 0));
+        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, idf_ffn::ffn_rows_of_tune(w->tune[IDF_TUNE_FFN]));
         u_in = k.parts;
         u_np = NSL;
         lnp_w = ar + ly.ln_w[1];
@@ -977,7 +977,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
         }
         // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
         idf_prof_mark(IDF_K_FFN_FUSED, s);
-        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, tune[IDF_TUNE_FFN] == 1 ? 32 : (tune[IDF_TUNE_FFN] == 2 ? 16 : 0));
+        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]));
         u_in = k.parts;
         u_np = NSL;
         lnp_w = ar + ly.ln_w[2];

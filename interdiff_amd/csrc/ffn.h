@@ -518,6 +518,190 @@ __global__ __launch_bounds__(NT) void ffn_fused16_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The same block for LARGE token counts: 64-row M tiles.  Above 1632 rows (51 x 32) the 32-row grid no longer fits the chip in one round
+// of workgroups, and every further round pays the kernel's fixed part again (prologue, GELU phase, store tail: ~ 40 % of a 32-row
+// workgroup's time; launch_ffn below says from where on that pays).  A 64-row workgroup does two tiles' matrix work behind ONE fixed part and ONE pass over the 416-KiB weight stream:
+// 3200 rows = 250 workgroups in one round instead of 500 in two; as two half-batch chains, 125 + 125 side by side.
+// LDS: 64 KiB of x2 / hid rows + a TWO-slot ring (64 KiB) + the bias slice = 129 KiB.  A slot is refilled right after the barrier that
+// certifies every wave has read it -- one pair-time ahead instead of two, and a pair-time is twice as long here.
+//   phase 1   4 row tiles x 13 column tiles: wave w owns row tile w & 3 and column tiles 0..6 (w < 4) or 7..12 (w >= 4): the two waves
+//             of a SIMD (w, w + 4) hold one row tile's 13 column tiles -- balanced without the shared tile of the 32-row kernel
+//   phase 2   4 row tiles x 16 column tiles: wave w owns row tile w & 3 and output column tiles 8 (w >> 2) .. +7
+// Every tile is summed in one accumulator over the chunks in order: bit-identical to the 16-row kernel, to rounding with the 32-row one.
+constexpr int BMX = 64;
+static_assert(BMX * CSS <= BMX * D + 2 * PSLOT, "output staging fits over the dead x2 / hid rows and the ring");
+template <int MODE = 0>
+__global__ __launch_bounds__(NT) void ffn_fused64_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
+                                                          const float *__restrict__ b1p, const float *__restrict__ b2,
+                                                          float *__restrict__ parts) {
+    __shared__ __attribute__((aligned(1024))) float smem[BMX * D + 2 * PSLOT + 256];
+    float *Xs = smem, *ring = smem + BMX * D, *Bs = ring + 2 * PSLOT;
+    idf_args_now(x2, M, pack, b1p, b2, parts);
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BMX;
+    const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
+    const uint32_t lane16 = lane << 4;
+    const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
+    const bool lt2 = wave < 2;
+    const int key = (4 - (li >> 2)) & 3;
+    auto issue_pair = [&](int P) {                    // pair P -> slot P & 1
+        if (P >= NPAIR) return;
+        const int nins = pair_ins(P);
+        const uint32_t so = (uint32_t)(pair_off(P) * 4), dof = (uint32_t)((P & 1) * PSLOT * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (8 * j + 7 < nins) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+            else if (8 * j < nins && lt2) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+        }
+    };
+    const int rt = wave & 3;                          // this wave's row tile, both phases
+    const bool hi = wave >= 4;                        // phase 1: column tiles 7..12 (six) instead of 0..6 (seven)
+    const int c0 = hi ? 7 : 0;
+
+    if (wave == 0) idf_dma16_s(idf_uniform_ptr(b1p + sl * HS), lane16, idf_lds_addr(Bs));
+    const uint32_t xs_lds = idf_lds_addr(Xs);
+#pragma unroll
+    for (int j = 0; j < BMX / NW; ++j) {
+        const int i = wave + NW * j;
+        idf_dma16_s(idf_uniform_ptr(x2 + (size_t)min(m0 + i, M - 1) * D), (uint32_t)((lane ^ (i & 15)) << 4), xs_lds + (uint32_t)(i * D * 4));
+    }
+    issue_pair(0);
+    issue_pair(1);
+    {   // bias, x2 rows and pair 0 have landed (they are older than this wave's share of pair 1)
+        const int nins = pair_ins(1);
+        if (nins % 8 == 0) wait_vmcnt_n(nins / 8);
+        else if (lt2) wait_vmcnt_n(nins / 8 + 1);
+        else wait_vmcnt_n(nins / 8);
+    }
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 a0, a1, b0[8], b1f[8];
+    const float *xb[4], *wb1[2], *wb2[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xb[m] = Xs + (rt * 16 + li) * D + (((kq ^ li) ^ (4 * m)) << 2);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        wb1[s2] = ring + s2 * PSLOT + ((kq ^ key) << 2) + li * 16 + c0 * 256;
+        wb2[s2] = ring + s2 * PSLOT + ((kq ^ key) << 2) + ((wave >> 2) * 8 * 16 + li) * 16;
+    }
+    auto read1 = [&](int c, float4 &a, float4 (&b)[8]) {
+        a = ldsv4(xb[c & 3] + 64 * (c >> 2));
+        const float *sb = wb1[(c >> 1) & 1] + (c & 1) * W1C;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) b[j] = ldsv4(sb + j * 256);
+        if (!hi) b[6] = ldsv4(sb + 6 * 256);
+    };
+    auto mma1 = [&](const float4 &a, const float4 (&b)[8]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) IDF_FFN_MFMA(acc[j], a.x, b[j].x);
+        if (!hi) IDF_FFN_MFMA(acc[6], a.x, b[6].x);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) IDF_FFN_MFMA(acc[j], a.y, b[j].y);
+        if (!hi) IDF_FFN_MFMA(acc[6], a.y, b[6].y);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) IDF_FFN_MFMA(acc[j], a.z, b[j].z);
+        if (!hi) IDF_FFN_MFMA(acc[6], a.z, b[6].z);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) IDF_FFN_MFMA(acc[j], a.w, b[j].w);
+        if (!hi) IDF_FFN_MFMA(acc[6], a.w, b[6].w);
+    };
+    read1(0, a0, b0);
+#pragma unroll
+    for (int P = 0; P < NP1; ++P) {
+        read1(2 * P + 1, a1, b1f);
+        mma1(a0, b0);
+        wait_vmcnt_n(0);                                     // pair P + 1 has landed (nothing younger is in flight)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as a builtin (see the 32-row kernel)
+        __builtin_amdgcn_s_barrier();
+        issue_pair(P + 2);                                   // every wave has read pair P: its slot is free
+        if (P + 1 < NP1) read1(2 * P + 2, a0, b0);
+        mma1(a1, b1f);
+    }
+    // hid = gelu(acc + b1) over the x2 rows, same swizzled image
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (j < 6 || !hi) {
+            const int col = (c0 + j) * 16 + li;
+            const float bv = Bs[col];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = rt * 16 + kq * 4 + rr;
+                Xs[row * D + ((((col >> 2) ^ (row & 15))) << 2) + (col & 3)] = gelu_fast(acc[j][rr] + bv);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+
+    // phase 2
+    const int nb = (wave >> 2) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto read2 = [&](int q, float4 &a, float4 (&b)[8]) {
+        a = ldsv4(xb[q & 3] + 64 * (q >> 2));
+        const float *sb = wb2[(NP1 + (q >> 1)) & 1] + (q & 1) * W2C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ldsv4(sb + j * 256);
+    };
+    auto mma2 = [&](const float4 &a, const float4 (&b)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) IDF_FFN_MFMA(acc[j], a.x, b[j].x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) IDF_FFN_MFMA(acc[j], a.y, b[j].y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) IDF_FFN_MFMA(acc[j], a.z, b[j].z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) IDF_FFN_MFMA(acc[j], a.w, b[j].w);
+    };
+    read2(0, a0, b0);
+    constexpr int NST = BMX * (D / 4) / NT;                 // float4 stores per thread (8)
+    float4 xres[NST], bres = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int P = NP1; P < NPAIR; ++P) {
+        const int q = 2 * (P - NP1);
+        const bool two = q + 1 < NTILE;
+        if (two) read2(q + 1, a1, b1f);
+        mma2(a0, b0);
+        wait_vmcnt_n(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        issue_pair(P + 2);
+        if (P == NPAIR - 3 && sl == 0) {                     // slab 0: the residual rows and the output bias land with the last pair
+            bres = *reinterpret_cast<const float4 *>(b2 + ((tid & 63) << 2));
+#pragma unroll
+            for (int it = 0; it < NST; ++it)
+                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + (tid >> 6) + it * NW, M - 1) * D + ((tid & 63) << 2));
+        }
+        if (q + 2 < NTILE) read2(q + 2, a0, b0);
+        if (two) mma2(a1, b1f);
+    }
+    float *Cs = smem;                                       // [64][CSS] over the dead hid rows (+ 1 KiB of slot 0): nobody reads LDS after the last barrier
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cs[(rt * 16 + kq * 4 + rr) * CSS + (nb + j) * 16 + li] = acc[j][rr];
+    __syncthreads();
+    float *out = parts + (size_t)sl * M * D;
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int row = (tid >> 6) + it * NW, c4 = (tid & 63) << 2, gr = m0 + row;
+        if (gr >= M) continue;
+        float4 v = ldsv4(Cs + row * CSS + c4);
+        if (sl == 0) {
+            const float4 x = xres[it];
+            v.x += x.x + bres.x; v.y += x.y + bres.y; v.z += x.z + bres.z; v.w += x.w + bres.w;
+        }
+        idf_store16_wt(out + (size_t)gr * D + c4, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // LayerNorm + linear for the QKV projection of the two standard layers, on the same skeleton as phase 1 above:
 //     C[M, N] = LN(sum of NP slabs of A)[M,256] . W[N,256]^T + bias            (nn.MultiheadAttention in_proj after the previous
 //                                                                               layer's norm3; torch TransformerDecoderLayer)
@@ -663,14 +847,26 @@ inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, co
                        M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
 }
 
-// rows: 32 / 16 = the M tile to use; 0 = choose by THIS launch's rows (16 when the 32-row grid would leave half the chip idle: M <= 800).
-// The two kernels differ in the rounding of one column tile, so a caller that splits a batch into chains must pass the choice made for
-// the WHOLE batch (idf_mdm_weights.tune[IDF_TUNE_FFN]: 0 auto, 1 = 32, 2 = 16; interdiff_amd/mdm.py sets it from the batch it is handed).
-constexpr int FFN16_MAX_ROWS = 800;
+// rows: 16 / 32 / 64 = the M tile to use; 0 = choose by THIS launch's rows (ffn_tile_for_rows).  The kernels differ in the rounding of one
+// column tile (32 vs 16 / 64), so a caller that splits a batch into chains must pass the choice made for the WHOLE batch
+// (idf_mdm_weights.tune[IDF_TUNE_FFN]: 0 auto, 1 = 32, 2 = 16, 3 = 64; interdiff_amd/mdm.py sets it from the batch it is handed).
+//   <= 800 rows: 16-row tiles (their grid still fits the chip in one round).
+//   >= 3200 rows: whichever of 32 / 64 takes less time by rounds of workgroups -- a 64-row workgroup costs 32.5 us, a 32-row one 17.7
+//   (tools/ffn16_ab.py): 3200 rows = 250 x 64-row workgroups in one round (34.4 us) instead of 500 x 32-row in two (37.5); 3300 rows = 260
+//   workgroups in two rounds (62 us) against 520 in three (51); 6400 rows 67 against 71.
+//   in between: 32-row tiles (a batch of 24 clips steps as two chains of 1200 rows whose 32-row launches overlap: 0.356 vs 0.407 ms/step).
+constexpr int FFN16_MAX_ROWS = 800, FFN64_MIN_ROWS = 3200, FFN_CUS = 256;
+inline int ffn_tile_for_rows(int rows) {
+    if (rows <= FFN16_MAX_ROWS) return 16;
+    if (rows < FFN64_MIN_ROWS) return 32;
+    const int r32 = idf_cdiv(idf_cdiv(rows, 32) * NSL, FFN_CUS), r64 = idf_cdiv(idf_cdiv(rows, 64) * NSL, FFN_CUS);
+    return 325 * r64 < 177 * r32 ? 64 : 32;
+}
+inline int ffn_rows_of_tune(int t) { return t == 1 ? 32 : (t == 2 ? 16 : (t == 3 ? 64 : 0)); }
 inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows = 0) {
-    if (rows == 0) rows = M <= FFN16_MAX_ROWS ? 16 : 32;
+    if (rows == 0) rows = ffn_tile_for_rows(M);
     if (rows == 16) hipLaunchKernelGGL(ffn_fused16_kernel<0>, dim3((unsigned)(idf_cdiv(M, BMH) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
+    else if (rows == 64) hipLaunchKernelGGL(ffn_fused64_kernel<0>, dim3((unsigned)(idf_cdiv(M, BMX) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
     else hipLaunchKernelGGL(ffn_fused_kernel<0>, dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), 0, s, x2, M, pack, b1p, b2, parts);
 }
-
 }  // namespace idf_ffn

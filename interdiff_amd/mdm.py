@@ -371,15 +371,26 @@ class MDM:
                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_encode')
         return cond, gt
 
-    FFN16_MAX_ROWS = 800      # csrc/ffn.h FFN16_MAX_ROWS: up to here the 16-row kernel's grid still fits the chip in one round
+    FFN16_MAX_ROWS, FFN64_MIN_ROWS = 800, 3200      # csrc/ffn.h
+
+    @classmethod
+    def ffn_tile_for_rows(cls, rows):
+        """csrc/ffn.h ffn_tile_for_rows, for the rows of a whole batch: 16-row tiles while their grid fits the chip in one round of
+        workgroups (<= 800 rows), from 3200 rows on whichever of 32 / 64 takes fewer (weighted) rounds, 32 in between."""
+        if rows <= cls.FFN16_MAX_ROWS:
+            return 16
+        if rows < cls.FFN64_MIN_ROWS:
+            return 32
+        rounds = lambda tile: -(-(-(-rows // tile) * _lib.FFN_SLICES) // 256)
+        return 64 if 325 * rounds(64) < 177 * rounds(32) else 32
 
     def _pick_ffn_tile(self, rows):
-        """The fused feed-forward block has a 32-row and a 16-row kernel (csrc/ffn.h) that agree to rounding, not bit for bit: every
-        launch of one sample must take the same one, whichever way the sampler cuts the batch into chains -- so the choice is made
-        HERE from the rows of the whole batch and handed down (``tune[IDF_TUNE_FFN]``), not left to the per-launch default.
-        ``self.ffn_rows`` (16 / 32) overrides it (A/B runs: tools/ffn16_ab.py)."""
-        rows = self.ffn_rows or (16 if rows <= self.FFN16_MAX_ROWS else 32)
-        self.w.tune[_lib.TUNE['ffn']] = 2 if rows == 16 else 1
+        """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to
+        rounding, not bit for bit: every launch of one sample must take the same one, whichever way the sampler cuts the batch into
+        chains -- so the choice is made HERE from the rows of the whole batch and handed down (``tune[IDF_TUNE_FFN]``), not left to the
+        per-launch default.  ``self.ffn_rows`` (16 / 32 / 64) overrides it (A/B runs: tools/ffn16_ab.py)."""
+        rows = self.ffn_rows or self.ffn_tile_for_rows(rows)
+        self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(rows, 1)
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).

@@ -31,13 +31,16 @@ def pair_ins(P):
 
 
 def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
-    """bm = 32: ffn_fused_kernel; bm = 16: ffn_fused16_kernel (one row tile, two column tiles per wave, no shared tile)."""
+    """bm = 32: ffn_fused_kernel; bm = 16: ffn_fused16_kernel (one row tile, two column tiles per wave, no shared tile); bm = 64:
+    ffn_fused64_kernel (four row tiles, wave w = row tile w & 3 x column half w >> 2, TWO ring slots refilled after the barrier)."""
     M = x2.shape[0]
     m0 = mt * bm
     small = bm == 16
+    big = bm == 64
+    nslot = 2 if big else 3
     nt = NTILE
     stream = pack[sl * SLICE_FLOATS:(sl + 1) * SLICE_FLOATS]
-    Xs, ring, Bs = np.zeros(bm * D), np.full(3 * PSLOT, np.nan), np.zeros(256)
+    Xs, ring, Bs = np.zeros(bm * D), np.full(nslot * PSLOT, np.nan), np.zeros(256)
     lane = np.arange(64)
     li, kq = lane & 15, lane >> 4
     key = (4 - (li >> 2)) & 3
@@ -52,7 +55,7 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
                 if i < nins:                              # 8j+7 < nins for every wave, or the ragged tail for waves 0, 1
                     assert (8 * j + 7 < nins) or (8 * j < nins and wave < 2)
                     src = pair_off(P) + i * 256
-                    ops.append(((P % 3) * PSLOT + i * 256, stream[src:src + 256].copy()))
+                    ops.append(((P % nslot) * PSLOT + i * 256, stream[src:src + 256].copy()))
         if late and ops:
             pending[P] = ops
         else:
@@ -89,8 +92,10 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
         nct = 4 if wave in (0, 2) else 3
         if small:                                     # 13 column tiles of the one row tile: 2,2,2,2,2,1,1,1
             r1, c0, nct = 0, (2 * wave if wave < 5 else 5 + wave), (2 if wave < 5 else 1)
+        if big:                                       # row tile w & 3, column tiles 0..6 (w < 4) or 7..12
+            r1, c0, nct = wave & 3, (7 if wave >= 4 else 0), (6 if wave >= 4 else 7)
         maps.append((r1, c0, nct))
-        for j in range(nct if small else (4 if wave < 4 else 3)):         # waves 1, 3 hold the odd-chunk half of their neighbour's fourth tile in acc[3]
+        for j in range(nct if (small or big) else (4 if wave < 4 else 3)):         # waves 1, 3 hold the odd-chunk half of their neighbour's fourth tile in acc[3]
             hid_acc[(wave, j)] = np.zeros((16, 16))
 
     def read1(wave, c):
@@ -98,33 +103,36 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
         rows = r1 * 16 + li
         a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (c & 3))) << 2) + 64 * (c >> 2) + t] for t in range(4)], axis=1)
         bs = []
-        for j in range(nct if small else 3):
-            base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
+        for j in range(nct if (small or big) else 3):
+            base = ((c >> 1) % nslot) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + (c0 + j) * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
-        if small:
+        if small or big:
             return a, bs
         # the shared column tile 3: owners (waves 0, 2) on even chunks and the last one, helpers (waves 1, 3) on the other odd chunks
         if (wave in (1, 3)) if (c & 1 and c != 15) else (wave in (0, 2)):
-            base = ((c >> 1) % 3) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + 3 * 256
+            base = ((c >> 1) % nslot) * PSLOT + (c & 1) * W1C + ((kq ^ key) << 2) + li * 16 + 3 * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
     frag0 = [read1(w, 0) for w in range(NW)]
     for P in range(8):
-        issue_pair(P + 2)
+        if not big:
+            issue_pair(P + 2)
         frag1 = [read1(w, 2 * P + 1) for w in range(NW)]
         for w in range(NW):
             a, bs = frag0[w]
             for j, b in enumerate(bs):
                 mfma_group(hid_acc[(w, j)], a, b)
         land(P + 1)                                   # the wait + barrier: pair P+1 has landed
+        if big:
+            issue_pair(P + 2)                         # two slots: pair P's slot is refilled once every wave has read it
         if P + 1 < 8:
             frag0 = [read1(w, 2 * P + 2) for w in range(NW)]
         for w in range(NW):
             a, bs = frag1[w]
             for j, b in enumerate(bs):
                 mfma_group(hid_acc[(w, j)], a, b)
-    assert maps[0][0] == maps[1][0] and maps[2][0] == maps[3][0]            # owner and helper work on the same row tile
-    if not small:
+    assert small or big or (maps[0][0] == maps[1][0] and maps[2][0] == maps[3][0])            # owner and helper work on the same row tile
+    if not (small or big):
         hid_acc[(0, 3)] += hid_acc.pop((1, 3))
         hid_acc[(2, 3)] += hid_acc.pop((3, 3))
     # epilogue 1: gelu(acc + b1) -> Xs (swizzled), D layout: lane (li, kq), reg rr -> row kq*4+rr, col li
@@ -137,23 +145,24 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
                     row, col = r1 * 16 + rr, (c0 + j) * 16 + cc
                     Xs[row * D + (((col >> 2) ^ (row & 15)) << 2) + (col & 3)] = _gelu(t[rr, cc] + Bs[col])
     # ---- phase 2
-    nj2 = 2 if small else 4
+    nj2 = 2 if small else (8 if big else 4)
     out_acc = {(w, j): np.zeros((16, 16)) for w in range(NW) for j in range(nj2)}
 
     def read2(wave, q):
-        r2, nb = (0, wave * 2) if small else (wave & 1, (wave >> 1) * 4)
+        r2, nb = (0, wave * 2) if small else ((wave & 3, (wave >> 2) * 8) if big else (wave & 1, (wave >> 1) * 4))
         rows = r2 * 16 + li
         a = np.stack([Xs[rows * D + (((kq ^ li) ^ (4 * (q & 3))) << 2) + 64 * (q >> 2) + t] for t in range(4)], axis=1)
         bs = []
         for j in range(nj2):
-            base = ((NP1 + (q >> 1)) % 3) * PSLOT + (q & 1) * W2C + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
+            base = ((NP1 + (q >> 1)) % nslot) * PSLOT + (q & 1) * W2C + ((kq ^ key) << 2) + (nb * 16 + li) * 16 + j * 256
             bs.append(np.stack([ring[base + t] for t in range(4)], axis=1))
         return a, bs
     frag0 = [read2(w, 0) for w in range(NW)]
     for P in range(NP1, NPAIR):
         q = 2 * (P - NP1)
         two = q + 1 < nt
-        issue_pair(P + 2)
+        if not big:
+            issue_pair(P + 2)
         if two:
             frag1 = [read2(w, q + 1) for w in range(NW)]
         for w in range(NW):
@@ -161,6 +170,8 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
             for j, b in enumerate(bs):
                 mfma_group(out_acc[(w, j)], a, b)
         land(P + 1)
+        if big:
+            issue_pair(P + 2)
         if q + 2 < nt:
             frag0 = [read2(w, q + 2) for w in range(NW)]
         if two:
@@ -171,7 +182,7 @@ def emulate_workgroup(x2, pack, b1p, b2, mt, sl, late, bm=BM):
     assert not pending
     part = np.zeros((bm, D))
     for w in range(NW):
-        r2, nb = (0, w * 2) if small else (w & 1, (w >> 1) * 4)
+        r2, nb = (0, w * 2) if small else ((w & 3, (w >> 2) * 8) if big else (w & 1, (w >> 1) * 4))
         for j in range(nj2):
             part[r2 * 16:r2 * 16 + 16, (nb + j) * 16:(nb + j) * 16 + 16] = out_acc[(w, j)]
     rows = np.minimum(m0 + np.arange(bm), M - 1)

@@ -227,7 +227,7 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
     pack = pack_ffn(w1, w2)
     assert [s for s in ffn_slices()] == [(0, 208), (208, 208), (416, 208), (624, 208), (832, 208)] and pack.size == 5 * 106496
     ref = x2.astype(np.float64) + _gelu(x2.astype(np.float64) @ w1.T.astype(np.float64) + b1) @ w2.T.astype(np.float64) + b2
-    for bm in (32, 16):                                    # ffn_fused_kernel / ffn_fused16_kernel (three M tiles, the last ragged)
+    for bm in (32, 16, 64):                                # ffn_fused_kernel / ffn_fused16_kernel (three M tiles, the last ragged) / ffn_fused64_kernel (one ragged tile)
         for late in (False, True):
             parts = emulate_ffn(x2, pack, pad_ffn_bias(b1), b2, late, bm)
             err = np.abs(parts.sum(0) - ref).max()
@@ -311,24 +311,24 @@ def test_scan_order_is_a_consistent_relabelling():
 
 
 def test_feed_forward_tile_is_picked_from_the_batch_rows():
-    """MDM._pick_ffn_tile (host logic, no GPU): the fused feed-forward block has a 16-row and a 32-row kernel that agree to rounding only,
-    so the tile handed to the library (tune[IDF_TUNE_FFN]: 2 / 1) follows the rows of the WHOLE batch -- 16-row tiles up to
-    FFN16_MAX_ROWS, 32-row tiles above -- and an explicit ``ffn_rows`` wins (A/B runs)."""
+    """MDM._pick_ffn_tile (host logic, no GPU): the fused feed-forward block has 16-, 32- and 64-row kernels; the 32-row one agrees with
+    the others to rounding only, so the tile handed to the library (tune[IDF_TUNE_FFN]: 2 / 1 / 3) follows the rows of the WHOLE batch
+    -- the same rule as csrc/ffn.h ffn_tile_for_rows -- and an explicit ``ffn_rows`` wins (A/B runs)."""
     from types import SimpleNamespace
     from interdiff_amd import _lib
     from interdiff_amd.mdm import MDM
     k = _lib.TUNE['ffn']
-    m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, FFN16_MAX_ROWS=MDM.FFN16_MAX_ROWS)
-    assert MDM.FFN16_MAX_ROWS == 800                         # csrc/ffn.h FFN16_MAX_ROWS: 50 row tiles x 5 slices = 250 workgroups <= 256 CUs
-    for rows, want in ((1, 2), (800, 2), (801, 1), (1600, 1), (3200, 1)):
+    m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, ffn_tile_for_rows=MDM.ffn_tile_for_rows)
+    want = {1: 16, 800: 16, 801: 32, 1600: 32, 2400: 32, 3199: 32, 3200: 64, 3264: 64, 3265: 32, 4896: 32, 4897: 64, 6400: 64, 6529: 32, 12800: 64}
+    for rows, tile in want.items():
+        assert MDM.ffn_tile_for_rows(rows) == tile, (rows, MDM.ffn_tile_for_rows(rows))
         MDM._pick_ffn_tile(m, rows)
-        assert m.w.tune[k] == want, (rows, m.w.tune[k])
-    m.ffn_rows = 32
-    MDM._pick_ffn_tile(m, 100)
-    assert m.w.tune[k] == 1
-    m.ffn_rows = 16
-    MDM._pick_ffn_tile(m, 5000)
-    assert m.w.tune[k] == 2
+        assert m.w.tune[k] == {16: 2, 32: 1, 64: 3}[tile], (rows, m.w.tune[k])
+    for forced, code in ((32, 1), (16, 2), (64, 3)):
+        m.ffn_rows = forced
+        MDM._pick_ffn_tile(m, 100)
+        assert m.w.tune[k] == code
     assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched
     src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
-    assert 'constexpr int FFN16_MAX_ROWS = %d;' % MDM.FFN16_MAX_ROWS in src
+    assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d, FFN_CUS = 256;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src
+    assert 'return 325 * r64 < 177 * r32 ? 64 : 32;' in src                # the same weights as MDM.ffn_tile_for_rows

@@ -609,18 +609,19 @@ def test_gemm_f32_epilogues_vs_torch_fp32(lib):
         linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0
 
 
-@pytest.mark.parametrize('M', [1, 15, 17, 31, 33, 160, 800, 1600, 3200])
+@pytest.mark.parametrize('M', [1, 15, 17, 31, 33, 63, 65, 160, 800, 1600, 3200, 3265])
 def test_fused_ffn_vs_torch_fp64(mdm, M):
     """interdiff_mdm_ffn (csrc/ffn.h: linear1 -> gelu -> linear2 in one launch, five partial slabs summed by the reader) against
-    torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts, BOTH row
-    tiles (the 32-row kernel and the 16-row one small batches take) and the default pick between them."""
+    torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts, ALL THREE row
+    tiles (the 32-row kernel, the 16-row one small batches take, the 64-row one large batches take) and the default pick between them;
+    the 16- and 64-row kernels sum every tile in the same order and must agree bit for bit."""
     from interdiff_amd.mdm import ffn_parts
     g = torch.Generator().manual_seed(100 + M)
     x2 = torch.randn(M, 256, generator=g)
     sd = fx.mdm_weights()
     outs = {}
     try:
-        for rows in (32, 16, 0):
+        for rows in (32, 16, 64, 0):
             mdm.ffn_rows = rows
             for enc, layer, pre in ((False, 1, 'decoder.layers.1.'), (False, 7, 'decoder.layers.7.'), (True, 3, 'encoder.layers.3.')):
                 parts = ffn_parts(mdm, x2.to(DEV), layer, encoder=enc)
@@ -636,10 +637,13 @@ def test_fused_ffn_vs_torch_fp64(mdm, M):
             assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1)), 'deterministic: no atomics, fixed summation order'
             assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1, batch_rows=M)), 'batch_rows = M is the default'
         for pre in ('decoder.layers.1.', 'decoder.layers.7.', 'encoder.layers.3.'):                   # the default = the documented pick
-            assert torch.equal(outs[0, pre], outs[16 if M <= mdm.FFN16_MAX_ROWS else 32, pre])
+            assert torch.equal(outs[0, pre], outs[mdm.ffn_tile_for_rows(M), pre])
+            assert torch.equal(outs[16, pre], outs[64, pre]), '16- and 64-row kernels: same summation order'
         mdm.ffn_rows = 0                                       # a chain of a larger batch takes the BATCH's tile
+        assert mdm.ffn_tile_for_rows(4000) == 32 and mdm.ffn_tile_for_rows(6400) == 64
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=4000), outs[32, 'decoder.layers.1.'])
-        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=max(M, 600)), outs[16 if max(M, 600) <= 800 else 32, 'decoder.layers.1.'])
+        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=6400), outs[64, 'decoder.layers.1.'])
+        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=max(M, 600)), outs[mdm.ffn_tile_for_rows(max(M, 600)), 'decoder.layers.1.'])
     finally:
         mdm.ffn_rows = 0
 

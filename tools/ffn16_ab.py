@@ -1,4 +1,4 @@
-"""32-row vs 16-row fused feed-forward kernel (csrc/ffn.h) by token count, on one box in one process (not product code):
+"""32-row vs 16-row vs 64-row fused feed-forward kernel (csrc/ffn.h) by token count, on one box in one process (not product code):
 per-launch time from a layer-cycling hipGraph (bench.time_dominant_kernel's recipe) and the error of both against torch fp64."""
 import json
 import os
@@ -45,16 +45,17 @@ def main():
     dev = torch.device('cuda:0')
     model, corr, bt, y, _ = bench.build_world(dev, 0)
     out = {}
-    for N in (100, 320, 400, 800, 1200, 1600, 3200):
+    for N in (100, 800, 1200, 1600, 1700, 2400, 3200, 3300, 6400):
         row = {}
         res = {}
-        for name, v in (('rows32', 32), ('rows16', 16)):
+        for name, v in (('rows32', 32), ('rows16', 16), ('rows64', 64)):
             model.ffn_rows = v
             row[name + '_us'] = time_ffn(model, dev, N)
             g = torch.Generator().manual_seed(11)
             x2 = torch.randn(N, 256, generator=g).to(dev)
             res[name] = ffn_parts(model, x2, 3).sum(0).cpu()
         row['max_abs_diff_16_vs_32'] = float((res['rows16'] - res['rows32']).abs().max())
+        row['rows64_equals_rows16'] = bool(torch.equal(res['rows16'], res['rows64']))
         row['scale'] = float(res['rows32'].abs().max())
         out[N] = row
         print(N, json.dumps(row), flush=True)

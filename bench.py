@@ -106,7 +106,8 @@ def time_dominant_kernel(model, dev, reps=200, chains=1, cycle_layers=True, n_ro
     round-2 burst on layer 1 (secondary key).  Returns the MEAN of three bursts (and the best, for reference).
     chains = 2: the form the sampler's plain steps launch it in -- the batch's rows as two halves, each half a chain of
     launches on its own branch of the graph; the figure is then per PAIR of concurrent half-size launches (the same FLOP).
-    n_rows: another batch's token rows (<= 800: the 16-row tile kernel, csrc/ffn.h ffn_fused16_kernel) instead of the workload's."""
+    n_rows: another batch's token rows (<= 800: the 16-row tile kernel, csrc/ffn.h ffn_fused16_kernel; 3200: the 64-row one) instead of the
+    workload's."""
     from interdiff_amd.mdm import ffn_parts
     total = n_rows or B_PER_GPU * T
     N = total // chains
@@ -427,6 +428,7 @@ def main():
         burst_us, burst_best = time_dominant_kernel(model, dev, cycle_layers=False)
         pair_us, pair_best = time_dominant_kernel(model, dev, chains=2)
         small_us, small_best = time_dominant_kernel(model, dev, n_rows=800)
+        big_us, big_best = time_dominant_kernel(model, dev, n_rows=3200)
         fwd_us = time_forward_graph(model, bt, y, dev)
         log('kernel profile done')
     # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
@@ -500,6 +502,10 @@ def main():
                                                              frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                              note='ffn_fused16_kernel: the tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU): '
                                                                   '250 workgroups of 16 rows instead of 125 of 32; same layer-cycling burst as the headline figure'),
+                                large_batch_64_row_tile=dict(rows=3200, us_per_launch=big_us, us_per_launch_best=big_best,
+                                                             frac=flops * 3200 / (B_PER_GPU * T) / (big_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                             note='ffn_fused64_kernel: the tile BASELINE config #3 (32 clips of 100 frames) takes: 250 workgroups of 64 rows in one round '
+                                                                  'instead of 500 of 32 in two; same layer-cycling burst as the headline figure'),
                                 traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
                                 note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
                                      'of a denoiser forward; duration = mean of three bursts of 192 launches replayed from a hipGraph that walk through the '

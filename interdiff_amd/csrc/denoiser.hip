@@ -737,6 +737,10 @@ inline int pick(int tuned, int dflt) { return tuned ? tuned : dflt; }
 // the last GEMM with the sampler update in its epilogue (gemm.h E_HEADS_POST): LDS-DMA kernel configurations only
 template <int NP>
 void run_heads_post_np(int cfg, hipStream_t s, const Args &g) {
+    if (g.T & 3) {                                   // clip lengths that are not a multiple of 4: the per-row form of the update (one configuration)
+        launch_glds<32, 32, 2, 2, 2, 64, A_LN, E_HEADS_POST_RAGGED, 3, NP>(s, g);
+        return;
+    }
     switch (cfg) {
     case 1: launch_glds<32, 64, 2, 2, 1, 32, A_LN, E_HEADS_POST, 3, NP>(s, g); break;
     case 3: launch_glds<32, 64, 2, 2, 2, 64, A_LN, E_HEADS_POST, 3, NP>(s, g); break;

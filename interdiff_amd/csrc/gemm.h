@@ -20,7 +20,8 @@
 namespace idf_gemm {
 
 enum { A_PLAIN = 0, A_LN = 1, A_TOKT = 2 };
-enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4, E_HEADS_POST = 5 };
+enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4, E_HEADS_POST = 5, E_HEADS_POST_RAGGED = 6 };      // 6: E_HEADS_POST for T % 4 != 0 (per-row update)
+constexpr bool is_post(int epi) { return epi == E_HEADS_POST || epi == E_HEADS_POST_RAGGED; }
 
 struct Args {
     const float *A;
@@ -134,19 +135,18 @@ __device__ __forceinline__ float sel8(const float4 a, const float4 b, int k) {
 // its own flat index -- unaligned, possibly in the next clip -- and draws component (index & 3) of Philox group (index >> 2), exactly
 // what interdiff_posterior_step_dev gives that element: two groups cover four consecutive elements, a third call only for the rows
 // that cross into the next clip.
-template <int TM, int TN>
+template <int TM, int TN, bool ragged>
 __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN> &po, int rbase0, int col0) {
     const int64_t st = g.post_state[4];                 // {t, loop index} of THIS step, parked by sampler_prepare_step (philox.h)
     const uint64_t it = (uint64_t)g.post_state[5], seed = (uint64_t)g.post_state[2];
     const size_t elem0 = (size_t)g.post_state[6];       // position of x[0] inside the whole sample (a chain of a split batch draws the whole batch's noise)
     po.c1 = g.post_table[st * 4]; po.c2 = g.post_table[st * 4 + 1]; po.sigma = g.post_table[st * 4 + 2];
-    const bool ragged = (g.T & 3) != 0;                 // launch-uniform
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = min(col0 + j * 16, g.N - 1);
-            if (!ragged) {
+            if constexpr (!ragged) {
                 const int rbase = min(rbase0 + i * 16, g.M - 4);      // clamped: out-of-tile lanes load valid addresses and store nothing
                 const int b = rbase / g.T, t = rbase - b * g.T;
                 const size_t flat = ((size_t)b * g.N + col) * g.T + t;
@@ -182,10 +182,9 @@ __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN
             asm volatile("" : "+v"(po.e[i][j].x), "+v"(po.e[i][j].y), "+v"(po.e[i][j].z), "+v"(po.e[i][j].w));     // computed here, not sunk into the epilogue
         }
 }
-template <int TM, int TN>
+template <int TM, int TN, bool ragged>
 __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[TM][TN], const float (&bvs)[TN], const PostOperands<TM, TN> &po,
                                               int rbase0, int col0) {
-    const bool ragged = (g.T & 3) != 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -198,7 +197,7 @@ __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[
             const float4 gv = po.gv[i][j];
             pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
             const float4 out = posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]);
-            if (!ragged) {
+            if constexpr (!ragged) {
                 const int b = rbase / g.T, t = rbase - b * g.T;
                 idf_store16_wt(g.post_x + ((size_t)b * g.N + col) * g.T + t, out);      // the next step's embedding reads x from other XCDs
             } else {
@@ -563,9 +562,9 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
     if constexpr (EPI == E_RESID) {
         if (ks == 0) load_resid<TM, TN>(g, rres, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     }
-    PostOperands<EPI == E_HEADS_POST ? TM : 1, EPI == E_HEADS_POST ? TN : 1> po;
-    if constexpr (EPI == E_HEADS_POST) {
-        if (ks == 0) post_prefetch<TM, TN>(g, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+    PostOperands<is_post(EPI) ? TM : 1, is_post(EPI) ? TN : 1> po;
+    if constexpr (is_post(EPI)) {
+        if (ks == 0) post_prefetch<TM, TN, EPI == E_HEADS_POST_RAGGED>(g, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
     }
     if constexpr (APRO == A_LN) {
         const float4 gw = g.lnw ? ld4(g.lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -676,8 +675,8 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void gemm_glds_kernel(const Args g
         if constexpr (KS > 1) __syncthreads();                    // the split-K partials have been read
         epilogue_rows<BM, BN, TM, TN, EPI, NW * 64>(g, smem, acc, rres, bvs, ks == 0, wm * TM * 16, wn * TN * 16, kq, li, m0, n0, tid);
     } else {
-        if constexpr (EPI == E_HEADS_POST) {
-            if (ks == 0) epilogue_post<TM, TN>(g, acc, bvs, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
+        if constexpr (is_post(EPI)) {
+            if (ks == 0) epilogue_post<TM, TN, EPI == E_HEADS_POST_RAGGED>(g, acc, bvs, po, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
         } else {
             if (ks == 0) epilogue<TM, TN, EPI>(g, acc, rres, bvs, m0 + wm * TM * 16 + kq * 4, n0 + wn * TN * 16 + li);
         }

@@ -155,15 +155,17 @@ class GaussianDiffusion:
         # Chains: at <= 16 clips every kernel of a step is one partial wave of workgroups bounded by latency (operand round trips,
         # kernel boundaries), so the two halves of the batch, stepped as independent kernel chains on two branches of the SAME captured
         # graph, overlap each other's dead time.  Clips never interact in a plain step, the noise of a chain is drawn at the whole
-        # batch's counters (state[6]), so the result is bit-identical to the single chain.  Hook steps stay whole-batch.
+        # batch's counters (state[6]), so the result is bit-identical to the single chain.  Hook steps stay whole-batch.  An odd batch
+        # splits into parts that differ by one clip (more than two chains measured slower: 0.296 / 0.309 vs 0.281 ms per step with 3 / 4 at B = 16).
         nch = N_CHAINS
-        split = (fused and self.split_chains and nch > 1 and B % nch == 0 and 2 * nch <= B <= SPLIT_MAX_BATCH
+        split = (fused and self.split_chains and nch > 1 and 2 * nch <= B <= SPLIT_MAX_BATCH
                  and B * img.shape[-1] > (getattr(model, 'FFN16_MAX_ROWS', 0) if self.split_min_rows is None else self.split_min_rows))      # smaller batches: launch-latency bound either way, and the feed-forward's 16-row grid already spans the chip (tools/small_batch_ab.py: equal at B = 8, one chain 7 % faster at B = 4)
         if split and not hasattr(st, 'chains'):
-            h = B // nch
             st.chains = []
             for c in range(nch):
-                sl = slice(c * h, (c + 1) * h)
+                start = c * (B // nch) + min(c, B % nch)            # balanced contiguous parts (sizes differ by at most one clip)
+                h = B // nch + (1 if c < B % nch else 0)
+                sl = slice(start, start + h)
                 st.chains.append(SimpleNamespace(
                     sl=sl, x=st.x[sl], ts=st.ts[sl], gt=st.gt[sl] if has_mask else None, mask=st.mask[sl] if has_mask else None,
                     state=st.state if c == 0 else torch.zeros(8, dtype=torch.int64, device=dev),
@@ -204,11 +206,11 @@ class GaussianDiffusion:
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, 0, 0], dtype=torch.int64))
         gate = getattr(denoised_fn, 'is_active', None)
         active = lambda i: denoised_fn is not None and (gate is None or gate(i))
-        if split and self.stagger_steps > 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs'):
+        if split and self.stagger_steps > 0 and B % nch == 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs'):
             return self._staggered_chains(model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask)
         if split:                                   # the other chains' states: the same schedule position, their x starts c chain-sizes in
             for c, ch in enumerate(st.chains[1:], 1):
-                ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))
+                ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, ch.sl.start * (st.x.numel() // B), 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         dump, it, i, end = [], 0, t_start, t_start - todo

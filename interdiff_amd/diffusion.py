@@ -40,7 +40,7 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=
 
 
 GRAPH_BLOCKS = (49, 7, 1)          # plain steps per captured hipGraph (49 = the gap between two correction steps)
-SPLIT_MAX_BATCH = int(os.environ.get('INTERDIFF_SPLIT_MAX_BATCH', 32))      # plain steps of a batch of up to this many clips run as N_CHAINS independent chains (see _graph_loop)
+SPLIT_MAX_BATCH = int(os.environ.get('INTERDIFF_SPLIT_MAX_BATCH', 128))     # plain steps of a batch of up to this many clips run as N_CHAINS independent chains (see _graph_loop); measured up to 128 (two chains 6 - 15 % faster than one at 40 .. 128 clips, tools/small_batch_ab.py)
 N_CHAINS = int(os.environ.get('INTERDIFF_CHAINS', 2))
 STAGGER_STEPS = int(os.environ.get('INTERDIFF_STAGGER', 0))      # > 0: the chains step through the whole loop on their own streams, chain c this many plain steps behind chain c - 1, the hook called per half batch (measured 5 % SLOWER at B = 16, equal at B = 32, tools/stagger_ab.py: not the default); 0: chains forked / joined inside every graph block, whole-batch hook steps
 MAX_GRAPH_SHAPES = 8               # captured (shape, mask, cond) entries kept per denoiser before the cache is dropped wholesale

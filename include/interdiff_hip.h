@@ -148,7 +148,7 @@ typedef struct {
     /* tile-configuration overrides for A/B measurements (tools/kbench.py), indexed by IDF_TUNE_*; all zero = the shipped
      * configuration.  A field of the handle, not process state: two models in one process never see each other's overrides.
      * One entry is NOT only for A/B runs -- tune[IDF_TUNE_FFN], the row tile of the fused feed-forward block: 0 = by the rows of
-     * the launch (16-row tiles up to 800 rows, 64-row tiles from 3200 rows on where they save a round of workgroups, 32-row tiles
+     * the launch (16-row tiles up to 800 rows, 64-row tiles from 2800 rows on, 32-row tiles
      * otherwise: csrc/ffn.h ffn_tile_for_rows), 1 = 32-row tiles, 2 = 16-row tiles, 3 = 64-row tiles.  The 32-row kernel agrees with
      * the other two to rounding (7e-7 of the output scale), not bit for bit: a caller that steps ONE batch as several calls on row subsets (the
      * sampler's half-batch chains) sets 1 or 2 from the rows of the whole batch so that every call takes the same kernel

@@ -851,17 +851,13 @@ inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, co
 // column tile (32 vs 16 / 64), so a caller that splits a batch into chains must pass the choice made for the WHOLE batch
 // (idf_mdm_weights.tune[IDF_TUNE_FFN]: 0 auto, 1 = 32, 2 = 16, 3 = 64; interdiff_amd/mdm.py sets it from the batch it is handed).
 //   <= 800 rows: 16-row tiles (their grid still fits the chip in one round).
-//   >= 3200 rows: whichever of 32 / 64 takes less time by rounds of workgroups -- a 64-row workgroup costs 32.5 us, a 32-row one 17.7
-//   (tools/ffn16_ab.py): 3200 rows = 250 x 64-row workgroups in one round (34.4 us) instead of 500 x 32-row in two (37.5); 3300 rows = 260
-//   workgroups in two rounds (62 us) against 520 in three (51); 6400 rows 67 against 71.
+//   >= 2800 rows: 64-row tiles.  3200 rows = 250 x 64-row workgroups in one round (34.4 us) instead of 500 x 32-row in two (37.5); inside
+//   the sampler, where such a batch steps as two chains whose launches interleave, the 64-row tile is ahead at every size measured
+//   (30 / 32 / 40 / 48 / 64 / 96 clips of 100 frames: 2 / 2.6 / 3.6 / 4 / 8 / 1.5 % of a step, equal at 28, profiles/r03_batch_scaling.txt).  A lone launch just
+//   past a multiple of 3264 rows is the exception (3300 rows: 260 workgroups in two rounds, 62 us, against 520 in three, 51): accepted.
 //   in between: 32-row tiles (a batch of 24 clips steps as two chains of 1200 rows whose 32-row launches overlap: 0.356 vs 0.407 ms/step).
-constexpr int FFN16_MAX_ROWS = 800, FFN64_MIN_ROWS = 3200, FFN_CUS = 256;
-inline int ffn_tile_for_rows(int rows) {
-    if (rows <= FFN16_MAX_ROWS) return 16;
-    if (rows < FFN64_MIN_ROWS) return 32;
-    const int r32 = idf_cdiv(idf_cdiv(rows, 32) * NSL, FFN_CUS), r64 = idf_cdiv(idf_cdiv(rows, 64) * NSL, FFN_CUS);
-    return 325 * r64 < 177 * r32 ? 64 : 32;
-}
+constexpr int FFN16_MAX_ROWS = 800, FFN64_MIN_ROWS = 2800;
+inline int ffn_tile_for_rows(int rows) { return rows <= FFN16_MAX_ROWS ? 16 : (rows < FFN64_MIN_ROWS ? 32 : 64); }
 inline int ffn_rows_of_tune(int t) { return t == 1 ? 32 : (t == 2 ? 16 : (t == 3 ? 64 : 0)); }
 inline void launch_ffn(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows = 0) {
     if (rows == 0) rows = ffn_tile_for_rows(M);

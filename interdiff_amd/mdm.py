@@ -371,18 +371,13 @@ class MDM:
                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_encode')
         return cond, gt
 
-    FFN16_MAX_ROWS, FFN64_MIN_ROWS = 800, 3200      # csrc/ffn.h
+    FFN16_MAX_ROWS, FFN64_MIN_ROWS = 800, 2800      # csrc/ffn.h
 
     @classmethod
     def ffn_tile_for_rows(cls, rows):
         """csrc/ffn.h ffn_tile_for_rows, for the rows of a whole batch: 16-row tiles while their grid fits the chip in one round of
-        workgroups (<= 800 rows), from 3200 rows on whichever of 32 / 64 takes fewer (weighted) rounds, 32 in between."""
-        if rows <= cls.FFN16_MAX_ROWS:
-            return 16
-        if rows < cls.FFN64_MIN_ROWS:
-            return 32
-        rounds = lambda tile: -(-(-(-rows // tile) * _lib.FFN_SLICES) // 256)
-        return 64 if 325 * rounds(64) < 177 * rounds(32) else 32
+        workgroups (<= 800 rows), 64-row tiles from 2800 rows on, 32 in between."""
+        return 16 if rows <= cls.FFN16_MAX_ROWS else (32 if rows < cls.FFN64_MIN_ROWS else 64)
 
     def _pick_ffn_tile(self, rows):
         """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to

@@ -319,7 +319,7 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
     from interdiff_amd.mdm import MDM
     k = _lib.TUNE['ffn']
     m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, ffn_tile_for_rows=MDM.ffn_tile_for_rows)
-    want = {1: 16, 800: 16, 801: 32, 1600: 32, 2400: 32, 3199: 32, 3200: 64, 3264: 64, 3265: 32, 4896: 32, 4897: 64, 6400: 64, 6529: 32, 12800: 64}
+    want = {1: 16, 800: 16, 801: 32, 1600: 32, 2400: 32, 2799: 32, 2800: 64, 3200: 64, 3264: 64, 3265: 64, 4800: 64, 6400: 64, 12800: 64}
     for rows, tile in want.items():
         assert MDM.ffn_tile_for_rows(rows) == tile, (rows, MDM.ffn_tile_for_rows(rows))
         MDM._pick_ffn_tile(m, rows)
@@ -330,5 +330,4 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
         assert m.w.tune[k] == code
     assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched
     src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
-    assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d, FFN_CUS = 256;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src
-    assert 'return 325 * r64 < 177 * r32 ? 64 : 32;' in src                # the same weights as MDM.ffn_tile_for_rows
+    assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src

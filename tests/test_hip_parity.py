@@ -640,8 +640,8 @@ def test_fused_ffn_vs_torch_fp64(mdm, M):
             assert torch.equal(outs[0, pre], outs[mdm.ffn_tile_for_rows(M), pre])
             assert torch.equal(outs[16, pre], outs[64, pre]), '16- and 64-row kernels: same summation order'
         mdm.ffn_rows = 0                                       # a chain of a larger batch takes the BATCH's tile
-        assert mdm.ffn_tile_for_rows(4000) == 32 and mdm.ffn_tile_for_rows(6400) == 64
-        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=4000), outs[32, 'decoder.layers.1.'])
+        assert mdm.ffn_tile_for_rows(2700) == 32 and mdm.ffn_tile_for_rows(6400) == 64
+        assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=2700), outs[32, 'decoder.layers.1.'])
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=6400), outs[64, 'decoder.layers.1.'])
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=max(M, 600)), outs[mdm.ffn_tile_for_rows(max(M, 600)), 'decoder.layers.1.'])
     finally:

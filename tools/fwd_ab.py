@@ -1,5 +1,6 @@
-"""Same-process A/B of denoiser-forward variants on one MI355X (not product code): idf_mdm_weights.tune[IDF_TUNE_MISC] switches
-(bit 0 = no L2 warm-up of the FFN weight stream from the row block, bit 1 = no static wave priority in the fused FFN), each timed as
+"""Same-process A/B of denoiser-forward variants on one MI355X (not product code): idf_mdm_weights.tune[<slot>] switches of whatever
+experiment is compiled in (round 3 used the reserved IDF_TUNE_MISC slot for the L2 warm-ups, the static wave priority and the side-stream
+prefetch -- all measured, none kept: the shipped library reads no bit of it), each setting timed as
 (a) one forward replayed from a hipGraph and (b) whole 1000-step samples without correction (the sampler's two-chain graphs), in
 alternation.  Box-to-box spread is several per cent: only same-call ratios mean anything.
     python tools/fwd_ab.py [--settings 3,0,2,1] [--reps 3] [--B 16]"""

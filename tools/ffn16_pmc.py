@@ -1,5 +1,6 @@
-"""A short driver for counter passes on the 16-row feed-forward kernel (not product code): 60 launches of interdiff_mdm_ffn at 800 rows,
-walking through the eight layers like a denoiser step.    tools/gpu_pmc.sh <tag> "<counters>" python tools/ffn16_pmc.py"""
+"""A short driver for counter passes on the 16- / 64-row feed-forward kernels (not product code): 60 launches of interdiff_mdm_ffn at 800
+(or argv[1]: 3200 -> the 64-row kernel) rows, walking through the eight layers like a denoiser step.
+    tools/gpu_pmc.sh <tag> "<counters>" python tools/ffn16_pmc.py [rows]"""
 import os
 import sys
 

@@ -62,7 +62,60 @@ def by_position(path, marker):
     print('    sum of kernels %.1f us + gaps %.1f us = %.1f us from the start of the first launch to the end of the last' % (tk, tg, span))
 
 
+def hook_intervals(path, marker):
+    """Third table: every correction call (a launch of corr_prepare_kernel) with the launches around it -- from the end of the last
+    plain-step launch before it to the start of the first plain-step launch after its posterior update: how much of that interval the
+    GPU spends in kernels and how much idle (graph replay boundaries, eager launches)."""
+    con = sqlite3.connect(path)
+    rows = [(short(n), s, e) for n, s, e in con.execute("select name, start, end from kernels order by start").fetchall()]
+    hooks = [i for i, r in enumerate(rows) if r[0].startswith('corr_prepare_kernel')]
+    out, gaps = [], []
+    for h in hooks:
+        a = h
+        while a > 0 and marker not in rows[a][0]:            # back to the start of the hook step's own forward
+            a -= 1
+        b = h
+        while b < len(rows) and not rows[b][0].startswith('posterior'):
+            b += 1
+        if a <= 0 or b + 1 >= len(rows) or b - a > 40:       # (a correction call outside a sampling loop, e.g. a warm-up: no forward before it)
+            continue
+        t0, t1 = rows[a - 1][2], rows[b + 1][1]              # end of the previous plain step's last launch .. start of the next step's first
+        busy = sum(e - s for _, s, e in rows[a:b + 1])
+        out.append(((t1 - t0) / 1e3, busy / 1e3, b + 1 - a))
+        gaps.append([(rows[i][0], (rows[i][1] - rows[i - 1][2]) / 1e3) for i in range(a, b + 2)])
+    if not out:
+        return
+    print()
+    print('correction steps (%d found): interval from the end of the previous plain step to the start of the next one' % len(out))
+    print('    mean interval %.1f us, of which kernels %.1f us (%d launches), idle %.1f us' % (
+        sum(o[0] for o in out) / len(out), sum(o[1] for o in out) / len(out), round(sum(o[2] for o in out) / len(out)),
+        sum(o[0] - o[1] for o in out) / len(out)))
+    n = min(len(g) for g in gaps)
+    big = [(i, sum(g[i][1] for g in gaps) / len(gaps)) for i in range(n)]
+    print('    idle before a launch (mean us, positions with >= 5 us): ' + ', '.join('%s %.0f' % (gaps[0][i][0][:24], v) for i, v in big if v >= 5))
+
+
+def big_gaps(path, thresh_us=40.0):
+    """Fourth table: idle gaps of the whole trace above a threshold, grouped by (launch before -> launch after): graph-replay boundaries and
+    host-bound stretches show up here."""
+    con = sqlite3.connect(path)
+    rows = [(short(n), s, e) for n, s, e in con.execute("select name, start, end from kernels order by start").fetchall()]
+    agg, end = {}, rows[0][2]
+    for i in range(1, len(rows)):
+        g = (rows[i][1] - end) / 1e3
+        if g >= thresh_us:
+            a = agg.setdefault((rows[i - 1][0][:34], rows[i][0][:34]), [0, 0.0])
+            a[0] += 1; a[1] += g
+        end = max(end, rows[i][2])
+    print()
+    print('idle gaps >= %.0f us (GPU has no kernel running), by the launches around them:' % thresh_us)
+    for (a, b), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        print('    %5d x mean %8.1f us   %s -> %s' % (n, t / n, a, b))
+
+
 if __name__ == '__main__':
     main(sys.argv[1])
     if len(sys.argv) > 2:
         by_position(sys.argv[1], sys.argv[2])
+        hook_intervals(sys.argv[1], sys.argv[2])
+        big_gaps(sys.argv[1])

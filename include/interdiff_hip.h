@@ -228,6 +228,15 @@ int interdiff_posterior_step(float *x, const float *x0, const float *noise, int6
                              float c1, float c2, float sigma, uint64_t seed, uint64_t step_index,
                              void *stream);
 int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream);
+/* The same two with an element offset: `elem0` (a multiple of 4, else IDF_E_INVAL) is the position of x[0] / out[0] inside the
+ * tensor whose noise stream is being drawn.  The reference fills ONE randn_like tensor for the whole batch
+ * (gaussian_diffusion.py:532); a rank that holds clips [first, first + B_local) of that batch passes
+ * elem0 = first * C * T and draws exactly the elements the unsharded run would ("sliced from one global
+ * tensor for parity with a 1-GPU run") -- sharded == unsharded bit for bit.  The un-suffixed entries are elem0 = 0. */
+int interdiff_posterior_step_at(float *x, const float *x0, const float *noise, int64_t n,
+                                float c1, float c2, float sigma, uint64_t seed, uint64_t step_index,
+                                uint64_t elem0, void *stream);
+int interdiff_randn_at(float *out, int64_t n, uint64_t seed, uint64_t step_index, uint64_t elem0, void *stream);
 /* Graph-replayable form of the same update: all per-step scalars live in HBM, so one captured hipGraph of
  * [interdiff_mdm_forward -> interdiff_posterior_step_dev -> interdiff_sampler_advance] serves every plain step.
  *   state int64[4] = {t (current timestep), loop index (noise counter), seed, arrival counter (zero it once)};

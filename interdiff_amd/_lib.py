@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -102,6 +102,8 @@ _SIGS = {
     'interdiff_inpaint': (C.c_int, [vp, vp, vp, i64, vp]),
     'interdiff_posterior_step': (C.c_int, [vp, vp, vp, i64, f32, f32, f32, u64, u64, vp]),
     'interdiff_randn': (C.c_int, [vp, i64, u64, u64, vp]),
+    'interdiff_posterior_step_at': (C.c_int, [vp, vp, vp, i64, f32, f32, f32, u64, u64, u64, vp]),
+    'interdiff_randn_at': (C.c_int, [vp, i64, u64, u64, u64, vp]),
     'interdiff_posterior_step_dev': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
     'interdiff_sampler_advance': (C.c_int, [vp, vp, i32, vp]),
     'interdiff_objprojector_sample': (C.c_int, [C.POINTER(ObjProj), vp, vp, vp, vp, i32, vp, vp]),

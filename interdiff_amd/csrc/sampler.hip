@@ -20,12 +20,12 @@ __global__ __launch_bounds__(256) void inpaint_kernel(float *__restrict__ x0, co
 template <bool GEN>
 __global__ __launch_bounds__(256) void posterior_kernel(float *__restrict__ x, const float *__restrict__ x0,
                                                         const float *__restrict__ noise, int64_t n, float c1, float c2,
-                                                        float sigma, uint64_t seed, uint64_t step) {
+                                                        float sigma, uint64_t seed, uint64_t step, uint64_t g0) {
     const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
         const int64_t i = g * 4;
         float4 e;
-        if constexpr (GEN) e = randn4(seed, step, (uint64_t)g);
+        if constexpr (GEN) e = randn4(seed, step, g0 + (uint64_t)g);
         if (i + 3 < n) {
             float4 xv = *reinterpret_cast<float4 *>(x + i);
             const float4 pv = *reinterpret_cast<const float4 *>(x0 + i);
@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void posterior_kernel(float *__restrict__ x, c
     }
 }
 
-__global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int64_t n, uint64_t seed, uint64_t step) {
+__global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, int64_t n, uint64_t seed, uint64_t step, uint64_t g0) {
     const int64_t n4 = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
-        const float4 e = randn4(seed, step, (uint64_t)g);
+        const float4 e = randn4(seed, step, g0 + (uint64_t)g);
         const float ev[4] = {e.x, e.y, e.z, e.w};
         for (int k = 0; k < 4 && g * 4 + k < n; ++k) out[g * 4 + k] = ev[k];
     }
@@ -108,9 +108,11 @@ extern "C" int interdiff_inpaint(float *x0, const float *gt, const uint8_t *mask
     return IDF_OK;
 }
 
-extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *noise, int64_t n, float c1, float c2,
-                                        float sigma, uint64_t seed, uint64_t step_index, void *stream) {
-    if (!x || !x0 || n < 0) return IDF_E_INVAL;
+// elem0 (a multiple of 4) = position of x[0] inside the tensor whose noise stream is drawn: a shard of a batch (one rank's clips, one
+// chain of a split batch) draws the WHOLE batch's noise at its own elements, so a sharded run equals the unsharded one bit for bit
+extern "C" int interdiff_posterior_step_at(float *x, const float *x0, const float *noise, int64_t n, float c1, float c2,
+                                           float sigma, uint64_t seed, uint64_t step_index, uint64_t elem0, void *stream) {
+    if (!x || !x0 || n < 0 || (elem0 & 3)) return IDF_E_INVAL;
     if (n == 0) return IDF_OK;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(noise)) & 15)
         return IDF_E_INVAL;
@@ -118,18 +120,23 @@ extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *
     idf_prof_mark(IDF_K_POSTERIOR, idf_stream(stream));
     if (noise)
         hipLaunchKernelGGL((posterior_kernel<false>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2,
-                           sigma, seed, step_index);
+                           sigma, seed, step_index, elem0 >> 2);
     else
         hipLaunchKernelGGL((posterior_kernel<true>), dim3(g), dim3(256), 0, idf_stream(stream), x, x0, noise, n, c1, c2, sigma,
-                           seed, step_index);
+                           seed, step_index, elem0 >> 2);
     idf_prof_mark(-1, idf_stream(stream));
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
 
+extern "C" int interdiff_posterior_step(float *x, const float *x0, const float *noise, int64_t n, float c1, float c2,
+                                        float sigma, uint64_t seed, uint64_t step_index, void *stream) {
+    return interdiff_posterior_step_at(x, x0, noise, n, c1, c2, sigma, seed, step_index, 0, stream);
+}
+
 extern "C" int interdiff_posterior_step_dev(float *x, const float *x0, const float *gt, const uint8_t *mask, int64_t n,
                                             const float *table, int64_t *state, int64_t *ts, int32_t B, void *stream) {
-    if (!x || !x0 || !table || !state || n < 0 || (mask && !gt) || (ts && B <= 0)) return IDF_E_INVAL;
+    if (!x || !x0 || !table || !state || n < 0 || (mask && !gt) || (ts && B <= 0)) return IDF_E_INVAL;   // (state[6] & 3 cannot be checked here without a sync: the host mirror asserts it)
     if (n == 0) return IDF_OK;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(gt)) & 15) return IDF_E_INVAL;
     if (reinterpret_cast<uintptr_t>(mask) & 3) return IDF_E_INVAL;
@@ -148,15 +155,19 @@ extern "C" int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B,
     return IDF_OK;
 }
 
-extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream) {
-    if (!out || n < 0) return IDF_E_INVAL;
+extern "C" int interdiff_randn_at(float *out, int64_t n, uint64_t seed, uint64_t step_index, uint64_t elem0, void *stream) {
+    if (!out || n < 0 || (elem0 & 3)) return IDF_E_INVAL;
     if (n == 0) return IDF_OK;
-    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, idf_stream(stream), out, n, seed, step_index);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, idf_stream(stream), out, n, seed, step_index, elem0 >> 2);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
 
-#define IDF_ABI_VERSION 9
+extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t step_index, void *stream) {
+    return interdiff_randn_at(out, n, seed, step_index, 0, stream);
+}
+
+#define IDF_ABI_VERSION 10
 #define IDF_STR_(x) #x
 #define IDF_STR(x) IDF_STR_(x)
 extern "C" int interdiff_abi_version(void) { return IDF_ABI_VERSION; }

@@ -15,6 +15,11 @@ Host-side design (not a translation of the reference loop):
     advance] is captured ONCE into a hipGraph whose per-step scalars (c1, c2, sigma, t, loop index, seed) live in
     HBM, and replayed for every step on which the correction hook is inactive (989 of 1000); hook steps run
     eagerly between replays.  The two routes are bit-identical (tests/test_hip_parity.py).
+Sharding: ``shard=(first_clip, total_clips)`` says that the batch handed in is clips [first, first + B) of a
+larger batch that other ranks (or other calls) hold the rest of.  The in-kernel noise is then drawn at the WHOLE batch's Philox
+counters (element offset first * C * T: the reference fills one ``randn_like`` tensor for the whole batch, :532) and the
+feed-forward tile is picked from the whole batch's token rows, so the shard's result is bit-identical to the same clips of an
+unsharded run -- whatever the route (eager, graph, chains).
 Only the configuration the eval path uses is implemented (ModelMeanType.START_X, ModelVarType.FIXED_SMALL,
 clip_denoised=False, identity timestep map); anything else raises NotImplementedError.
 """
@@ -98,10 +103,14 @@ class GaussianDiffusion:
             self._tables[key] = torch.from_numpy(np.stack([self._c1, self._c2, sig, blend], axis=1).astype(np.float32)).contiguous().to(device)
         return self._tables[key]
 
-    def _graph_loop(self, model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_start):
+    def _graph_loop(self, model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_start, shard=None):
         lib = _lib.load()
         y = model_kwargs.get('y', {})
         B, dev = img.shape[0], img.device
+        first, total = (0, B) if shard is None else shard
+        per_clip = img.numel() // B
+        elem0 = first * per_clip                    # position of this batch's x[0] inside the whole (possibly sharded) batch: the Philox counter base
+        rows = total * img.shape[-1]                # the WHOLE batch's token rows: what every launch's feed-forward tile is picked by (MDM._pick_ffn_tile)
         table = self._table(dev)
         has_mask = 'inpainting_mask' in y and 'inpainted_motion' in y
         mu8 = gc = None
@@ -116,7 +125,7 @@ class GaussianDiffusion:
         # The cache lives ON the denoiser object: the captured graphs bake in the addresses of its arena, workspace and memory
         # context, so they must die with it (a cache keyed by id(model) would replay freed memory once the id is recycled).
         cache = model.__dict__.setdefault('_graph_cache', {})
-        key = (self._uid, tuple(img.shape), has_mask, tuple(cond.shape))
+        key = (self._uid, tuple(img.shape), has_mask, tuple(cond.shape), model.ffn_class_for_rows(rows) if hasattr(model, 'ffn_class_for_rows') else 0)    # the captured launches bake the tile class in
         st = cache.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),
@@ -137,13 +146,14 @@ class GaussianDiffusion:
             st.gt.copy_(gc)
             st.mask.copy_(mu8)
         model.prepare_memory(st.cond)                   # once per sample, on the current stream (inside the caller's clock)
+        rows_kw = {'batch_rows': rows} if getattr(model, 'accepts_batch_rows', False) else {}
         if fresh:
-            model(st.x, st.ts, out=st.x0, **st.kwargs)               # warm-up: workspaces, kernel attributes
+            model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)               # warm-up: workspaces, kernel attributes
             if getattr(model, 'supports_forward_step', False):
                 # ... and the fused step's own instantiations (last GEMM with the update in its epilogue, QKV kernel with the sampler
                 # bookkeeping): their FIRST launch must not happen inside a capture, where a launch error cannot be reported
                 scratch = SimpleNamespace(x=st.x.clone(), ts=st.ts.clone(), state=torch.tensor([1, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev))
-                model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, **st.kwargs)
+                model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
             torch.cuda.synchronize(dev)
 
         def posterior(x, x0, g, mk, st):
@@ -177,8 +187,6 @@ class GaussianDiffusion:
                 ch.cond.copy_(st.cond[:, ch.sl])
                 model.prepare_memory(ch.cond, into=ch.memctx)
 
-        rows = B * img.shape[-1]                    # the whole batch's token rows: what every chain's feed-forward tile is picked by (MDM._pick_ffn_tile)
-
         def graph_of(k):
             """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
             if (k, fused, split) not in st.graphs:
@@ -196,21 +204,23 @@ class GaussianDiffusion:
                     else:
                         for _ in range(k):
                             if fused:               # the update runs in the epilogue of the denoiser's last GEMM (same bits)
-                                model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs)
+                                model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
                             else:
-                                model(st.x, st.ts, out=st.x0, **st.kwargs)
+                                model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
                                 posterior(st.x, st.x0, st.gt, st.mask, st)
                 st.graphs[(k, fused, split)] = g
             return st.graphs[(k, fused, split)]
         st.x.copy_(img)
-        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, 0, 0], dtype=torch.int64))
+        if elem0 % 4 or per_clip % 4:
+            raise ValueError('a shard must start at a multiple of 4 elements (C * T = %d per clip)' % per_clip)
+        st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, elem0, 0], dtype=torch.int64))
         gate = getattr(denoised_fn, 'is_active', None)
         active = lambda i: denoised_fn is not None and (gate is None or gate(i))
         if split and self.stagger_steps > 0 and B % nch == 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs'):
-            return self._staggered_chains(model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask)
+            return self._staggered_chains(model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask, rows, elem0)
         if split:                                   # the other chains' states: the same schedule position, their x starts c chain-sizes in
             for c, ch in enumerate(st.chains[1:], 1):
-                ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, ch.sl.start * (st.x.numel() // B), 0], dtype=torch.int64))
+                ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, elem0 + ch.sl.start * per_clip, 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         dump, it, i, end = [], 0, t_start, t_start - todo
@@ -221,7 +231,7 @@ class GaussianDiffusion:
                 if 'fwd' not in st.graphs:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        model(st.x, st.ts, out=st.x0, **st.kwargs)
+                        model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
                     st.graphs['fwd'] = g
                 st.graphs['fwd'].replay()
                 x0 = st.x0
@@ -249,7 +259,7 @@ class GaussianDiffusion:
                 dump.append(st.x.clone())
         return dump if dump_steps is not None else st.x.clone()
 
-    def _staggered_chains(self, model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask):
+    def _staggered_chains(self, model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask, rows, elem0):
         """The two-chain form taken to the whole loop: every half batch is stepped from the first to the last timestep on its OWN stream --
         plain steps as captured per-chain graphs, hook steps eagerly on the half batch (``denoised_fn.slice_kwargs``: every operand of
         the hook is per clip, eval_smpl_short.py:88-106) -- and chain c starts c x ``stagger_steps`` plain steps after chain 0.  The
@@ -259,7 +269,6 @@ class GaussianDiffusion:
         lib = _lib.load()
         dev, B = st.x.device, st.x.shape[0]
         chains, h = st.chains, st.x.shape[0] // len(st.chains)
-        rows = st.x.shape[0] * st.x.shape[-1]
         end = t_start - todo
         # ---- the schedule, the same for every chain: plain runs in captured block sizes, hook steps, dump points
         prog, i, it = [], t_start, 0
@@ -302,7 +311,7 @@ class GaussianDiffusion:
                     model(ch.x, ch.ts, out=ch.x0, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
                 ch.graphs['fwd'] = g
         for c, ch in enumerate(chains):
-            ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, c * ch.x.numel(), 0], dtype=torch.int64))
+            ch.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, elem0 + c * ch.x.numel(), 0], dtype=torch.int64))
         st.ts.fill_(t_start)
         ts_all = self._timesteps(B, dev)
         kw = [denoised_fn.slice_kwargs(model_kwargs, ch.sl) for ch in chains] if need_fwd else None
@@ -347,10 +356,10 @@ class GaussianDiffusion:
             ch.lag_event = None
         return dumps if dump_steps is not None else st.x.clone()
 
-    def _step(self, model, img, x0_buf, i, it, t, model_kwargs, denoised_fn, noise_i, seed):
+    def _step(self, model, img, x0_buf, i, it, t, model_kwargs, denoised_fn, noise_i, seed, elem0=0, rows_kw={}):
         lib = _lib.load()
         y = model_kwargs.get('y', {})
-        x0 = model(img, t, **model_kwargs)
+        x0 = model(img, t, **model_kwargs, **rows_kw)
         if 'inpainting_mask' in y and 'inpainted_motion' in y:
             m, g = y['inpainting_mask'], y['inpainted_motion']
             assert x0.shape == m.shape == g.shape
@@ -360,9 +369,9 @@ class GaussianDiffusion:
         if denoised_fn is not None:
             x0 = denoised_fn(x0, t, model_kwargs)
         sigma = 0.0 if i == 0 else float(self._sigma[i])
-        _lib.check(lib.interdiff_posterior_step(_lib.dptr(img, torch.float32), _lib.dptr(x0, torch.float32),
-                                                _lib.dptr(noise_i, torch.float32, allow_none=True), img.numel(),
-                                                float(self._c1[i]), float(self._c2[i]), sigma, seed, it, _lib.stream()),
+        _lib.check(lib.interdiff_posterior_step_at(_lib.dptr(img, torch.float32), _lib.dptr(x0, torch.float32),
+                                                   _lib.dptr(noise_i, torch.float32, allow_none=True), img.numel(),
+                                                   float(self._c1[i]), float(self._c2[i]), sigma, seed, it, elem0, _lib.stream()),
                    'posterior_step')
         return x0
 
@@ -370,13 +379,15 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
                       cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None, seed=None, n_steps=None,
-                      use_graph=True, first_t=None):
+                      use_graph=True, first_t=None, shard=None):
         """Same keyword surface as the reference (:598-614).  Extra: ``step_noise`` (tensor [n,...] or callable
         (loop_index, x) -> tensor) for deterministic parity, ``seed`` for the in-kernel generator (None: a fresh one per call
         from torch's global generator, see ``fresh_seed``), ``n_steps`` to
         run only the first n iterations (t = T-1 .. T-n) -- used by the bench / short-chain parity tests, ``use_graph=False``
         to force the eager route, ``first_t`` to enter the schedule at that timestep with ``noise`` taken as x_{first_t}
-        (a window of the loop for measurements; default T-1)."""
+        (a window of the loop for measurements; default T-1), ``shard=(first_clip, total_clips)``: the batch is clips
+        [first, first + B) of a larger one -- noise counters and the feed-forward tile are the larger batch's (module docstring);
+        ``noise`` / ``step_noise`` tensors, when given, are this shard's slices."""
         if clip_denoised:
             raise NotImplementedError('clip_denoised=True is not used on the eval path (eval_smpl_short.py:153)')
         if cond_fn is not None or skip_timesteps or init_image is not None or randomize_class or cond_fn_with_grad or const_noise:
@@ -388,12 +399,21 @@ class GaussianDiffusion:
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
+        if shard is not None:
+            shard = (int(shard[0]), int(shard[1]))
+            if not 0 <= shard[0] <= shard[0] + shape[0] <= shard[1]:
+                raise ValueError('shard=(first_clip, total_clips) must contain this batch of %d clips' % shape[0])
+        first, total = (0, shape[0]) if shard is None else shard
+        per_clip = int(np.prod(shape[1:]))
+        elem0 = first * per_clip
+        if shard is not None and (elem0 % 4 or per_clip % 4):
+            raise ValueError('a shard must start at a multiple of 4 elements (C * T = %d per clip)' % per_clip)
         if noise is not None:
             img = noise.clone().contiguous().float()             # NOT inpainted when given (:691-692)
         else:
             lib = _lib.load()
             img = torch.empty(*shape, dtype=torch.float32, device=device)
-            _lib.check(lib.interdiff_randn(_lib.dptr(img), img.numel(), seed, 0xFFFFFFFF, _lib.stream()), 'randn')
+            _lib.check(lib.interdiff_randn_at(_lib.dptr(img), img.numel(), seed, 0xFFFFFFFF, elem0, _lib.stream()), 'randn')
             y = model_kwargs.get('y', {})
             if 'inpainting_mask' in y and 'inpainted_motion' in y:
                 m = y['inpainting_mask']
@@ -405,7 +425,8 @@ class GaussianDiffusion:
         todo = t_first + 1 if n_steps is None else min(int(n_steps), t_first + 1)
         if (step_noise is None and use_graph and getattr(model, 'graph_safe', False) and img.is_cuda
                 and 'cond' in model_kwargs.get('y', {}) and os.environ.get('INTERDIFF_NO_GRAPH') != '1'):
-            return self._graph_loop(model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_first)
+            return self._graph_loop(model, img, model_kwargs, denoised_fn, seed, todo, dump_steps, t_first, shard)
+        rows_kw = {'batch_rows': total * shape[-1]} if shard is not None and getattr(model, 'accepts_batch_rows', False) else {}
         ts = self._timesteps(shape[0], device)
         dump = []
         cond = model_kwargs.get('y', {}).get('cond') if isinstance(model_kwargs.get('y', None), dict) else None
@@ -420,7 +441,7 @@ class GaussianDiffusion:
                 nz = step_noise(it, img).contiguous()
             else:
                 nz = step_noise[it]
-            self._step(model, img, None, i, it, t, model_kwargs, denoised_fn, nz, seed)
+            self._step(model, img, None, i, it, t, model_kwargs, denoised_fn, nz, seed, elem0, rows_kw)
             if dump_steps is not None and it in dump_steps:
                 dump.append(img.clone())
         return dump if dump_steps is not None else img

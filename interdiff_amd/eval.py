@@ -60,11 +60,17 @@ def finalize(sample, batch, smpl, past_len):
     return obj_pred, body_pred, verts, jtr, jtr[:, :, 0, :]
 
 
-def _x_T(gt, seed):
-    """x_T ~ N(0, I) (:153 ``torch.randn``): from torch's global generator, or from ``seed`` when the caller wants a reproducible draw."""
+def _x_T(gt, seed, shard=None):
+    """x_T ~ N(0, I) (:153 ``torch.randn``): from torch's global generator, or from ``seed`` when the caller wants a reproducible draw.
+    ``shard=(first_clip, total_clips)``: ``gt`` is clips [first, first + B) of a larger batch; with a seed the WHOLE batch's tensor is
+    drawn and this shard's slice returned ("sliced from one global tensor for parity with a 1-GPU run")."""
     if seed is None:
         return torch.randn(*gt.shape, device=gt.device)
-    return torch.randn(*gt.shape, device=gt.device, generator=torch.Generator(device=gt.device).manual_seed(int(seed)))
+    gen = torch.Generator(device=gt.device).manual_seed(int(seed))
+    if shard is None or (shard[0] == 0 and shard[1] == gt.shape[0]):
+        return torch.randn(*gt.shape, device=gt.device, generator=gen)
+    first, total = shard
+    return torch.randn(total, *gt.shape[1:], device=gt.device, generator=gen)[first:first + gt.shape[0]].contiguous()
 
 
 def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=None, **loop_kw):
@@ -72,7 +78,7 @@ def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=Non
     jtr [T,B,J,3], pelvis [T,B,3]) like the reference (:177).  ``noise`` / ``step_noise`` / ``seed`` make it deterministic."""
     gt = batch['gt']
     if noise is None:
-        noise = _x_T(gt, loop_kw.get('seed'))
+        noise = _x_T(gt, loop_kw.get('seed'), loop_kw.get('shard'))
     sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise,
                                      model_kwargs={'y': model_kwargs_for(batch, past_len)}, denoised_fn=correction, **loop_kw)
     return finalize(sample, batch, correction.smpl if correction is not None else loop_kw['smpl'], past_len)
@@ -82,7 +88,7 @@ def sample_once(model, diffusion, smpl, batch, past_len=10, noise=None, **loop_k
     """Diffusion only (mode no_correction, :179-215)."""
     gt = batch['gt']
     if noise is None:
-        noise = _x_T(gt, loop_kw.get('seed'))
+        noise = _x_T(gt, loop_kw.get('seed'), loop_kw.get('shard'))
     y = model_kwargs_for(batch, past_len)
     sample = diffusion.p_sample_loop(model, tuple(gt.shape), clip_denoised=False, noise=noise, model_kwargs={'y': y}, **loop_kw)
     return finalize(sample, batch, smpl, past_len)
@@ -105,11 +111,12 @@ def smooth(obj, body, verts, jtrs, pelvis, future_len):
     return tuple(out)
 
 
-def batch_from_raw(model, raw, past_len=10):
+def batch_from_raw(model, raw, past_len=10, batch_clips=None):
     """Dataset-side quantities -> the clip batch of this module, through the HIP conditioning path.
     raw: body_pose [T,B,66] axis-angle, hand_pose [T,B,90], body_trans [T,B,3], obj_angles [T,B,3] axis-angle,
-    obj_trans [T,B,3], beta [T,B,10], obj_points [B,P,3]."""
-    cond, gt = model._get_embeddings(raw['body_pose'], raw['body_trans'], raw['obj_angles'], raw['obj_trans'], raw['obj_points'], past_len)
+    obj_trans [T,B,3], beta [T,B,10], obj_points [B,P,3].  ``batch_clips``: clips of the whole batch when ``raw`` is a shard of it."""
+    cond, gt = model._get_embeddings(raw['body_pose'], raw['body_trans'], raw['obj_angles'], raw['obj_trans'], raw['obj_points'], past_len,
+                                     **({} if batch_clips is None else {'batch_clips': batch_clips}))
     return dict(gt=gt.permute(1, 2, 0).unsqueeze(1).contiguous(), cond=cond, hand_pose=raw['hand_pose'].contiguous(),
                 beta=raw['beta'].contiguous(), obj_points=raw['obj_points'].contiguous())
 
@@ -127,7 +134,8 @@ def next_window_raw(body, obj, pelvis, raw, future_len):
     return nxt, centroid
 
 
-def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, x_T=None, step_noise=None, **loop_kw):
+def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, x_T=None, step_noise=None, shard=None,
+                **loop_kw):
     """Autoregressive long-horizon forecasting (eval_smpl_long.py:26-84,273-285; BASELINE config #4).
 
     Upstream this path is unreleased/broken (``denormalize`` / ``correct`` are undefined, ``get_batch`` copies clip 0 into
@@ -138,6 +146,8 @@ def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='c
     append the window's future frames.  Every clip keeps its chain on its own GPU: no exchange between ranks.
     ``x_T(k)`` / ``step_noise(k)`` (optional callables) inject window k's initial noise / per-step noise callable for deterministic
     parity with oracle/long_horizon.py; by default window k draws both from ``seed + k`` (``seed=None``: a fresh base seed per call).
+    ``shard=(first_clip, total_clips)``: ``raw`` is a clip shard of a larger rollout; every window then draws the larger batch's noise at
+    this shard's elements (diffusion.py), so the shard's rollout equals the same clips of the unsharded one bit for bit.
     Returns (obj [T+K*F,B,6], body [T+K*F,B,159], verts, jtr, pelvis) in the first window's coordinate frame."""
     smpl = correction.smpl
     T = raw['body_pose'].shape[0]
@@ -145,17 +155,20 @@ def sample_long(model, diffusion, correction, raw, windows, past_len=10, mode='c
     if seed is None:                     # like p_sample_loop / evaluate_batch: every call draws its own noise unless the caller pins a seed
         from .diffusion import fresh_seed
         seed = fresh_seed()
+    clips_kw = {} if shard is None else {'batch_clips': shard[1]}
+    if shard is not None:
+        loop_kw = dict(loop_kw, shard=shard)
     def run(bt, k):
         sd = seed + k
-        nz = x_T(k) if x_T is not None else _x_T(bt['gt'], sd)
+        nz = x_T(k) if x_T is not None else _x_T(bt['gt'], sd, shard)
         kw = dict(loop_kw, step_noise=step_noise(k)) if step_noise is not None else loop_kw
         if mode == 'correction':
             return sample_once_proj(model, diffusion, correction, bt, past_len, noise=nz, seed=sd, **kw)
         return sample_once(model, diffusion, smpl, bt, past_len, noise=nz, seed=sd, **kw)
-    obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len), 0)
+    obj, body, verts, jtr, pelvis = run(batch_from_raw(model, raw, past_len, **clips_kw), 0)
     for k in range(windows):
         nxt, centroid = next_window_raw(body[-past_len:], obj[-past_len:], pelvis[-past_len:], raw, fut)
-        o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len), 1 + k)
+        o, b_, v, j, p = run(batch_from_raw(model, nxt, past_len, **clips_kw), 1 + k)
         o, b_ = o.clone(), b_.clone()
         o[..., 3:] += centroid
         b_[..., -3:] += centroid
@@ -221,29 +234,40 @@ BATCH_DIMS = dict(gt=0, cond=1, hand_pose=1, beta=1, obj_points=0)        # clip
 
 
 def evaluate_sharded(model, diffusion, correction, batch, past_len=10, mode='correction', diverse_samples=1, seed=None,
-                     presharded=False, **loop_kw):
+                     presharded=False, rank=None, world=None, collate=True, **loop_kw):
     """One eval batch of the reference's outer loop (:265-296) over ALL ranks: every rank takes a contiguous shard of the clips
     (they are independent through the whole path), runs ``evaluate_batch`` on it and the six per-clip metric vectors are
     collated with ONE fixed-size all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests; shard sizes are known by construction, so
     nothing is exchanged or synchronised before it) -- the only collective of the path.
     Returns (per-clip metrics {name: [B_total]} in clip order on every rank, their means {name: float} = the numbers upstream
-    accumulates at :291-296).  ``seed``: base seed; a rank's draws use ``seed + first_clip * diverse_samples + j`` so that ranks
-    never share a noise stream and a given (clip shard, draw) is reproducible whatever the world size of an even split.
-    ``presharded``: ``batch`` is this rank's shard already (bench.py builds its clips per rank)."""
-    rank, world = dist.get_rank_world()
-    if presharded:                                                  # `batch` already is this rank's shard (equal sizes assumed for the seeds)
+    accumulates at :291-296).
+
+    A sharded run IS the unsharded run, bit for bit (given ``seed``): draw j of every rank uses the same seed ``seed + j`` and the rank's
+    clips sit at their GLOBAL position in that draw's noise stream (``shard=(first_clip, total_clips)`` down to the Philox counters
+    of every step and the slice of x_T, diffusion.py), and the feed-forward tile class follows the global batch.  The reference draws
+    one ``randn_like`` tensor per step for the whole batch (gaussian_diffusion.py:532); SURVEY.md §8(e) names this option.
+    ``presharded``: ``batch`` is this rank's shard already and every rank holds the same number of clips (bench.py builds its clips
+    per rank); ragged pre-sharded batches must go through the unsharded form.
+    ``rank`` / ``world``: override the process group's (a test that emulates N ranks one after another on one GPU);
+    ``collate=False``: skip the all-gather and return this rank's metrics only (same emulation)."""
+    r0, w0 = dist.get_rank_world()
+    rank, world = r0 if rank is None else int(rank), w0 if world is None else int(world)
+    if presharded:                                                  # `batch` already is this rank's shard: equal sizes on every rank
         B = batch['gt'].shape[0]
-        sl, local = slice(rank * B, (rank + 1) * B), batch
+        total, sl, local = world * B, slice(rank * B, (rank + 1) * B), batch
+        counts = [B] * world
     else:
-        sl = dist.shard_slice(batch['gt'].shape[0], rank, world)
+        total = batch['gt'].shape[0]
+        sl = dist.shard_slice(total, rank, world)
         local = dist.shard_batch(batch, rank, world, BATCH_DIMS)
+        counts = [dist.shard_slice(total, q, world).stop - dist.shard_slice(total, q, world).start for q in range(world)]
     if sl.stop > sl.start:
-        sd = None if seed is None else int(seed) + sl.start * diverse_samples
-        m = evaluate_batch(model, diffusion, correction, local, past_len, mode, diverse_samples, seed=sd, **loop_kw)
+        m = evaluate_batch(model, diffusion, correction, local, past_len, mode, diverse_samples, seed=seed,
+                           **dict(loop_kw, shard=(sl.start, total)))
     else:                                                           # more ranks than clips: contribute an empty shard
         m = {k: torch.empty(0, device=batch['gt'].device) for k in METRIC_KEYS}
-    counts = None if presharded else [dist.shard_slice(batch['gt'].shape[0], q, world).stop - dist.shard_slice(batch['gt'].shape[0], q, world).start
-                                      for q in range(world)]
+    if not collate:
+        return m, {k: float(v.mean()) for k, v in m.items() if v.numel()}
     full = dist.gather_metrics(m, world, counts=counts)                 # ONE fixed-size all-gather, no host sync before it
     return full, {k: float(v.mean()) for k, v in full.items()}
 
@@ -251,14 +275,15 @@ def evaluate_sharded(model, diffusion, correction, batch, past_len=10, mode='cor
 RAW_DIMS = dict(body_pose=1, hand_pose=1, body_trans=1, obj_angles=1, obj_trans=1, beta=1, obj_points=0)      # clip dimension of the raw (dataset-side) tensors
 
 
-def sample_long_sharded(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, **kw):
+def sample_long_sharded(model, diffusion, correction, raw, windows, past_len=10, mode='correction', seed=None, rank=None, world=None, **kw):
     """BASELINE config #4's partitioning (eval_smpl_long.py, B = 64 over 8 GPUs): every rank rolls out ITS clips -- the
-    autoregressive chain of a clip never leaves its GPU, there is no exchange between ranks.  ``seed``: base seed; a rank's windows
-    draw from ``seed + first_clip * (windows + 1) + k`` so that ranks never share a noise stream.  Returns (this rank's clip slice
-    of the global batch, ``sample_long``'s tuple for those clips)."""
-    rank, world = dist.get_rank_world()
+    autoregressive chain of a clip never leaves its GPU, there is no exchange between ranks.  Every rank runs the windows under the
+    SAME seeds (``seed + k``) with its clips at their global position in the noise streams (``shard``), so the ranks' rollouts are the
+    clips of the unsharded rollout bit for bit.  ``rank`` / ``world`` override the process group's (one-GPU emulation of N ranks).
+    Returns (this rank's clip slice of the global batch, ``sample_long``'s tuple for those clips)."""
+    r0, w0 = dist.get_rank_world()
+    rank, world = r0 if rank is None else int(rank), w0 if world is None else int(world)
     B = raw['body_pose'].shape[1]
     sl = dist.shard_slice(B, rank, world)
     local = dist.shard_batch(raw, rank, world, RAW_DIMS)
-    sd = None if seed is None else int(seed) + sl.start * (windows + 1)
-    return sl, sample_long(model, diffusion, correction, local, windows, past_len, mode, seed=sd, **kw)
+    return sl, sample_long(model, diffusion, correction, local, windows, past_len, mode, seed=seed, shard=(sl.start, B), **kw)

@@ -263,6 +263,7 @@ def pack_pointnet2(sd, device, prefix='pcEmbedding', eps=1e-5):
 class MDM:
     """Drop-in for the reference denoiser at the sampler seam: ``MDM(state_dict)(x, ts, y={'cond': ...})``."""
     graph_safe = True        # forward() enqueues kernels only (no allocation / sync once warmed up): hipGraph-capturable
+    accepts_batch_rows = True        # forward() / forward_step() take ``batch_rows=`` (the sampler's shard / chain plumbing)
 
     def __init__(self, state_dict, device='cuda', n_steps=1000, rotary=ROTARY_DEFAULT):
         self.lib = _lib.load()
@@ -347,10 +348,11 @@ class MDM:
         self._memctx = memctx
         return memctx
 
-    def _get_embeddings(self, body_pose, body_trans, obj_angles, obj_trans, obj_points, past_len=10):
+    def _get_embeddings(self, body_pose, body_trans, obj_angles, obj_trans, obj_points, past_len=10, batch_clips=None):
         """``MDM._get_embeddings`` (model/diffusion_smpl.py:195-223) on tensors instead of the dataset's dict-of-lists:
         body_pose [T,B,66] axis-angle, body_trans [T,B,3], obj_angles [T,B,3] axis-angle, obj_trans [T,B,3],
-        obj_points [B,P,3]  ->  (cond [past_len,B,256], gt [T,B,144])."""
+        obj_points [B,P,3]  ->  (cond [past_len,B,256], gt [T,B,144]).  ``batch_clips``: clips of the WHOLE batch these B are a
+        shard of (the encoder's feed-forward tile class follows it, ``_pick_ffn_tile``)."""
         from . import transforms as tr
         if self.pn is None or not self.w.has_encoder:
             raise RuntimeError('this state_dict has no encoder / pcEmbedding weights')
@@ -363,7 +365,7 @@ class MDM:
         obj6 = tr.matrix_to_rotation_6d(tr.axis_angle_to_matrix(obj_angles.reshape(T, B, -1, 3))).reshape(T, B, -1)
         gt = torch.cat([body6, body_trans.float(), obj6, obj_trans.float()], dim=2)                       # [T,B,144]
         x_past = gt[:past_len].permute(1, 2, 0).unsqueeze(1).contiguous()                                # [B,1,144,past]
-        self._pick_ffn_tile(B * past_len)
+        self._pick_ffn_tile((batch_clips or B) * past_len, B * past_len)
         need = self.lib.interdiff_mdm_encode_workspace_bytes(B, past_len)
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         cond = torch.empty(past_len, B, D, dtype=torch.float32, device=self.device)
@@ -379,19 +381,32 @@ class MDM:
         workgroups (<= 800 rows), 64-row tiles from 2800 rows on, 32 in between."""
         return 16 if rows <= cls.FFN16_MAX_ROWS else (32 if rows < cls.FFN64_MIN_ROWS else 64)
 
-    def _pick_ffn_tile(self, rows):
+    @classmethod
+    def ffn_class_for_rows(cls, rows):
+        """Rounding class of the feed-forward tile a batch of ``rows`` token rows takes: 32 (the 32-row kernel: one column tile per
+        slice is summed in two accumulators) or 16 (the 16- and 64-row kernels, bit-identical to each other)."""
+        return 32 if cls.ffn_tile_for_rows(rows) == 32 else 16
+
+    def _pick_ffn_tile(self, rows, own_rows=None):
         """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to
-        rounding, not bit for bit: every launch of one sample must take the same one, whichever way the sampler cuts the batch into
-        chains -- so the choice is made HERE from the rows of the whole batch and handed down (``tune[IDF_TUNE_FFN]``), not left to the
-        per-launch default.  ``self.ffn_rows`` (16 / 32 / 64) overrides it (A/B runs: tools/ffn16_ab.py)."""
-        rows = self.ffn_rows or self.ffn_tile_for_rows(rows)
-        self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(rows, 1)
+        rounding, not bit for bit: every launch of one sample must take the same rounding class, whichever way the batch is cut into
+        chains (diffusion.py) or shards (dist.py) -- so the class is chosen HERE from ``rows`` = the rows of the WHOLE batch and
+        handed down (``tune[IDF_TUNE_FFN]``), not left to the per-launch default.  Inside the 16 / 64 class the tile follows
+        ``own_rows`` = the rows of this launch (a rank's 8 clips of a 64-clip batch take the 16-row grid: same bits as the 64-row
+        kernel the unsharded batch runs, twice as fast at that size).  ``self.ffn_rows`` (16 / 32 / 64) overrides all of it (A/B runs:
+        tools/ffn16_ab.py)."""
+        tile = self.ffn_rows
+        if not tile:
+            tile = self.ffn_tile_for_rows(rows)
+            if tile != 32 and own_rows is not None and own_rows != rows:
+                tile = 16 if own_rows <= self.FFN16_MAX_ROWS else 64
+        self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(tile, 1)
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).
         ``batch_rows``: B * T of the batch this call is a chain of (default: this call's own)."""
         B, one, Cc, T = x.shape
-        self._pick_ffn_tile(batch_rows or B * T)
+        self._pick_ffn_tile(batch_rows or B * T, B * T)
         if memctx is None:
             if y is None or 'cond' not in y:
                 raise ValueError("model_kwargs['y']['cond'] is required")
@@ -427,7 +442,7 @@ class MDM:
         model's -- what lets two chains of one sample run side by side; ``batch_rows`` then names the whole batch's B * T (see
         ``_pick_ffn_tile``)."""
         B, one, Cc, T = x.shape
-        self._pick_ffn_tile(batch_rows or B * T)
+        self._pick_ffn_tile(batch_rows or B * T, B * T)
         if one != 1 or Cc != self.w.C or not x.is_contiguous():
             raise ValueError('x must be a contiguous [B,1,%d,T]' % self.w.C)
         if memctx is None:
@@ -451,7 +466,7 @@ def ffn_parts(model, x2, layer, encoder=False, out=None, batch_rows=None):
     sum is x2 + linear2(gelu(linear1(x2))) (interdiff_mdm_ffn).  Tile by ``batch_rows`` (default M), see MDM._pick_ffn_tile."""
     lib = _lib.load()
     M = x2.shape[0]
-    model._pick_ffn_tile(batch_rows or M)
+    model._pick_ffn_tile(batch_rows or M, M)
     x2 = x2.contiguous()
     if out is None:
         out = torch.empty(_lib.FFN_SLICES, M, D, dtype=torch.float32, device=x2.device)

@@ -98,26 +98,26 @@ def test_pack_objprojector_folds():
 def test_gloo_sharding_world2():
     """N>1 path on CPU: clips are sharded over ranks, metrics all-gathered (gloo stands in for RCCL)."""
     import torch.multiprocessing as mp
-    from interdiff_amd import dist as idist
-    mp.spawn(idist._selftest_worker, args=(2, 29517), nprocs=2, join=True)
+    from tests import dist_workers
+    mp.spawn(dist_workers._selftest_worker, args=(2, 29517), nprocs=2, join=True)
 
 
 def test_gloo_evaluate_sharded_world2():
     """The eval entry that issues the path's one collective (interdiff_amd/eval.py: evaluate_sharded, eval_smpl_short.py:265-296):
-    uneven clip shards, per-rank seed offsets, all-gather, clip order of the collated per-clip metric vectors -- 2 gloo ranks."""
+    uneven clip shards, one seed for all ranks + each shard's global position, all-gather, clip order of the collated per-clip metric vectors -- 2 gloo ranks."""
     import torch.multiprocessing as mp
-    from interdiff_amd import dist as idist
-    mp.spawn(idist._selftest_eval_worker, args=(2, 29531), nprocs=2, join=True)
+    from tests import dist_workers
+    mp.spawn(dist_workers._selftest_eval_worker, args=(2, 29531), nprocs=2, join=True)
 
 
 def test_gloo_world8_config4_and_config5_shapes():
     """BASELINE configs #4 / #5 partitioning at the named shapes, 8 gloo ranks on CPU (no 8-GPU node was available to measure on):
-    ``evaluate_sharded`` at B = 64 (8 clips per rank: shard, seed offsets, the ONE fixed-size all-gather, clip order) and
+    ``evaluate_sharded`` at B = 64 (8 clips per rank: shard, global positions, the ONE fixed-size all-gather, clip order) and
     ``sample_long_sharded`` at B = 64 (every rank rolls out its own clips, no exchange; equal to the unsharded rollout clip by clip)."""
     import torch.multiprocessing as mp
-    from interdiff_amd import dist as idist
-    mp.spawn(idist._selftest_eval_worker, args=(8, 29547), nprocs=8, join=True)
-    mp.spawn(idist._selftest_long_worker, args=(8, 29559), nprocs=8, join=True)
+    from tests import dist_workers
+    mp.spawn(dist_workers._selftest_eval_worker, args=(8, 29547), nprocs=8, join=True)
+    mp.spawn(dist_workers._selftest_long_worker, args=(8, 29559), nprocs=8, join=True)
 
 
 def test_behave_etl_matches_reference_dataset(tmp_path):
@@ -318,12 +318,17 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
     from interdiff_amd import _lib
     from interdiff_amd.mdm import MDM
     k = _lib.TUNE['ffn']
-    m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, ffn_tile_for_rows=MDM.ffn_tile_for_rows)
+    m = SimpleNamespace(w=_lib.MdmWeights(), ffn_rows=0, ffn_tile_for_rows=MDM.ffn_tile_for_rows, FFN16_MAX_ROWS=MDM.FFN16_MAX_ROWS)
     want = {1: 16, 800: 16, 801: 32, 1600: 32, 2400: 32, 2799: 32, 2800: 64, 3200: 64, 3264: 64, 3265: 64, 4800: 64, 6400: 64, 12800: 64}
     for rows, tile in want.items():
         assert MDM.ffn_tile_for_rows(rows) == tile, (rows, MDM.ffn_tile_for_rows(rows))
         MDM._pick_ffn_tile(m, rows)
         assert m.w.tune[k] == {16: 2, 32: 1, 64: 3}[tile], (rows, m.w.tune[k])
+    # a shard / chain of a batch: the ROUNDING CLASS (32 vs 16 = 64) is the whole batch's, the tile inside the 16 / 64 class its own
+    for whole, own, tile in ((6400, 800, 16), (6400, 1600, 64), (6400, 3200, 64), (1600, 800, 32), (1600, 400, 32), (800, 400, 16), (3200, 1600, 64), (2400, 1200, 32)):
+        MDM._pick_ffn_tile(m, whole, own)
+        assert m.w.tune[k] == {16: 2, 32: 1, 64: 3}[tile], (whole, own, m.w.tune[k])
+        assert MDM.ffn_class_for_rows(whole) == (32 if tile == 32 else 16)
     for forced, code in ((32, 1), (16, 2), (64, 3)):
         m.ffn_rows = forced
         MDM._pick_ffn_tile(m, 100)

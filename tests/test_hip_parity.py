@@ -1385,3 +1385,120 @@ def test_timed_route_window_vs_oracle(lib, mdm):
                             bt['noise'].clone(), lambda i, x: stream[i], {'y': y}, n_steps=n, first_t=fx.TIMED_FIRST_T)
     e = close(got, ref, 1e-4, 'timed route, 50 steps from t=560 at B=16,T=100 vs oracle')
     fx.record_parity('timed_route_vs_oracle_B16_T100_50steps_from_t560', worst_rel_err=e, asserted=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ row (e): sharded == unsharded, bit for bit
+def _shard_y(y, sl):
+    dims = dict(inpainted_motion=0, inpainting_mask=0, obj_points=0, hand_pose=1, beta=1, cond=1)
+    return {k: (v[(slice(None),) * dims[k] + (sl,)].contiguous() if k in dims else v) for k, v in y.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,world', [(64, 8), (16, 2), (24, 3)])
+def test_emulated_ranks_equal_unsharded_sampler(lib, mdm, smpl, B, world):
+    """SURVEY.md §8(e) / VERDICT r03 #1: ``world`` emulated ranks, run ONE AFTER ANOTHER on this GPU, each on its contiguous clip shard
+    with ``shard=(first_clip, total_clips)`` == the unsharded batch, ``torch.equal`` on the sampler state after 120 steps from t = 560
+    (corrected steps t = 500 and t = 450 inside), at T = 100, P = 2048 -- the timed route (graphs, fused steps, chains, in-kernel
+    Philox at the GLOBAL counters, feed-forward tile class of the GLOBAL batch).  B = 64 over 8 ranks is BASELINE config #4's
+    partitioning (global 64-row tile, ranks on the bit-identical 16-row grid); B = 16 over 2: the global batch takes the 32-row tile,
+    so must the 800-row shards; B = 24 over 3: chains inside the shards as well.  Also the eager route on one shard.
+    Reference seam: eval_smpl_short.py:252-296 (one randn_like tensor per step for the whole batch, gaussian_diffusion.py:532)."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    from interdiff_amd.dist import shard_slice
+    diff = create_gaussian_diffusion('cosine', 1000)
+    T, P = fx.TIMED_T, fx.TIMED_P
+    bt, y = fx.timed_inputs(B)
+    y, x_t = dev(y), bt['noise'].to(DEV)
+    corr = make_correction(smpl, T, P)
+    seed = 777 + B
+    kw = dict(clip_denoised=False, denoised_fn=corr, n_steps=fx.TIMED_STEPS, first_t=fx.TIMED_FIRST_T)
+    whole = diff.p_sample_loop(mdm, tuple(x_t.shape), noise=x_t, model_kwargs={'y': y}, seed=seed, **kw)
+    parts = []
+    for r in range(world):
+        sl = shard_slice(B, r, world)
+        xs = x_t[sl].contiguous()
+        parts.append(diff.p_sample_loop(mdm, tuple(xs.shape), noise=xs, model_kwargs={'y': _shard_y(y, sl)}, seed=seed, shard=(sl.start, B), **kw))
+    got = torch.cat(parts, dim=0)
+    assert torch.equal(got, whole), 'sharded (%d ranks) differs from unsharded at B=%d: %g' % (world, B, (got - whole).abs().max())
+    # a shard WITHOUT its global position is a different sample (the test would be vacuous otherwise)
+    sl = shard_slice(B, world - 1, world)
+    xs = x_t[sl].contiguous()
+    alone = diff.p_sample_loop(mdm, tuple(xs.shape), noise=xs, model_kwargs={'y': _shard_y(y, sl)}, seed=seed, **kw)
+    assert not torch.equal(alone, whole[sl])
+    # eager route of the last shard, in-kernel generator at the global counters
+    eager = diff.p_sample_loop(mdm, tuple(xs.shape), noise=xs, model_kwargs={'y': _shard_y(y, sl)}, seed=seed, shard=(sl.start, B), use_graph=False, **kw)
+    assert torch.equal(eager, whole[sl]), 'eager shard: %g' % (eager - whole[sl]).abs().max()
+    # x_T drawn in-kernel (noise=None): the shard draws its slice of the whole batch's tensor
+    y2 = dict(y)
+    w2 = diff.p_sample_loop(mdm, tuple(x_t.shape), model_kwargs={'y': y2}, seed=seed, clip_denoised=False, n_steps=3)
+    s2 = diff.p_sample_loop(mdm, tuple(xs.shape), model_kwargs={'y': _shard_y(y2, sl)}, seed=seed, clip_denoised=False, n_steps=3, shard=(sl.start, B))
+    assert torch.equal(s2, w2[sl])
+    fx.record_parity('sharded_equals_unsharded_B%d_world%d_T100_P2048_120steps_from_t560' % (B, world), bit_identical=1.0, corrected_steps_inside=2)
+
+
+@pytest.mark.gpu
+def test_emulated_ranks_equal_unsharded_eval_and_rollout(lib, smpl):
+    """The two sharded entry points themselves, 8 emulated ranks on one GPU against the unsharded call, bit for bit:
+    ``evaluate_sharded`` (eval_smpl_short.py:252-296; B = 16 clips, T = 24, two draws, 50-step schedule with a corrected step: equal
+    per-clip metric vectors) and ``sample_long_sharded`` (BASELINE config #4's partitioning; K = 2 windows: equal rollouts incl. the
+    conditioning pass per window)."""
+    from interdiff_amd import eval as ev, synthetic as syn
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P, past, steps, K, world = 24, 16, 256, fx.PAST, 50, 2, 8
+    ei = {k: torch.from_numpy(v).to(DEV) for k, v in syn.make_embedding_inputs(seed=8, B=B, T=T, n_points=P).items()}
+    g = torch.Generator().manual_seed(4)
+    raw = dict(ei, hand_pose=(0.1 * torch.randn(T, B, 90, generator=g)).to(DEV), beta=torch.randn(1, B, 10, generator=g).expand(T, B, 10).contiguous().to(DEV))
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=steps)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', steps)
+    batch = ev.batch_from_raw(model, raw, past)
+    full, means = ev.evaluate_sharded(model, diff, corr, batch, past, 'correction', 2, seed=31)          # world = 1: the unsharded run
+    got = {k: [] for k in full}
+    for r in range(world):
+        m, _ = ev.evaluate_sharded(model, diff, corr, batch, past, 'correction', 2, seed=31, rank=r, world=world, collate=False)
+        for k in m:
+            got[k].append(m[k])
+    for k in full:
+        assert torch.equal(torch.cat(got[k]), full[k]), (k, torch.cat(got[k]), full[k])
+    whole = ev.sample_long(model, diff, corr, raw, K, past, seed=5)
+    for r in range(world):
+        sl, mine = ev.sample_long_sharded(model, diff, corr, raw, K, past, seed=5, rank=r, world=world)
+        for name, a, b in zip(('obj', 'body', 'verts', 'jtr', 'pelvis'), whole, mine):
+            assert torch.equal(a[:, sl], b), 'rank %d %s: %g' % (r, name, (a[:, sl] - b).abs().max())
+    fx.record_parity('sharded_equals_unsharded_evaluate_and_rollout_B16_world8', bit_identical=1.0)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_all_gather_on_gpu(lib):
+    """The path's one collective through RCCL for real on the one GPU there is: a 1-rank ``nccl`` process group, ``gather_metrics`` with
+    the world == 1 shortcut bypassed (``force_collective``), header verified.  Runs in a child process so that the process group never
+    leaks into the other tests."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json, torch
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+from interdiff_amd import dist as idist
+import torch.distributed as dist
+r, w, l = idist.init_from_env('nccl', single_rank_group=True)
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and (r, w) == (0, 1)
+local = {k: torch.arange(5, dtype=torch.float32, device='cuda') + 10 * i for i, k in enumerate(idist.METRIC_KEYS)}
+out, header = idist.gather_metrics(local, 1, counts=[5], return_header=True, force_collective=True, check_header=True)
+torch.cuda.synchronize()
+assert header.tolist() == [5.0] and all(torch.equal(out[k], local[k]) for k in local)
+assert out['penetrate'].data_ptr() != local['penetrate'].data_ptr()          # came back out of the all-gather buffers, not the shortcut
+assert idist.max_over_ranks(1.5, 'cuda') == 1.5 and idist.gather_scalar(2.5, 'cuda') == [2.5]
+info = idist.collective_backend_info()
+idist.barrier(); idist.shutdown()
+print('RCCL_OK ' + json.dumps(info))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'RCCL_OK' in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    import json
+    info = json.loads(p.stdout.split('RCCL_OK ', 1)[1].splitlines()[0])
+    assert info['backend'] == 'nccl' and info['rccl_version']
+    fx.record_parity('rccl_single_rank_all_gather', ok=1.0, rccl_version=str(info['rccl_version']))

@@ -130,6 +130,9 @@ typedef struct {
     int64_t sa_in_pack;        /* std only: sa_in_w in the LayerNorm+linear kernel's stream order (5 slices x 16 chunks [160][16], rows past 768 zero; mdm.py pack_linear160) */
     int64_t sa_out_frag;       /* std only: sa_out_w in MFMA fragment order [head][4 column quarters][4 k-groups][4 column tiles][64 lanes][4] (mdm.py sa_out_fragments): the attention kernel's out-projection tail */
     int64_t ln_w[3], ln_b[3];
+    int64_t ffn_pack_h2;       /* 0, or linear1 + linear2 split into two f16 planes (hi, residual x 2^11) in the split-f16 FFN kernel's stream order
+                                  (5 x 110592 floats, mdm.py pack_ffn_h2; csrc/ffn_h2.h).  Only set when the packer has PROVED that no operand of
+                                  this layer's feed-forward block can leave the f16 range (mdm.py ffn_h2_range_ok) */
 } idf_mdm_layer;
 
 typedef struct {
@@ -152,7 +155,11 @@ typedef struct {
      * otherwise: csrc/ffn.h ffn_tile_for_rows), 1 = 32-row tiles, 2 = 16-row tiles, 3 = 64-row tiles.  The 32-row kernel agrees with
      * the other two to rounding (7e-7 of the output scale), not bit for bit: a caller that steps ONE batch as several calls on row subsets (the
      * sampler's half-batch chains) sets 1 or 2 from the rows of the whole batch so that every call takes the same kernel
-     * (interdiff_amd/mdm.py: MDM._pick_ffn_tile does this before every forward / forward_step / encode / ffn call). */
+     * (interdiff_amd/mdm.py: MDM._pick_ffn_tile does this before every forward / forward_step / encode / ffn call).
+     * tune[IDF_TUNE_FFN_MATH] selects the arithmetic of the feed-forward block: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/ffn.h),
+     * 1 = split-f16 (every fp32 operand as two f16 planes, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate: fp32-grade
+     * results at 1/43 of the matrix-pipe time, csrc/ffn_h2.h) for every layer whose ffn_pack_h2 is set, exact fp32 for the others.  Its
+     * 16-, 32- and 64-row tiles are bit-identical, so with 1 the row tile is a pure performance choice. */
     int32_t tune[8];
 } idf_mdm_weights;
 
@@ -429,7 +436,7 @@ int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kind);
 
 /* indices into idf_mdm_weights.tune (value 0 = the shipped default) */
 enum {
-    IDF_TUNE_GEMM_EMBED = 0, IDF_TUNE_GEMM_QKV, IDF_TUNE_GEMM_OUTPROJ, IDF_TUNE_FFN, IDF_TUNE_RESERVED,
+    IDF_TUNE_GEMM_EMBED = 0, IDF_TUNE_GEMM_QKV, IDF_TUNE_GEMM_OUTPROJ, IDF_TUNE_FFN, IDF_TUNE_FFN_MATH,
     IDF_TUNE_GEMM_HEADS, IDF_TUNE_CONTACT, IDF_TUNE_MISC, IDF_TUNE_COUNT
 };
 

@@ -15,7 +15,7 @@ vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_ui
 
 MDM_LAYERS = 8
 FFN_SLICES = 5              # IDF_FFN_SLICES: partial output slabs of the fused feed-forward kernel
-TUNE = dict(embed=0, qkv=1, outproj=2, ffn=3, heads=5, contact=6, misc=7)      # indices into MdmWeights.tune (IDF_TUNE_*)
+TUNE = dict(embed=0, qkv=1, outproj=2, ffn=3, ffn_math=4, heads=5, contact=6, misc=7)      # indices into MdmWeights.tune (IDF_TUNE_*)
 
 
 class SmplModel(C.Structure):
@@ -30,7 +30,7 @@ class MdmLayer(C.Structure):
                 ('ca_q_w', i64), ('ca_q_b', i64), ('ca_kv_w', i64), ('ca_kv_b', i64),
                 ('ca_out_w', i64), ('ca_out_b', i64),
                 ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64), ('ffn_b1p', i64), ('sa_in_pack', i64), ('sa_out_frag', i64),
-                ('ln_w', i64 * 3), ('ln_b', i64 * 3)]
+                ('ln_w', i64 * 3), ('ln_b', i64 * 3), ('ffn_pack_h2', i64)]
 
 
 class MdmWeights(C.Structure):

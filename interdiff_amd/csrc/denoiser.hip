@@ -21,6 +21,19 @@
 #include "common.h"
 #include "gemm.h"
 #include "ffn.h"
+#include "ffn_h2.h"
+
+// the feed-forward block of one layer: arithmetic by tune[IDF_TUNE_FFN_MATH] (and whether the packer set the layer's split-f16 stream),
+// row tile by tune[IDF_TUNE_FFN] (0: by this launch's rows)
+static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, const float *ar, const int32_t *tune, const float *x2, int M, float *parts) {
+    int rows = idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]);
+    if (tune[IDF_TUNE_FFN_MATH] == 1 && ly.ffn_pack_h2 != 0) {
+        if (rows == 0) rows = idf_ffn::ffn_tile_for_rows(M);
+        return idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows);
+    }
+    idf_ffn::launch_ffn(s, x2, M, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows);
+    return IDF_OK;
+}
 #include <float.h>
 
 // phase stamps of the row-block kernel exist only in tools/rowblock_probe.hip (which defines the macro before including this file)
@@ -770,8 +783,8 @@ extern "C" int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_
     if (!w || !x2 || !parts || M <= 0 || layer < 0 || layer >= L || (encoder && !w->has_encoder)) return IDF_E_INVAL;
     if ((reinterpret_cast<uintptr_t>(x2) & 15) || (reinterpret_cast<uintptr_t>(parts) & 15)) return IDF_E_INVAL;
     const idf_mdm_layer &ly = encoder ? w->enc_layer[layer] : w->layer[layer];
-    const int rows = idf_ffn::ffn_rows_of_tune(w->tune[IDF_TUNE_FFN]);
-    idf_ffn::launch_ffn(idf_stream(stream), x2, M, w->arena + ly.ffn_pack, w->arena + ly.ffn_b1p, w->arena + ly.ff2_b, parts, rows);
+    const int rc = idf_launch_layer_ffn(idf_stream(stream), ly, w->arena, w->tune, x2, M, parts);
+    if (rc != IDF_OK) return rc;
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -877,7 +890,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
                                ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride,
                                k.xn, ar + ly.sa_out_b);
         }
-        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, idf_ffn::ffn_rows_of_tune(w->tune[IDF_TUNE_FFN]));
+        if (const int rc = idf_launch_layer_ffn(s, ly, ar, w->tune, k.x2, N, k.parts); rc != IDF_OK) return rc;
         u_in = k.parts;
         u_np = NSL;
         lnp_w = ar + ly.ln_w[1];
@@ -981,7 +994,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
         }
         // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
         idf_prof_mark(IDF_K_FFN_FUSED, s);
-        idf_ffn::launch_ffn(s, k.x2, N, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, k.parts, idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]));
+        if (const int rc = idf_launch_layer_ffn(s, ly, ar, tune, k.x2, N, k.parts); rc != IDF_OK) return rc;
         u_in = k.parts;
         u_np = NSL;
         lnp_w = ar + ly.ln_w[2];

@@ -1,0 +1,357 @@
+// Fused feed-forward block on the f16 matrix pipe with fp32-grade results ("split-f16", round 4):
+//
+//     u3 = x2 + gelu(x2 . W1^T + b1) . W2^T + b2          same contract, grid, slabs and epilogue as csrc/ffn.h
+//
+// gfx950 has no TF32 path: an fp32-input MFMA runs at the vector rate (157 TFLOP/s), 1/16 of the f16 / bf16 rate, and the exact-fp32
+// kernel of ffn.h spends 26.6 k of its 40 k cycles per workgroup issuing it.  Here every fp32 operand v is split ONCE into two
+// half-precision planes
+//         hi  = f16(v)                      (0 when |v| < 2^-14: no subnormal ever enters the hi plane)
+//         lo' = f16((v - f32(hi)) * 2^11)   (the residual, exact in fp32, scaled back into the normal range)
+// so that v = hi + lo' 2^-11 up to 2^-23 |v| (an f16 keeps 11 significant bits, the residual has at most 12 + sign), and
+//         x . w  =  xh wh  +  2^-11 (xh wl' + xl' wh)  +  O(2^-22 |x w|)
+// is THREE v_mfma_f32_16x16x32_f16 per 32 k instead of EIGHT v_mfma_f32_16x16x4_f32 at 1/16 of the rate: 1/43 of the matrix-pipe
+// time.  Products of halves are exact in fp32, both sums are accumulated in fp32 (a main and a correction accumulator per tile; the
+// 2^-11 is applied once, in fp32, when the tile leaves).  A bf16 split would need three planes (8 bits each), six products and
+// 6 bytes per weight in the stream; the f16 split needs two planes, three products and the SAME 4 bytes per weight as fp32 -- the
+// stream, which is what bounds this kernel now, does not grow.  The price of f16 is its range: |v| must stay below 65504.  The host
+// packer proves that at pack time from the weights (mdm.py ffn_h2_range_ok: LayerNorm bounds the input rows, |W1| row sums bound the
+// hidden activations) and leaves ffn_pack_h2 = 0 -- this kernel unreachable -- for a layer where it cannot.
+//
+// Everything else follows ffn.h: grid = ceil(M / BM) x 5 hidden slices of 208 units, 512 threads; the slice's weights arrive as ONE
+// contiguous pre-packed stream by inline-asm LDS-DMA through a ring of 32-KiB slots with hand-counted vmcnt waits; the partial
+// [BM,256] tile goes to slab `slice` (slab 0 + residual + b2).  What differs:
+//  * a ring slot holds one K = 32 step: [tile][plane][lane][8 halves] -- every (tile, plane) fragment is 1 KiB contiguous in lane
+//    order, i.e. exactly what one ds_read_b128 of a wave fetches, conflict-free without a swizzle (mdm.py pack_ffn_h2);
+//    phase 1: 13 hidden tiles x 2 planes = 26 KiB per step, 8 steps; phase 2: 16 output tiles x 2 planes = 32 KiB, 7 steps
+//    (K = 208 padded to 224 with zero weights): 432 KiB per slice;
+//  * the WEIGHTS are the MFMA's A operand and the token rows its B operand (the two layouts are mirror images, the swap is free):
+//    D[i][n] then has lane n = token and registers i = 4 consecutive hidden units / output columns, so the GELU phase writes 8-byte
+//    pieces of the hid planes and the epilogue 16-byte pieces of the output tile (ffn.h: scalar LDS stores);
+//  * x2 rows land by DMA as fp32 and are split IN PLACE by the wave that fetched them (row r: hi plane at r KiB, lo' plane 512 B
+//    behind it, 16-byte chunk t at position t ^ (r & 15)); the hid planes overwrite them in the same image;
+//  * no K split across waves anywhere (ffn.h's 32-row kernel shares one column tile between two waves): every output element is
+//    summed by one accumulator pair over the steps in order, whatever the row tile -- the 16-, 32- and 64-row instantiations are
+//    BIT-IDENTICAL, so chains and shards of a batch may pick their tile freely (diffusion.py, dist.py);
+//  * one barrier per K step; the fragments of step P are fetched right behind the barrier that publishes them and the MFMAs of step
+//    P - 1 run while they land (register double buffer).
+#pragma once
+#include "common.h"
+
+namespace idf_ffn_h2 {
+
+constexpr int D = IDF_MDM_D, FF = IDF_MDM_FF;
+constexpr int NSL = IDF_FFN_SLICES;                 // hidden slices = partial slabs (5)
+constexpr int NW = 8, NT = NW * 64;
+constexpr int HS = 208, NH1 = HS / 16;              // hidden units / hidden tiles of a slice
+constexpr int NO2 = D / 16;                         // output column tiles
+constexpr int KS1 = D / 32, KS2 = (HS + 31) / 32;   // K steps of 32: 8 (phase 1), 7 (phase 2, 208 -> 224)
+constexpr int NPAIR = KS1 + KS2;                    // ring fills ("pairs" in ffn.h's vocabulary: one K step each here)
+constexpr int P1B = NH1 * 2 * 1024, P2B = NO2 * 2 * 1024;      // bytes of a phase-1 / phase-2 step: 26 KiB / 32 KiB
+constexpr int SLICE_BYTES = KS1 * P1B + KS2 * P2B;  // 442368 = 432 KiB of stream per slice
+constexpr int SLICE_FLOATS = SLICE_BYTES / 4;
+constexpr int SLOT = 32768;                         // bytes of a ring slot
+constexpr int CSS = D + 4;                          // row stride (floats) of the output staging tile
+constexpr float LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int step_off(int P) { return P < KS1 ? P * P1B : KS1 * P1B + (P - KS1) * P2B; }       // bytes into the slice stream
+__host__ __device__ constexpr int step_ins(int P) { return P >= NPAIR ? 0 : (P < KS1 ? P1B / 1024 : P2B / 1024); }  // 1-KiB DMA instructions: 26 / 32
+
+__device__ __forceinline__ void wait_vmcnt(int n) {          // n is a constant after unrolling
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// v = hi + lo' / 2048 (see the header).  Both conversions round to nearest even (v_cvt_f16_f32).
+__device__ __forceinline__ void split1(float v, _Float16 &hi, _Float16 &lo) {
+    _Float16 h = (_Float16)v;
+    if (__builtin_fabsf(v) < 6.103515625e-05f) h = (_Float16)0.0f;
+    hi = h;
+    lo = (_Float16)((v - (float)h) * LO_SCALE);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
+    _Float16 a0, a1, a2, a3, b0, b1, b2, b3;
+    split1(v.x, a0, b0);
+    split1(v.y, a1, b1);
+    split1(v.z, a2, b2);
+    split1(v.w, a3, b3);
+    hi = __builtin_bit_cast(uint2, (h4{a0, a1, a2, a3}));
+    lo = __builtin_bit_cast(uint2, (h4{b0, b1, b2, b3}));
+}
+
+#define IDF_H2_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0)
+
+// TT = token tiles of 16 rows per workgroup (1, 2, 4 -> BM = 16, 32, 64); S = ring slots (3; 2 for TT = 4, where the planes take 64 KiB).
+// LDS: BM KiB of planes + S x 32 KiB ring + 1 KiB bias = 113 / 129 / 129 KiB.
+// MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue (tools/ffn_h2_probe.hip ablations only).
+template <int TT, int S, int MODE = 0>
+__global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
+                                                     const float *__restrict__ b1p, const float *__restrict__ b2,
+                                                     float *__restrict__ parts) {
+    constexpr int BM = 16 * TT;
+    static_assert((TT == 1 || TT == 2 || TT == 4) && (S == 2 || S == 3), "geometry");
+    static_assert(BM * 1024 + S * SLOT + 1024 <= 160 * 1024, "LDS");
+    static_assert(TT == 4 ? BM * CSS * 4 <= BM * 1024 + S * SLOT : BM * CSS * 4 <= 2 * SLOT, "output staging");
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
+    float *ring = smem + BM * 256, *Bs = ring + S * (SLOT / 4);    // Bs: the slice's linear1 bias (208 floats)
+    idf_args_now(x2, M, pack, b1p, b2, parts);
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BM;
+    const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
+    const uint32_t lane16 = lane << 4;
+    const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;                 // this lane's 16 B inside a step: instruction wave + 8 j adds 8192 j
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);     // LDS byte address of this wave's first instruction in slot 0
+    const bool lt2 = wave < 2;                                              // 26 = 3 * 8 + 2: waves 0 and 1 issue a 4th instruction for a phase-1 step
+
+    auto issue_step = [&](int P) {                    // DMA instructions of step P: instruction i = wave + 8 j copies stream bytes [step_off + 1024 i, +1024) to slot P % S
+        if (P >= NPAIR) return;
+        if constexpr (MODE == 2) { if (P >= S - 1) return; }
+        const int nins = step_ins(P);
+        const uint32_t so = (uint32_t)step_off(P), dof = (uint32_t)((P % S) * SLOT);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (8 * j + 7 < nins) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+            else if (8 * j < nins && lt2) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
+        }
+    };
+    // wait until this wave's DMAs of step P have landed: the steps P + 1 .. P + S - 2 issued behind them may keep flying
+    auto wait_step = [&](int P) {
+        bool some = false;
+#pragma unroll
+        for (int Q = P + 1; Q <= P + S - 2; ++Q) some = some || Q < NPAIR;
+        if constexpr (MODE == 2) some = some && P + 1 < S - 1;
+        if (!some) { wait_vmcnt(0); return; }
+        const int nins = step_ins(P + 1);             // S == 3 here: exactly one younger step
+        if (nins % 8 == 0) wait_vmcnt(nins / 8);
+        else if (lt2) wait_vmcnt(nins / 8 + 1);
+        else wait_vmcnt(nins / 8);
+    };
+
+    // ---- prologue: bias slice, x2 rows (fp32, row r at r KiB, linear), the first S - 1 steps
+    if (wave == 0) idf_dma16_s(idf_uniform_ptr(b1p + sl * HS), lane16, idf_lds_addr(Bs));
+    const uint32_t xs_lds = idf_lds_addr(Xs);
+#pragma unroll
+    for (int j = 0; j < BM / NW; ++j) {
+        const int i = wave + NW * j;
+        idf_dma16_s(idf_uniform_ptr(x2 + (size_t)min(m0 + i, M - 1) * D), lane16, xs_lds + (uint32_t)(i * 1024));
+    }
+#pragma unroll
+    for (int P = 0; P < S - 1; ++P) issue_step(P);
+    {   // the x2 rows (and the bias) are older than this wave's share of the steps just issued
+        int younger = 0;
+#pragma unroll
+        for (int P = 0; P < S - 1; ++P) younger += step_ins(P) / 8;         // + 1 for waves 0, 1 per ragged step
+        if (lt2) wait_vmcnt(younger + (S - 1));
+        else wait_vmcnt(younger);
+    }
+    // split the rows this wave fetched, in place: lane l holds k = 4l .. 4l+3 of row r -> chunk l >> 1, half (l & 1)
+#pragma unroll
+    for (int j = 0; j < BM / NW; ++j) {
+        const int r = wave + NW * j;
+        const float4 v = *reinterpret_cast<const float4 *>(Xs + r * 256 + lane * 4);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        float *dst = Xs + r * 256 + ((((lane >> 1) ^ (r & 15)) << 2)) + ((lane & 1) << 1);
+        *reinterpret_cast<uint2 *>(dst) = hi;
+        *reinterpret_cast<uint2 *>(dst + 128) = lo;
+    }
+
+    // ---- tile maps.  Phase 1: 13 hidden tiles: waves 0..4 own two (2w, 2w+1), waves 5..7 one (10, 11, 12); every wave covers all TT
+    // token tiles for its hidden tiles (a weight fragment is read once per workgroup).  Phase 2: 16 output tiles, wave w owns 2w, 2w+1.
+    const bool two1 = wave < 5;
+    const int h0 = two1 ? 2 * wave : 5 + wave;
+    const int o0 = 2 * wave;
+    f32x4 accM[2][TT], accC[2][TT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) accM[a][t] = accC[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    struct Frags {
+        h8 wh[2], wl[2], xh[TT], xl[TT];
+    };
+    Frags F[2];
+    const int e = g ^ n;                                                    // token-plane chunk (4 s + g) of row n sits at position (e ^ 4 s)
+    auto ld8 = [&](const float *p) { return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(p)); };
+    auto read_x = [&](int s, Frags &f) {              // B operand: planes of the token tiles, K step s (x2 planes in phase 1, hid planes in phase 2)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float *row = Xs + (16 * t + n) * 256 + ((e ^ (4 * s)) << 2);
+            f.xh[t] = ld8(row);
+            f.xl[t] = ld8(row + 128);
+        }
+    };
+    auto read1 = [&](int s, Frags &f) {               // A operand: hidden tiles h0 (, h0 + 1) of step s
+        const float *sb = ring + (s % S) * (SLOT / 4) + h0 * 512 + lane * 4;
+        f.wh[0] = ld8(sb);
+        f.wl[0] = ld8(sb + 256);
+        if (two1) {
+            f.wh[1] = ld8(sb + 512);
+            f.wl[1] = ld8(sb + 768);
+        }
+        read_x(s, f);
+    };
+    auto read2 = [&](int q, Frags &f) {               // A operand: output tiles o0, o0 + 1 of phase-2 step q
+        const float *sb = ring + ((KS1 + q) % S) * (SLOT / 4) + o0 * 512 + lane * 4;
+        f.wh[0] = ld8(sb);
+        f.wl[0] = ld8(sb + 256);
+        f.wh[1] = ld8(sb + 512);
+        f.wl[1] = ld8(sb + 768);
+        read_x(q, f);
+    };
+    auto mma = [&](const Frags &f, bool both) {
+        if constexpr (MODE == 1) {
+            asm volatile("" ::"v"(f.wh[0]), "v"(f.wl[0]), "v"(f.wh[1]), "v"(f.wl[1]), "v"(f.xh[0]), "v"(f.xl[0]));
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accM[0][t], f.wh[0], f.xh[t]);
+        if (both) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accM[1][t], f.wh[1], f.xh[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[0][t], f.wh[0], f.xl[t]);
+        if (both) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[1][t], f.wh[1], f.xl[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[0][t], f.wl[0], f.xh[t]);
+        if (both) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[1][t], f.wl[1], f.xh[t]);
+        }
+    };
+    auto publish = [&](int P) {                       // step P has landed for every wave, and every wave is done with step P - 1's slot
+        wait_step(P);
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0) as a builtin: the compiler then KNOWS the LDS queue is empty
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- phase 1: hid^T[hidden][token] = W1[slice] . x2^T
+#pragma unroll
+    for (int P = 0; P < KS1; ++P) {
+        publish(P);                                   // (P = 0: also publishes the planes)
+        issue_step(P + S - 1);                        // into the slot of step P - 1
+        read1(P, F[P & 1]);
+        if (P > 0) mma(F[(P - 1) & 1], two1);
+    }
+    mma(F[(KS1 - 1) & 1], two1);
+
+    // ---- hid = gelu(acc + b1), split, over the x2 planes (every wave is past its last read of them behind the next barrier)
+    publish(KS1);                                     // first phase-2 step has landed too
+    issue_step(KS1 + S - 1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a == 0 || two1) {
+            const float4 bv = *reinterpret_cast<const float4 *>(Bs + (h0 + a) * 16 + 4 * g);
+            const int chunk = 2 * (h0 + a) + (g >> 1);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                float4 v;
+                v.x = gelu_fast(accM[a][t][0] + accC[a][t][0] * LO_UNSCALE + bv.x);
+                v.y = gelu_fast(accM[a][t][1] + accC[a][t][1] * LO_UNSCALE + bv.y);
+                v.z = gelu_fast(accM[a][t][2] + accC[a][t][2] * LO_UNSCALE + bv.z);
+                v.w = gelu_fast(accM[a][t][3] + accC[a][t][3] * LO_UNSCALE + bv.w);
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                float *dst = Xs + (16 * t + n) * 256 + ((chunk ^ n) << 2) + ((g & 1) << 1);
+                *reinterpret_cast<uint2 *>(dst) = hi;
+                *reinterpret_cast<uint2 *>(dst + 128) = lo;
+            }
+        }
+    }
+    // K padding 208 -> 224: chunks 26, 27 of every row, both planes, are zero (the weights there are zero too, but 0 x stale bits may be NaN)
+    if (tid < BM * 4) {
+        const int r = tid >> 2, pl = (tid >> 1) & 1, ch = 26 + (tid & 1);
+        *reinterpret_cast<uint4 *>(Xs + r * 256 + pl * 128 + ((ch ^ (r & 15)) << 2)) = uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) accM[a][t] = accC[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                     // hid planes visible
+
+    // ---- phase 2: part^T[out][token] = W2[:, slice] . hid^T
+    read2(0, F[0]);
+    constexpr int NST = BM * (D / 4) / NT;            // float4 stores per thread
+    float4 xres[NST], bres = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 1; q < KS2; ++q) {
+        publish(KS1 + q);
+        issue_step(KS1 + q + S - 1);
+        if (q == KS2 - 1 && sl == 0) {                // slab 0 carries the residual and the output bias: plain loads, younger than every DMA (the wait above was vmcnt(0))
+            bres = *reinterpret_cast<const float4 *>(b2 + ((tid & 63) << 2));
+#pragma unroll
+            for (int it = 0; it < NST; ++it)
+                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + (tid >> 6) + it * NW, M - 1) * D + ((tid & 63) << 2));
+        }
+        read2(q, F[q & 1]);
+        mma(F[(q - 1) & 1], true);
+    }
+    mma(F[(KS2 - 1) & 1], true);
+
+    // ---- partial tile leaves through LDS as 16-byte row stores.  TT <= 2: staged in ring slots 0 / 1 (the last step, still being read by
+    // slower waves, sits in slot (NPAIR - 1) % 3 = 2); TT = 4: over the planes and slot 0, once every wave is done reading them.
+    float *Cs = TT == 4 ? smem : ring;
+    if constexpr (TT == 4) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float4 v;
+            v.x = accM[a][t][0] + accC[a][t][0] * LO_UNSCALE;
+            v.y = accM[a][t][1] + accC[a][t][1] * LO_UNSCALE;
+            v.z = accM[a][t][2] + accC[a][t][2] * LO_UNSCALE;
+            v.w = accM[a][t][3] + accC[a][t][3] * LO_UNSCALE;
+            *reinterpret_cast<float4 *>(Cs + (16 * t + n) * CSS + (o0 + a) * 16 + 4 * g) = v;
+        }
+    __syncthreads();
+    float *out = parts + (size_t)sl * M * D;
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int row = (tid >> 6) + it * NW, c4 = (tid & 63) << 2, gr = m0 + row;
+        if (gr >= M) continue;
+        float4 v = *reinterpret_cast<const float4 *>(Cs + row * CSS + c4);
+        if (sl == 0) {
+            const float4 x = xres[it];
+            v.x += x.x + bres.x; v.y += x.y + bres.y; v.z += x.z + bres.z; v.w += x.w + bres.w;
+        }
+        idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
+    }
+}
+
+template <int TT, int S>
+inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {
+    constexpr int BM = 16 * TT, LDS = BM * 1024 + S * SLOT + 1024;
+    static std::atomic<uint64_t> done{0};
+    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS, done);
+    if (rc != IDF_OK) return rc;
+    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS, s, x2, M, pack, b1p, b2, parts);
+    return IDF_OK;
+}
+// rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits
+inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows) {
+    if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts);
+    if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts);
+    return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts);
+}
+}  // namespace idf_ffn_h2

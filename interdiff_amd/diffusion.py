@@ -125,7 +125,7 @@ class GaussianDiffusion:
         # The cache lives ON the denoiser object: the captured graphs bake in the addresses of its arena, workspace and memory
         # context, so they must die with it (a cache keyed by id(model) would replay freed memory once the id is recycled).
         cache = model.__dict__.setdefault('_graph_cache', {})
-        key = (self._uid, tuple(img.shape), has_mask, tuple(cond.shape), model.ffn_class_for_rows(rows) if hasattr(model, 'ffn_class_for_rows') else 0)    # the captured launches bake the tile class in
+        key = (self._uid, tuple(img.shape), has_mask, tuple(cond.shape), model.ffn_graph_key(rows) if hasattr(model, 'ffn_graph_key') else 0)    # the captured launches bake the feed-forward kernel choice in
         st = cache.get(key)
         if st is None:
             st = SimpleNamespace(x=torch.zeros_like(img), x0=torch.empty_like(img), ts=torch.zeros(B, dtype=torch.int64, device=dev),

@@ -16,6 +16,7 @@ Weights-only constants folded at pack time (host, once):
 """
 import ctypes as C
 import math
+import os
 import numpy as np
 import torch
 from . import _lib
@@ -23,6 +24,7 @@ from . import _lib
 D, FF, HEADS, NQ, MEM, LAYERS = 256, 1024, 4, 10, 10, 8
 QAN_LAYERS = (1, 2, 3, 4, 5, 6)
 ROTARY_DEFAULT = True
+FFN_MATH_DEFAULT = 'split'
 
 
 def positional_table(max_len=5000, d=D):
@@ -109,6 +111,67 @@ def pack_ffn(w1, w2):
     out = np.concatenate(out)
     assert out.size == _lib.FFN_SLICES * (16 * FFN_SLICE_H * 16 + (FFN_SLICE_H // 16) * D * 16)
     return out
+
+
+H2_KS1, H2_KS2 = D // 32, (FFN_SLICE_H + 31) // 32            # K steps of 32 in the two phases of the split-f16 kernel (csrc/ffn_h2.h): 8, 7
+H2_SLICE_FLOATS = (H2_KS1 * (FFN_SLICE_H // 16) * 2 * 1024 + H2_KS2 * (D // 16) * 2 * 1024) // 4       # 110592 floats = 432 KiB per slice
+H2_LIMIT = 60000.0          # |value| every operand of the split-f16 kernel must provably stay below (f16 max 65504)
+
+
+def split_f16(a):
+    """fp32 array -> (hi, lo') float16 planes with a = hi + lo' / 2048 up to 2^-23 |a| (csrc/ffn_h2.h split1, same roundings):
+    hi = f16(a), 0 where |a| < 2^-14 (no subnormal in the hi plane); lo' = f16((a - hi) * 2^11) (the residual is exact in fp32)."""
+    a = np.asarray(a, np.float32)
+    with np.errstate(over='ignore'):
+        hi = a.astype(np.float16)
+    hi[np.abs(a) < np.float32(2.0 ** -14)] = 0
+    lo = ((a - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    return hi, lo
+
+
+def _h2_fragments(w, k0):
+    """w [16 T rows][K] fp32, K step at k0 -> [T tiles][2 planes][64 lanes][8] float16: lane (i = lane & 15, g = lane >> 4) of tile t
+    holds plane(w[16 t + i][k0 + 8 g + j]), j = 0..7 (zero past K) -- the v_mfma_f32_16x16x32_f16 operand of that lane, so that a
+    wave's ds_read_b128 of a (tile, plane) fragment is 1 KiB contiguous in lane order."""
+    rows, K = w.shape
+    blk = np.zeros((rows, 32), np.float32)
+    kk = min(32, K - k0)
+    blk[:, :kk] = w[:, k0:k0 + kk]
+    hi, lo = split_f16(blk)
+    planes = np.stack([hi, lo], axis=0).reshape(2, rows // 16, 16, 4, 8)          # [plane][tile][i][g][j]
+    return np.ascontiguousarray(planes.transpose(1, 0, 3, 2, 4)).reshape(-1)      # [tile][plane][g][i][j] = [tile][plane][lane][j]
+
+
+def pack_ffn_h2(w1, w2):
+    """linear1.weight [1024,256], linear2.weight [256,1024] -> the split-f16 FFN kernel's weight stream (csrc/ffn_h2.h), as float32
+    words for the arena: per hidden slice the 8 K steps of W1[slice] ([13 tiles][2 planes][64 lanes][8 halves] = 26 KiB each) followed
+    by the 7 K steps of W2[:, slice] ([16 tiles][2 planes][64][8] = 32 KiB each, hidden units past 208 zero)."""
+    w1, w2 = np.asarray(w1, np.float32), np.asarray(w2, np.float32)
+    assert w1.shape == (FF, D) and w2.shape == (D, FF)
+    hp = FFN_SLICE_H * _lib.FFN_SLICES
+    w1p, w2p = np.zeros((hp, D), np.float32), np.zeros((D, hp), np.float32)
+    w1p[:FF], w2p[:, :FF] = w1, w2
+    out = []
+    for h0, hs in ffn_slices():
+        for s in range(H2_KS1):
+            out.append(_h2_fragments(w1p[h0:h0 + hs], 32 * s))
+        for q in range(H2_KS2):
+            out.append(_h2_fragments(w2p[:, h0:h0 + hs], 32 * q))
+    out = np.concatenate(out)
+    assert out.dtype == np.float16 and out.size * 2 == _lib.FFN_SLICES * H2_SLICE_FLOATS * 4
+    return out.view(np.float32)
+
+
+def ffn_h2_range_ok(w1, b1, w2, ln_w, ln_b):
+    """True when NO operand of this layer's feed-forward block can leave the f16 range, whatever the input: the block's input rows are
+    LayerNorm outputs, |x2| <= sqrt(255) max|gamma| + max|beta| < 16 max|gamma| + max|beta|; the hidden activations obey
+    |gelu(pre)| <= |pre| <= max_row ||W1_row||_1 max|x2| + max|b1|; and the weights themselves are checked.  (A caller that hands
+    interdiff_mdm_ffn arbitrary rows -- the standalone op -- owns this bound itself.)"""
+    w1, w2 = np.asarray(w1, np.float64), np.asarray(w2, np.float64)
+    xmax = 16.0 * np.abs(np.asarray(ln_w, np.float64)).max() + np.abs(np.asarray(ln_b, np.float64)).max()
+    hmax = np.abs(w1).sum(axis=1).max() * xmax + np.abs(np.asarray(b1, np.float64)).max()
+    vals = (xmax, hmax, np.abs(w1).max(), np.abs(w2).max())
+    return bool(np.all(np.isfinite(vals)) and max(vals) < H2_LIMIT)
 
 
 QKV_SLICE = 160          # output columns per workgroup of the LayerNorm+linear kernel (csrc/ffn.h LHS)
@@ -206,6 +269,9 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
         ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
         ly.ffn_b1p = ar.add(pad_ffn_bias(g(p + 'linear1.bias')))
+        # split-f16 stream (csrc/ffn_h2.h): only when the range proof holds; the block's input is norm2's output (post-norm layer)
+        ly.ffn_pack_h2 = (ar.add(pack_ffn_h2(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
+                          if ffn_h2_range_ok(g(p + 'linear1.weight'), g(p + 'linear1.bias'), g(p + 'linear2.weight'), g(p + 'norm2.weight'), g(p + 'norm2.bias')) else 0)
         for k in range(3):
             ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
             ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
@@ -229,6 +295,8 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.ff2_w, ly.ff2_b = ar.add(g(p + 'linear2.weight')), ar.add(g(p + 'linear2.bias'))
             ly.ffn_pack = ar.add(pack_ffn(g(p + 'linear1.weight'), g(p + 'linear2.weight')))
             ly.ffn_b1p = ar.add(pad_ffn_bias(g(p + 'linear1.bias')))
+            ly.ffn_pack_h2 = (ar.add(pack_ffn_h2(g(p + 'linear1.weight'), g(p + 'linear2.weight')))       # encoder layer: the block's input is norm1's output
+                              if ffn_h2_range_ok(g(p + 'linear1.weight'), g(p + 'linear1.bias'), g(p + 'linear2.weight'), g(p + 'norm1.weight'), g(p + 'norm1.bias')) else 0)
             for k in range(2):
                 ly.ln_w[k] = ar.add(g(p + 'norm%d.weight' % (k + 1)))
                 ly.ln_b[k] = ar.add(g(p + 'norm%d.bias' % (k + 1)))
@@ -272,6 +340,11 @@ class MDM:
         self._mem_key, self._mem_cond, self._memctx, self._ws = None, None, None, None
         self._ws_shape, self._ws_pool, self._memctx_pool = None, {}, {}
         self.ffn_rows = 0                           # 0: feed-forward tile by batch size (_pick_ffn_tile); 16 / 32: forced
+        # arithmetic of the feed-forward block: 'split' = split-f16 MFMA (csrc/ffn_h2.h: two f16 planes per fp32 operand, three f16 MFMAs per
+        # product, fp32 accumulate -- fp32-grade results, layers whose range proof failed at pack time stay exact); 'exact' = fp32 MFMA (csrc/ffn.h)
+        self.ffn_math = os.environ.get('INTERDIFF_FFN_MATH', FFN_MATH_DEFAULT)
+        if self.ffn_math not in ('split', 'exact'):
+            raise ValueError("ffn_math must be 'split' or 'exact'")
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -387,6 +460,10 @@ class MDM:
         slice is summed in two accumulators) or 16 (the 16- and 64-row kernels, bit-identical to each other)."""
         return 32 if cls.ffn_tile_for_rows(rows) == 32 else 16
 
+    def ffn_graph_key(self, rows):
+        """What a captured launch sequence bakes in about the feed-forward block (the sampler's graph cache key, diffusion.py)."""
+        return (self.ffn_class_for_rows(rows), self.ffn_math, self.ffn_rows)
+
     def _pick_ffn_tile(self, rows, own_rows=None):
         """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to
         rounding, not bit for bit: every launch of one sample must take the same rounding class, whichever way the batch is cut into
@@ -401,6 +478,7 @@ class MDM:
             if tile != 32 and own_rows is not None and own_rows != rows:
                 tile = 16 if own_rows <= self.FFN16_MAX_ROWS else 64
         self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(tile, 1)
+        self.w.tune[_lib.TUNE['ffn_math']] = 1 if getattr(self, 'ffn_math', 'exact') == 'split' else 0
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).

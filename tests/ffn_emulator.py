@@ -300,3 +300,168 @@ def emulate_ln_linear(A_slabs, lnw, lnb, pack, bias, N, late):
                             if gr < M and col < N:
                                 C[gr, col] = acc[(w, j)][rr, cc] + bias[col]
     return C
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# csrc/ffn_h2.h (split-f16 feed-forward kernel), one workgroup, lane by lane: the f16 planes of the packed stream (mdm.py pack_ffn_h2),
+# the ring of K-step slots with the DMA applied early / late, the in-place split of the x2 rows, the plane addressing
+# (chunk t of row r at position t ^ (r & 15)), the v_mfma_f32_16x16x32_f16 operand <-> lane maps with the WEIGHTS as the A operand,
+# the GELU / split / zero-pad phase and the staged output tile.  Products of halves are exact; sums are taken in float64 here, so the
+# result equals the split arithmetic's exact value (the kernel's fp32 accumulation differs from it by rounding only).
+H2_KS1, H2_KS2 = 8, 7
+H2_NPAIR = H2_KS1 + H2_KS2
+H2_P1B, H2_P2B, H2_SLOT = 13 * 2 * 1024, 16 * 2 * 1024, 32768
+H2_SLICE_BYTES = H2_KS1 * H2_P1B + H2_KS2 * H2_P2B
+
+
+def h2_step_off(P):
+    return P * H2_P1B if P < H2_KS1 else H2_KS1 * H2_P1B + (P - H2_KS1) * H2_P2B
+
+
+def h2_step_ins(P):
+    return 0 if P >= H2_NPAIR else (H2_P1B // 1024 if P < H2_KS1 else H2_P2B // 1024)
+
+
+def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
+    from interdiff_amd.mdm import split_f16
+    tt_n = bm // 16
+    S = 2 if bm == 64 else 3
+    M = x2.shape[0]
+    m0 = mt * bm
+    stream = np.frombuffer(np.ascontiguousarray(pack_words).tobytes(), np.uint8)[sl * H2_SLICE_BYTES:(sl + 1) * H2_SLICE_BYTES]
+    planes = np.zeros(bm * 1024, np.uint8)                # Xs: row r at r KiB = [hi 512 B | lo' 512 B]
+    ring = np.full(S * H2_SLOT, 0x7e, np.uint8)           # 0x7e7e = a NaN half: stale bytes must never be multiplied
+    lane = np.arange(64)
+    n, g = lane & 15, lane >> 4
+    pending = {}
+
+    def issue_step(P):
+        nins = h2_step_ins(P)
+        ops = []
+        for wave in range(NW):
+            for j in range(4):
+                i = wave + 8 * j
+                if i < nins:
+                    assert (8 * j + 7 < nins) or (8 * j < nins and wave < 2)
+                    src = h2_step_off(P) + 1024 * i
+                    ops.append(((P % S) * H2_SLOT + 1024 * i, stream[src:src + 1024].copy()))
+        if late and ops:
+            pending[P] = ops
+        else:
+            for dst, data in ops:
+                ring[dst:dst + 1024] = data
+
+    def publish(P):                                        # wait_step(P) + barrier: everything up to step P has landed
+        for Q in sorted(k for k in pending if k <= P):
+            for dst, data in pending.pop(Q):
+                ring[dst:dst + 1024] = data
+
+    def halves(buf, byte_addr):                            # [64 lanes][8] float16 at per-lane byte addresses
+        idx = byte_addr[:, None] + np.arange(16)[None, :]
+        return buf[idx].copy().view(np.float16).astype(np.float64)
+
+    def write_plane_piece(r, chunk, half, hi4, lo4):       # 4 halves (8 bytes) of row r at chunk position chunk ^ (r & 15), second half if `half`
+        a = r * 1024 + ((chunk ^ (r & 15)) << 4) + 8 * half
+        planes[a:a + 8] = np.frombuffer(hi4.astype(np.float16).tobytes(), np.uint8)
+        planes[a + 512:a + 520] = np.frombuffer(lo4.astype(np.float16).tobytes(), np.uint8)
+
+    # prologue: x2 rows as fp32 (row r at r KiB), steps 0 .. S - 2; split in place by the fetching wave
+    rows = np.stack([x2[min(m0 + i, M - 1)] for i in range(bm)]).astype(np.float32)
+    for P in range(S - 1):
+        issue_step(P)
+    for r in range(bm):
+        hi, lo = split_f16(rows[r])
+        for l in range(64):
+            write_plane_piece(r, l >> 1, l & 1, hi[4 * l:4 * l + 4], lo[4 * l:4 * l + 4])
+
+    def read_x(s):                                         # B operand of token tile t: [tt][plane] -> [64][8]
+        out = []
+        for t in range(tt_n):
+            a = (16 * t + n) * 1024 + (((g ^ n) ^ (4 * s)) << 4)
+            out.append((halves(planes, a), halves(planes, a + 512)))
+        return out
+
+    def read_w(P, tile):                                   # A operand: (hi, lo) [64][8]
+        a = (P % S) * H2_SLOT + (tile * 2) * 1024 + lane * 16
+        return halves(ring, a), halves(ring, a + 1024)
+
+    def mfma(acc, a, b):                                   # D[i][nn] += sum_{g, j} A[lane (i, g)][j] * B[lane (nn, g)][j]; acc [16 i][16 nn]
+        A = a.reshape(4, 16, 8)                            # [g][i][j]
+        B = b.reshape(4, 16, 8)                            # [g][n][j]
+        return acc + np.einsum('gij,gnj->in', A, B)
+
+    res = {}                                               # phase-1 results: (wave, a, t) -> [16 hidden][16 token]
+    hid_tiles = {w: ([2 * w, 2 * w + 1] if w < 5 else [5 + w]) for w in range(NW)}
+    accs = {(w, a, t): [np.zeros((16, 16)), np.zeros((16, 16))] for w in range(NW) for a in range(len(hid_tiles[w])) for t in range(tt_n)}
+    frag_prev = None
+    for P in range(H2_KS1 + 1):
+        if P < H2_KS1:
+            publish(P)
+            issue_step(P + S - 1)
+            xs = read_x(P)
+            frag = (xs, {w: [read_w(P, h) for h in hid_tiles[w]] for w in range(NW)})
+        if frag_prev is not None:
+            xs_p, ws_p = frag_prev
+            for w in range(NW):
+                for a, (wh, wl) in enumerate(ws_p[w]):
+                    for t in range(tt_n):
+                        xh, xl = xs_p[t]
+                        m, c = accs[(w, a, t)]
+                        accs[(w, a, t)] = [mfma(m, wh, xh), mfma(mfma(c, wh, xl), wl, xh)]
+        frag_prev = frag if P < H2_KS1 else None
+    publish(H2_KS1)
+    issue_step(H2_KS1 + S - 1)
+    bias = np.asarray(b1p, np.float64)[sl * HS:sl * HS + HS]
+    for w in range(NW):
+        for a, h in enumerate(hid_tiles[w]):
+            for t in range(tt_n):
+                m, c = accs[(w, a, t)]
+                pre = (m + c / 2048.0) + bias[16 * h:16 * h + 16, None]            # [hidden i][token nn]
+                hid = _gelu(pre).astype(np.float32)
+                for nn in range(16):
+                    for gg in range(4):
+                        hi, lo = split_f16(hid[4 * gg:4 * gg + 4, nn])
+                        write_plane_piece(16 * t + nn, 2 * h + (gg >> 1), gg & 1, hi, lo)
+    for tid in range(bm * 4):
+        r, pl, ch = tid >> 2, (tid >> 1) & 1, 26 + (tid & 1)
+        a = r * 1024 + pl * 512 + ((ch ^ (r & 15)) << 4)
+        planes[a:a + 16] = 0
+    # phase 2
+    acc2 = {(w, a, t): [np.zeros((16, 16)), np.zeros((16, 16))] for w in range(NW) for a in range(2) for t in range(tt_n)}
+    frag_prev = None
+    for q in range(H2_KS2 + 1):
+        if q < H2_KS2:
+            if q > 0:
+                publish(H2_KS1 + q)
+                issue_step(H2_KS1 + q + S - 1)
+            xs = read_x(q)
+            frag = (xs, {w: [read_w(H2_KS1 + q, 2 * w + a) for a in range(2)] for w in range(NW)})
+        if frag_prev is not None:
+            xs_p, ws_p = frag_prev
+            for w in range(NW):
+                for a, (wh, wl) in enumerate(ws_p[w]):
+                    for t in range(tt_n):
+                        xh, xl = xs_p[t]
+                        m, c = acc2[(w, a, t)]
+                        acc2[(w, a, t)] = [mfma(m, wh, xh), mfma(mfma(c, wh, xl), wl, xh)]
+        frag_prev = frag if q < H2_KS2 else None
+    assert not pending, 'DMA issued but never waited for: %r' % sorted(pending)
+    out = np.zeros((bm, D))
+    for w in range(NW):
+        for a in range(2):
+            for t in range(tt_n):
+                m, c = acc2[(w, a, t)]
+                out[16 * t:16 * t + 16, 16 * (2 * w + a):16 * (2 * w + a) + 16] = (m + c / 2048.0).T
+    if sl == 0:
+        out = out + rows.astype(np.float64) + np.asarray(b2, np.float64)[None, :]
+    return out[:max(0, min(bm, M - m0))]
+
+
+def emulate_ffn_h2(x2, pack_words, b1p, b2, late, bm=32):
+    M = x2.shape[0]
+    parts = np.zeros((NSL, M, D))
+    for mt in range(-(-M // bm)):
+        for sl in range(NSL):
+            o = emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm)
+            parts[sl, mt * bm:mt * bm + o.shape[0]] = o
+    return parts

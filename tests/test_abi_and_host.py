@@ -234,6 +234,44 @@ def test_ffn_pack_and_kernel_addressing_by_emulation():
             assert err < 1e-9, (bm, late, err)
 
 
+def test_split_f16_ffn_pack_and_kernel_addressing_by_emulation():
+    """The split-f16 feed-forward kernel (csrc/ffn_h2.h) restated lane by lane in numpy (tests/ffn_emulator.py emulate_ffn_h2) on the
+    stream pack_ffn_h2 builds: the f16 planes (hi, residual x 2^11), the [tile][plane][lane][8] fragments, the K-step ring with the DMA
+    applied at issue time and at the covering wait, the in-place split of the x2 rows, the plane addressing, weights as the MFMA's
+    A operand, the GELU / split / zero-pad phase -- sum of the five slabs == x2 + linear2(gelu(linear1(x2))) to the split's own
+    representation error (2^-23 per operand; sums exact in the emulator), all three row tiles, ragged rows.  Also the split itself and
+    the pack-time range proof."""
+    import numpy as np
+    from interdiff_amd.mdm import pack_ffn_h2, pad_ffn_bias, split_f16, ffn_h2_range_ok, H2_SLICE_FLOATS
+    from tests.ffn_emulator import emulate_ffn_h2, _gelu
+    rs = np.random.RandomState(0)
+    v = np.concatenate([rs.standard_normal(4096) * 10.0 ** rs.uniform(-12, 4, 4096), [0.0, -0.0, 2.0 ** -14, 2.0 ** -15, -2.0 ** -24, 65000.0, 1e-30]]).astype(np.float32)
+    hi, lo = split_f16(v)
+    back = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+    assert np.all(np.abs(back - v) <= np.maximum(np.abs(v.astype(np.float64)) * 2.0 ** -23, 2.0 ** -25)), 'v = hi + lo / 2048 to 2^-23 |v| (absolute 2^-25 at the bottom)'
+    nz = hi != 0
+    assert np.all(np.abs(hi[nz].astype(np.float32)) >= 2.0 ** -14), 'no subnormal in the hi plane'
+    M = 37                                                 # ragged in every tile size
+    x2 = rs.standard_normal((M, 256)).astype(np.float32)
+    w1 = (rs.standard_normal((1024, 256)) / 16).astype(np.float32)
+    w2 = (rs.standard_normal((256, 1024)) / 32).astype(np.float32)
+    b1, b2 = rs.standard_normal(1024).astype(np.float32), rs.standard_normal(256).astype(np.float32)
+    pack = pack_ffn_h2(w1, w2)
+    assert pack.dtype == np.float32 and pack.size == 5 * H2_SLICE_FLOATS == 5 * 110592
+    ref = x2.astype(np.float64) + _gelu(x2.astype(np.float64) @ w1.T.astype(np.float64) + b1) @ w2.T.astype(np.float64) + b2
+    outs = []
+    for bm in (32, 16, 64):
+        for late in (False, True):
+            parts = emulate_ffn_h2(x2, pack, pad_ffn_bias(b1), b2, late, bm)
+            err = np.abs(parts.sum(0) - ref).max() / np.abs(ref).max()
+            assert err < 2e-7, (bm, late, err)
+            outs.append(parts)
+    assert all(np.array_equal(outs[0], o) for o in outs[1:]), 'row tile and DMA timing must not change a single element'
+    ones, zeros = np.ones(256, np.float32), np.zeros(256, np.float32)
+    assert ffn_h2_range_ok(w1, b1, w2, ones, zeros)
+    assert not ffn_h2_range_ok(w1 * 400, b1, w2, ones, zeros) and not ffn_h2_range_ok(w1, b1, w2 * 3e6, ones, zeros) and not ffn_h2_range_ok(w1, b1, w2, ones * 5000, zeros)
+
+
 def test_out_projection_fragments_match_the_attention_kernel_addressing():
     """mdm.sa_out_fragments vs the loads of self_attn_kernel<true> (csrc/denoiser.hip): lane (kq, li) of wave `wave` reads, for head h,
     k-group s and column tile c, the float4 at ((((h*4+wave)*4+s)*4+c)*64+lane)*4 and uses element e as W_o[(wave*4+c)*16+li][h*64+16s+4kq+e];
@@ -333,6 +371,9 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
         m.ffn_rows = forced
         MDM._pick_ffn_tile(m, 100)
         assert m.w.tune[k] == code
-    assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched
+    assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched (ffn_math: 'exact' without the attribute)
+    m.ffn_math = 'split'
+    MDM._pick_ffn_tile(m, 100)
+    assert m.w.tune[_lib.TUNE['ffn_math']] == 1
     src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
     assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src

@@ -609,18 +609,24 @@ def test_gemm_f32_epilogues_vs_torch_fp32(lib):
         linear(torch.randn(4, 48).to(DEV), torch.randn(16, 48).to(DEV))          # K % 64 != 0
 
 
+@pytest.mark.parametrize('math', ['exact', 'split'])
 @pytest.mark.parametrize('M', [1, 15, 17, 31, 33, 63, 65, 160, 800, 1600, 3200, 3265])
-def test_fused_ffn_vs_torch_fp64(mdm, M):
+def test_fused_ffn_vs_torch_fp64(mdm, M, math):
     """interdiff_mdm_ffn (csrc/ffn.h: linear1 -> gelu -> linear2 in one launch, five partial slabs summed by the reader) against
     torch CPU float64 on the model's own weights: a decoder layer and an encoder layer, ragged and multi-round row counts, ALL THREE row
     tiles (the 32-row kernel, the 16-row one small batches take, the 64-row one large batches take) and the default pick between them;
-    the 16- and 64-row kernels sum every tile in the same order and must agree bit for bit."""
+    the 16- and 64-row kernels sum every tile in the same order and must agree bit for bit.
+    ``math``: 'exact' = fp32 MFMA (csrc/ffn.h), 'split' = split-f16 MFMA (csrc/ffn_h2.h) -- the SAME 2e-6 gate, the measured errors of
+    both go side by side into the parity log; the split kernel's three row tiles are bit-identical."""
     from interdiff_amd.mdm import ffn_parts
     g = torch.Generator().manual_seed(100 + M)
     x2 = torch.randn(M, 256, generator=g)
     sd = fx.mdm_weights()
     outs = {}
+    keep_math, mdm.ffn_math = mdm.ffn_math, math
+    worst = 0.0
     try:
+        assert all(mdm.w.layer[l].ffn_pack_h2 != 0 for l in range(8)) and all(mdm.w.enc_layer[l].ffn_pack_h2 != 0 for l in range(8)), 'range proof must hold for the test weights'
         for rows in (32, 16, 64, 0):
             mdm.ffn_rows = rows
             for enc, layer, pre in ((False, 1, 'decoder.layers.1.'), (False, 7, 'decoder.layers.7.'), (True, 3, 'encoder.layers.3.')):
@@ -631,7 +637,7 @@ def test_fused_ffn_vs_torch_fp64(mdm, M):
                 w2, b2 = sd[pre + 'linear2.weight'].double(), sd[pre + 'linear2.bias'].double()
                 xd = x2.double()
                 ref = xd + torch.nn.functional.gelu(xd @ w1.T + b1) @ w2.T + b2
-                close(got, ref, 2e-6, 'fused FFN M=%d rows=%d %s' % (M, rows, pre))
+                worst = max(worst, close(got, ref, 2e-6, 'fused FFN (%s) M=%d rows=%d %s' % (math, M, rows, pre)))
                 outs[rows, pre] = parts
             again = ffn_parts(mdm, x2.to(DEV), 1)
             assert torch.equal(again, ffn_parts(mdm, x2.to(DEV), 1)), 'deterministic: no atomics, fixed summation order'
@@ -639,13 +645,17 @@ def test_fused_ffn_vs_torch_fp64(mdm, M):
         for pre in ('decoder.layers.1.', 'decoder.layers.7.', 'encoder.layers.3.'):                   # the default = the documented pick
             assert torch.equal(outs[0, pre], outs[mdm.ffn_tile_for_rows(M), pre])
             assert torch.equal(outs[16, pre], outs[64, pre]), '16- and 64-row kernels: same summation order'
+            if math == 'split':
+                assert torch.equal(outs[16, pre], outs[32, pre]), 'split-f16 kernel: no K split across waves, every row tile gives the same bits'
         mdm.ffn_rows = 0                                       # a chain of a larger batch takes the BATCH's tile
         assert mdm.ffn_tile_for_rows(2700) == 32 and mdm.ffn_tile_for_rows(6400) == 64
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=2700), outs[32, 'decoder.layers.1.'])
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=6400), outs[64, 'decoder.layers.1.'])
         assert torch.equal(ffn_parts(mdm, x2.to(DEV), 1, batch_rows=max(M, 600)), outs[mdm.ffn_tile_for_rows(max(M, 600)), 'decoder.layers.1.'])
+        fx.record_parity('fused_ffn_vs_fp64_%s_M%d' % (math, M), worst_rel_err=worst, asserted=2e-6)
     finally:
         mdm.ffn_rows = 0
+        mdm.ffn_math = keep_math
 
 
 # ------------------------------------------------------------------------------------------ other BASELINE configurations

@@ -416,6 +416,9 @@ int interdiff_optimize_finish(const idf_opt_ctx *c, const idf_opt_state *st, flo
 /* HOST-side instance of the device inline that back-propagates through matrix_to_axis_angle + the SMPL Rodrigues for
  * n joints (R [n][9], g_out [n][9] -> g_in [n][9]); lets the CPU test suite check the derivative code without a GPU. */
 int interdiff_debug_joint_map_vjp(const float *R, const float *g_out, float *g_in, int32_t n);
+/* Diagnostic: n_wg one-wave workgroups each fill 6 KiB of LDS with a pattern and re-read it `spin` times; out[0] counts foreign writes seen,
+ * out[4 + 4 k ..] = {workgroup, word, value found, pass} of the first 1000 (tools/lds_sentinel_probe.py; not used by the product path). */
+int interdiff_debug_lds_sentinel(uint32_t *out, int32_t n_wg, int32_t spin, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Live per-kernel timing for bench.py's `roofline` block (not on the product path).

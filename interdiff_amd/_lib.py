@@ -120,6 +120,7 @@ _SIGS = {
     'interdiff_optimize_step': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp]),
     'interdiff_optimize_finish': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp, vp, vp, vp, vp]),
     'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
+    'interdiff_debug_lds_sentinel': (C.c_int, [vp, i32, i32, vp]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     static_assert(BM * 1024 + S * SLOT + 1024 <= 160 * 1024, "LDS");
     static_assert(TT == 4 ? BM * CSS * 4 <= BM * 1024 + S * SLOT : BM * CSS * 4 <= 2 * SLOT, "output staging");
     extern __shared__ __attribute__((aligned(1024))) float smem[];
+    asm volatile("" ::: "v255");                       // the whole register file: see EXCLUSIVE CU below
     float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
     float *ring = smem + BM * 256, *Bs = ring + S * (SLOT / 4);    // Bs: the slice's linear1 bias (208 floats)
     idf_args_now(x2, M, pack, b1p, b2, parts);
@@ -243,12 +244,17 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     };
 
     // ---- phase 1: hid^T[hidden][token] = W1[slice] . x2^T
+    // The DMA issue is what a K step costs now (26 - 32 instructions per step at the CU's ~20 cycles apiece; the MFMAs of a step are 192
+    // cycles per wave), and a wave sits in its own issue: the two waves of a SIMD (w, w + 4) therefore take turns -- waves 0..3 refill
+    // the ring BEFORE their fragment reads and MFMAs, waves 4..7 AFTER theirs -- so that one wave's issue runs beside the other's matrix work.
+    const bool early = wave < NW / 2;
 #pragma unroll
     for (int P = 0; P < KS1; ++P) {
         publish(P);                                   // (P = 0: also publishes the planes)
-        issue_step(P + S - 1);                        // into the slot of step P - 1
+        if (early) issue_step(P + S - 1);             // into the slot of step P - 1
         read1(P, F[P & 1]);
         if (P > 0) mma(F[(P - 1) & 1], two1);
+        if (!early) issue_step(P + S - 1);
     }
     mma(F[(KS1 - 1) & 1], two1);
 
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 #pragma unroll
     for (int q = 1; q < KS2; ++q) {
         publish(KS1 + q);
-        issue_step(KS1 + q + S - 1);
+        if (early) issue_step(KS1 + q + S - 1);
         if (q == KS2 - 1 && sl == 0) {                // slab 0 carries the residual and the output bias: plain loads, younger than every DMA (the wait above was vmcnt(0))
             bres = *reinterpret_cast<const float4 *>(b2 + ((tid & 63) << 2));
 #pragma unroll
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         }
         read2(q, F[q & 1]);
         mma(F[(q - 1) & 1], true);
+        if (!early) issue_step(KS1 + q + S - 1);
     }
     mma(F[(KS2 - 1) & 1], true);
 
@@ -339,13 +346,22 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     }
 }
 
+// EXCLUSIVE CU.  While this kernel ran beside OTHER kernels' workgroups on the same CU (two streams: the staggered-chains option of
+// diffusion.py, or any second queue), the other kernel occasionally computed wrong values -- reproducer tools/hook_stage_probe.py: the
+// one-wave SMPL pose kernel (6 KiB of LDS) got joints 50 / 51 wrong in ~40 % of the runs, only with this kernel as the neighbour (never
+// with the fp32 kernel of ffn.h, never with this kernel's no-MFMA or no-DMA ablations), while an LDS sentinel beside it (tools/
+// lds_sentinel_probe.py) saw no foreign LDS write.  The mechanism is not established.  The kernel therefore takes its CU for itself:
+// it asks for the whole 160 KiB of LDS and for 256 VGPRs per wave (2 waves per SIMD x 256 = the register file), so that no other
+// workgroup can be resident next to it -- 0 differences in the same probe.  It costs nothing: the grid is one workgroup per CU by design.
+constexpr int LDS_REQUEST = 160 * 1024;
 template <int TT, int S>
 inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {
-    constexpr int BM = 16 * TT, LDS = BM * 1024 + S * SLOT + 1024;
+    constexpr int BM = 16 * TT;
+    static_assert(BM * 1024 + S * SLOT + 1024 <= LDS_REQUEST, "LDS");
     static std::atomic<uint64_t> done{0};
-    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS, done);
+    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS_REQUEST, done);
     if (rc != IDF_OK) return rc;
-    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS, s, x2, M, pack, b1p, b2, parts);
+    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, pack, b1p, b2, parts);
     return IDF_OK;
 }
 // rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits

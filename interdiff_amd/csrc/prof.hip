@@ -51,3 +51,37 @@ extern "C" int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kin
     g_kind.clear();
     return IDF_OK;
 }
+
+// ---- LDS sentinel (tools/lds_sentinel_probe.py): a one-wave workgroup fills its 6 KiB of LDS with a pattern and keeps re-reading it;
+// any word that changes was written by somebody else.  Diagnostic only.
+namespace {
+__global__ __launch_bounds__(64) void lds_sentinel_kernel(uint32_t *__restrict__ out, int spin) {
+    __shared__ uint32_t buf[1536];
+    const int j = threadIdx.x;
+    for (int i = j; i < 1536; i += 64) buf[i] = 0xA5000000u | (uint32_t)i;
+    __syncthreads();
+    for (int it = 0; it < spin; ++it) {
+        for (int i = j; i < 1536; i += 64) {
+            const uint32_t v = buf[i];
+            if (v != (0xA5000000u | (uint32_t)i)) {
+                const uint32_t slot = atomicAdd(out, 1u);
+                if (slot < 1000) {
+                    out[4 + 4 * slot] = blockIdx.x;
+                    out[5 + 4 * slot] = (uint32_t)i;
+                    out[6 + 4 * slot] = v;
+                    out[7 + 4 * slot] = (uint32_t)it;
+                }
+                buf[i] = 0xA5000000u | (uint32_t)i;
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int interdiff_debug_lds_sentinel(uint32_t *out, int32_t n_wg, int32_t spin, void *stream) {
+    if (!out || n_wg <= 0) return IDF_E_INVAL;
+    hipLaunchKernelGGL(lds_sentinel_kernel, dim3((unsigned)n_wg), dim3(64), 0, idf_stream(stream), out, spin);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}

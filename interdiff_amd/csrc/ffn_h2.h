@@ -98,7 +98,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 template <int TT, int S, int MODE = 0>
 __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
                                                      const float *__restrict__ b1p, const float *__restrict__ b2,
-                                                     float *__restrict__ parts) {
+                                                     float *__restrict__ parts, int order) {
     constexpr int BM = 16 * TT;
     static_assert((TT == 1 || TT == 2 || TT == 4) && (S == 2 || S == 3), "geometry");
     static_assert(BM * 1024 + S * SLOT + 1024 <= 160 * 1024, "LDS");
@@ -107,11 +107,20 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     asm volatile("" ::: "v255");                       // the whole register file: see EXCLUSIVE CU below
     float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
     float *ring = smem + BM * 256, *Bs = ring + S * (SLOT / 4);    // Bs: the slice's linear1 bias (208 floats)
-    idf_args_now(x2, M, pack, b1p, b2, parts);
+    idf_args_now(x2, M, pack, b1p, b2, parts, order, gridDim.x);
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BM;
+    // Workgroup order.  order 0 (shipped): ffn.h's M-tile-major ids.  order 1 (A/B only, tools/ffn_h2_ab.py): SLICE-major over XCD-affine
+    // logical ids -- workgroup id runs on XCD id % 8, each with its own 4-MiB L2; giving one XCD consecutive logical ids and walking the
+    // M tiles of one slice before the next slice, an XCD streams one or two of the five 432-KiB slice streams through its L2 (13 slice
+    // loads per launch over the fabric) instead of all five (40).  Measured in one process (profiles/r04_ffn_split_f16_ab.txt): a burst of
+    // launches 10.9 vs 11.4 us, but the denoiser forward 231-236 vs 223-228 us and whole samples 0.2215 vs 0.2207 ms/step -- in situ the
+    // M-tile-major order is no worse, so it stays.
+    const int nwg = gridDim.x, id = blockIdx.x, nmt = nwg / NSL;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int sl = order ? wg / nmt : id % NSL, mt = order ? wg - sl * nmt : id / NSL, m0 = mt * BM;       // order 0: ffn.h's M-tile-major ids (A/B: tools/ffn_h2_ab.py)
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
     const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;                 // this lane's 16 B inside a step: instruction wave + 8 j adds 8192 j
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     // The DMA issue is what a K step costs now (26 - 32 instructions per step at the CU's ~20 cycles apiece; the MFMAs of a step are 192
     // cycles per wave), and a wave sits in its own issue: the two waves of a SIMD (w, w + 4) therefore take turns -- waves 0..3 refill
     // the ring BEFORE their fragment reads and MFMAs, waves 4..7 AFTER theirs -- so that one wave's issue runs beside the other's matrix work.
-    const bool early = wave < NW / 2;
+    const bool early = S == 2 || wave < NW / 2;       // (a two-slot ring has no slack for the late group: its refill would land just before the wait for it)
 #pragma unroll
     for (int P = 0; P < KS1; ++P) {
         publish(P);                                   // (P = 0: also publishes the planes)
@@ -355,19 +364,19 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 // workgroup can be resident next to it -- 0 differences in the same probe.  It costs nothing: the grid is one workgroup per CU by design.
 constexpr int LDS_REQUEST = 160 * 1024;
 template <int TT, int S>
-inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts) {
+inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int order) {
     constexpr int BM = 16 * TT;
     static_assert(BM * 1024 + S * SLOT + 1024 <= LDS_REQUEST, "LDS");
     static std::atomic<uint64_t> done{0};
     const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS_REQUEST, done);
     if (rc != IDF_OK) return rc;
-    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, pack, b1p, b2, parts);
+    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, pack, b1p, b2, parts, order);
     return IDF_OK;
 }
 // rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits
-inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows) {
-    if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts);
-    if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts);
-    return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts);
+inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows, int order) {
+    if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts, order);
+    if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts, order);
+    return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts, order);
 }
 }  // namespace idf_ffn_h2

@@ -42,9 +42,13 @@ def main():
             model.ffn_rows = 0
             row[math + '_err_vs_fp64'] = err_fp64(model, sd, N)
         print('ffn', N, json.dumps(row), flush=True)
-    for rep in range(2):
-        for math in ('exact', 'split'):
-            model.ffn_math = math
+    from interdiff_amd import _lib
+    for rep in range(3):
+        for math in ('split', 'split_slice_major'):
+            model.ffn_math = 'split'
+            model.w.tune[_lib.TUNE['misc']] = 2 if math == 'split_slice_major' else 0
+            if rep == 0:
+                print('burst', math, time_ffn(model, dev, 1600), time_ffn(model, dev, 800), flush=True)
             model.__dict__.pop('_graph_cache', None)
             out = dict(math=math)
             out['forward_us'] = round(bench.time_forward_graph(model, bt, y, dev), 2)

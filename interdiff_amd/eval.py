@@ -13,7 +13,7 @@ elementwise adds outside it: the rendering-only ``smooth`` and the translation r
 """
 import ctypes as C
 import torch
-from . import _lib, dist, transforms as tr
+from . import _lib, dist, io, transforms as tr
 from .dist import METRIC_KEYS
 
 SMPL_DIM = 132          # 22 joints x rot6d (eval_smpl_short.py:416)
@@ -73,9 +73,21 @@ def _x_T(gt, seed, shard=None):
     return torch.randn(total, *gt.shape[1:], device=gt.device, generator=gen)[first:first + gt.shape[0]].contiguous()
 
 
+def as_clip_batch(model, batch, past_len=10):
+    """The reference hands its entry points the DataLoader's batch -- a dict of per-frame lists (data/dataset_smpl.py:182-204;
+    ``sample_once_proj(batch)``, eval_smpl_short.py:133-150).  Such a batch goes through ``io.batch_from_dataset`` (the stacks of
+    model/diffusion_smpl.py:197-201) and the HIP conditioning path (``batch_from_raw``); a clip batch of this module's tensor schema
+    passes through."""
+    if io.is_dataset_batch(batch):
+        return batch_from_raw(model, io.batch_from_dataset(batch, device=model.device), past_len)
+    return batch
+
+
 def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=None, **loop_kw):
     """Full InterDiff: diffusion + correction hook.  Returns (obj_pred [T,B,6], body_pred [T,B,159], verts [T,B,V,3],
-    jtr [T,B,J,3], pelvis [T,B,3]) like the reference (:177).  ``noise`` / ``step_noise`` / ``seed`` make it deterministic."""
+    jtr [T,B,J,3], pelvis [T,B,3]) like the reference (:177).  ``noise`` / ``step_noise`` / ``seed`` make it deterministic.
+    ``batch``: a clip batch (module docstring) or the DataLoader's dict-of-lists batch, as the reference passes it."""
+    batch = as_clip_batch(model, batch, past_len)
     gt = batch['gt']
     if noise is None:
         noise = _x_T(gt, loop_kw.get('seed'), loop_kw.get('shard'))
@@ -86,6 +98,7 @@ def sample_once_proj(model, diffusion, correction, batch, past_len=10, noise=Non
 
 def sample_once(model, diffusion, smpl, batch, past_len=10, noise=None, **loop_kw):
     """Diffusion only (mode no_correction, :179-215)."""
+    batch = as_clip_batch(model, batch, past_len)
     gt = batch['gt']
     if noise is None:
         noise = _x_T(gt, loop_kw.get('seed'), loop_kw.get('shard'))
@@ -215,6 +228,7 @@ def evaluate_batch(model, diffusion, correction, batch, past_len=10, mode='corre
     given (reproducible), otherwise one fresh 62-bit seed per draw from torch's global generator.  A fixed ``noise`` (x_T) with
     ``diverse_samples > 1`` therefore still gives different samples."""
     smpl = correction.smpl
+    batch = as_clip_batch(model, batch, past_len)
     obj_gt, jtr_gt, body_gt, faces = get_gt(batch, smpl)
     met = Metrics(correction)
     best = None

@@ -377,3 +377,80 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
     assert m.w.tune[_lib.TUNE['ffn_math']] == 1
     src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
     assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src
+
+
+def test_io_lightning_checkpoint_reproduces_the_committed_fixture(tmp_path):
+    """interdiff_amd.io.load_lightning_state_dict on the reference's REAL checkpoints/correction.ckpt (a pytorch-lightning 1.7 file,
+    ``LitInteraction.load_from_checkpoint``: eval_smpl_short.py:425-426, train_correction_smpl.py:24-40) must give, array for array and
+    byte for byte, what tests/golden/correction_ckpt.npz holds (the fixture every ObjProjector test and bench.py load).  Skipped where
+    the reference tree is absent (the GPU box); a synthetic ``.ckpt`` of the same layout is always checked."""
+    from interdiff_amd import io as iio
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'correction_ckpt.npz'))
+    fake = str(tmp_path / 'fake.ckpt')
+    torch.save({'state_dict': {'model.' + k: torch.from_numpy(z[k]) for k in z.files[:5]} | {'other.w': torch.zeros(2)}, 'hyper_parameters': {'x': 1},
+                'pytorch-lightning_version': '1.7.1'}, fake)
+    sd = iio.load_lightning_state_dict(fake)
+    assert sorted(sd) == sorted(z.files[:5]) and all(np.array_equal(sd[k].numpy(), z[k]) for k in sd)
+    with pytest.raises(ValueError):
+        iio.load_lightning_state_dict(fake, prefix='nothing.')
+    iio.state_dict_to_npz(sd, str(tmp_path / 'sd.npz'))
+    back = iio.load_state_dict_npz(str(tmp_path / 'sd.npz'))
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    real = '/root/reference/interdiff/checkpoints/correction.ckpt'
+    if not os.path.exists(real):
+        pytest.skip('reference checkpoint not on this box')
+    sd = iio.load_lightning_state_dict(real)
+    assert sorted(sd) == sorted(z.files) and len(sd) == 196
+    for k in z.files:
+        a = sd[k].numpy()
+        assert a.dtype == z[k].dtype and a.shape == z[k].shape and a.tobytes() == z[k].tobytes(), k
+    iio.state_dict_to_npz(sd, str(tmp_path / 'real.npz'))
+    z2 = np.load(str(tmp_path / 'real.npz'))
+    assert all(z2[k].tobytes() == z[k].tobytes() for k in z.files)
+
+
+def test_io_smplh_npz_and_dataset_batch_adaptor(tmp_path):
+    """``load_smplh_npz``: the seven SMPL_Layer buffers (smpl_layer.py:47-69) from an .npz, in this package's naming and in the official
+    SMPL+H release's (``f``, ``kintree_table`` [2,J], 16 shape components, flat posedirs).  ``batch_from_dataset``: the DataLoader
+    batch of data/dataset_smpl.py:182-204 (dict of per-frame lists) -> the stacks the reference builds itself
+    (model/diffusion_smpl.py:197-201, eval_smpl_short.py:145-150)."""
+    from interdiff_amd import io as iio
+    from interdiff_amd import synthetic as syn
+    m = syn.smplh_model(7)
+    p1 = str(tmp_path / 'ours.npz')
+    iio.save_smplh_npz(p1, m)
+    a = iio.load_smplh_npz(p1)
+    for k in iio.SMPLH_KEYS:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(m[k]).reshape(a[k].shape)), k
+    V, J = a['v_template'].shape[0], a['weights'].shape[1]
+    rs = np.random.RandomState(0)
+    sd16 = np.concatenate([np.asarray(m['shapedirs'], np.float32), rs.standard_normal((V, 3, 6)).astype(np.float32)], axis=2)
+    par = np.asarray(m['parents']).astype(np.int64)
+    kt = np.stack([np.where(par < 0, 4294967295, par), np.arange(J)]).astype(np.uint32)
+    p2 = str(tmp_path / 'official.npz')
+    np.savez(p2, v_template=m['v_template'], shapedirs=sd16, posedirs=np.asarray(m['posedirs']).reshape(V * 3, -1), J_regressor=m['J_regressor'],
+             weights=m['weights'], kintree_table=kt, f=np.asarray(m['faces']).astype(np.uint32))
+    b = iio.load_smplh_npz(p2)
+    for k in iio.SMPLH_KEYS:
+        assert np.array_equal(b[k], a[k]), k
+    with pytest.raises(ValueError):
+        np.savez(str(tmp_path / 'bad.npz'), **{**{k: np.asarray(m[k]) for k in iio.SMPLH_KEYS}, 'weights': np.asarray(m['weights'])[:, :40]})
+        iio.load_smplh_npz(str(tmp_path / 'bad.npz'))
+    # dataset batch: T records of collated tensors
+    T, B, P = 5, 3, 7
+    g = torch.Generator().manual_seed(0)
+    frames = [dict(smplfit_params=dict(pose=torch.randn(B, 156, generator=g).double(), betas=torch.randn(B, 10, generator=g), trans=torch.randn(B, 3, generator=g)),
+                   objfit_params=dict(angle=torch.randn(B, 3, generator=g).double(), trans=torch.randn(B, 3, generator=g).double()),
+                   pelvis=torch.zeros(B, 3)) for _ in range(T)]
+    batch = dict(frames=frames, obj_points=torch.randn(B, P, 6, generator=g).double(), gender=['male'] * B)
+    assert iio.is_dataset_batch(batch) and not iio.is_dataset_batch(dict(gt=0))
+    raw = iio.batch_from_dataset(batch)
+    pose = torch.cat([f['smplfit_params']['pose'].unsqueeze(0) for f in frames], dim=0).float()           # the reference's own expressions
+    assert torch.equal(raw['body_pose'], pose[..., :66]) and torch.equal(raw['hand_pose'], pose[..., 66:])
+    assert torch.equal(raw['body_trans'], torch.cat([f['smplfit_params']['trans'].unsqueeze(0) for f in frames], dim=0).float())
+    assert torch.equal(raw['obj_angles'], torch.cat([f['objfit_params']['angle'].unsqueeze(0) for f in frames], dim=0).float())
+    assert torch.equal(raw['obj_trans'], torch.cat([f['objfit_params']['trans'].unsqueeze(0) for f in frames], dim=0).float())
+    assert torch.equal(raw['beta'], torch.stack([f['smplfit_params']['betas'] for f in frames], dim=0))
+    assert torch.equal(raw['obj_points'], batch['obj_points'][:, :, :3].float())
+    assert all(v.dtype == torch.float32 and v.is_contiguous() for v in raw.values())
+    assert raw['body_pose'].shape == (T, B, 66) and raw['beta'].shape == (T, B, 10) and raw['obj_points'].shape == (B, P, 3)

@@ -1512,3 +1512,32 @@ print('RCCL_OK ' + json.dumps(info))
     info = json.loads(p.stdout.split('RCCL_OK ', 1)[1].splitlines()[0])
     assert info['backend'] == 'nccl' and info['rccl_version']
     fx.record_parity('rccl_single_rank_all_gather', ok=1.0, rccl_version=str(info['rccl_version']))
+
+
+@pytest.mark.gpu
+def test_dataset_batch_form_is_a_drop_in(mdm, smpl):
+    """``sample_once_proj(batch)`` / ``sample_once(batch)`` with the DataLoader's dict-of-lists batch, as the reference calls them
+    (eval_smpl_short.py:133-150,179-215; data/dataset_smpl.py:182-204), equal the stacked-tensor form bit for bit; ``evaluate_batch`` takes it too."""
+    from interdiff_amd import eval as ev, synthetic as syn
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P, past, steps = 16, 3, 128, fx.PAST, 20
+    ei = {k: torch.from_numpy(v) for k, v in syn.make_embedding_inputs(seed=9, B=B, T=T, n_points=P).items()}
+    g = torch.Generator().manual_seed(3)
+    hand, beta = 0.1 * torch.randn(T, B, 90, generator=g), torch.randn(1, B, 10, generator=g).expand(T, B, 10).contiguous()
+    frames = [dict(smplfit_params=dict(pose=torch.cat([ei['body_pose'][t], hand[t]], dim=1), betas=beta[t], trans=ei['body_trans'][t]),
+                   objfit_params=dict(angle=ei['obj_angles'][t].double(), trans=ei['obj_trans'][t].double())) for t in range(T)]
+    ds_batch = dict(frames=frames, obj_points=torch.cat([ei['obj_points'], torch.zeros(B, P, 3)], dim=2), gender=['male'] * B)
+    raw = dev(dict(ei, hand_pose=hand, beta=beta))
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=steps)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', steps)
+    clip = ev.batch_from_raw(model, raw, past)
+    a = ev.sample_once_proj(model, diff, corr, clip, past, seed=4)
+    b = ev.sample_once_proj(model, diff, corr, ds_batch, past, seed=4)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    a = ev.sample_once(model, diff, smpl, clip, past, seed=5)
+    b = ev.sample_once(model, diff, smpl, ds_batch, past, seed=5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ma, mb = ev.evaluate_batch(model, diff, corr, clip, past, seed=6), ev.evaluate_batch(model, diff, corr, ds_batch, past, seed=6)
+    assert all(torch.equal(ma[k], mb[k]) for k in ma)

@@ -136,10 +136,10 @@ typedef struct {
 } idf_mdm_layer;
 
 typedef struct {
-    int32_t C;                 /* token width (144)                                      */
+    int32_t C;                 /* token width (144; 106 for the skeleton tokens of config #1) */
     int32_t n_steps;           /* rows of temb_table                                     */
     const float *arena;
-    int64_t in_w, in_b;        /* [256][C] = [bodyEmbedding | objEmbedding], summed bias  */
+    int64_t in_w, in_b;        /* [256][(C + 3) & ~3] = [bodyEmbedding | objEmbedding | 0], summed bias  */
     int64_t out_w, out_b;      /* [C][256] = [bodyFinalLinear ; objFinalLinear]          */
     int64_t temb_table;        /* [n_steps][256] = time_embed(pe[t]) (weights-only const) */
     int64_t pe;                /* [max_T][256] positional table rows 0..max_T-1          */
@@ -188,7 +188,7 @@ int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, in
 /* x [B,1,C,T], ts int64 [B] -> x0 [B,1,C,T].
  * Size limits (IDF_E_INVAL beyond them): T <= 208 -- the temporal self-attention of the two standard layers parks K and V of one
  * (clip, head) in one CU's LDS (2 x T x 68 floats + the score tile = 149 KiB at T = 208); T <= max_T of the packed positional table;
- * C <= 256 and C % 4 == 0.  The reference itself is bounded only by PositionalEncoding(max_len=5000) (model/layers.py:11); its
+ * C <= 256 (any width: W_in's rows are packed zero-padded to a multiple of 4 floats, mdm.py; BASELINE config #1 has C = 106).  The reference itself is bounded only by PositionalEncoding(max_len=5000) (model/layers.py:11); its
  * datasets use T = 35 (eval_smpl_short.py:376-377) and BASELINE.json T = 100.  B is unbounded (clips are independent). */
 int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x,
                           const int64_t *ts, int32_t B, int32_t T, float *x0,

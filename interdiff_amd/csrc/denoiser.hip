@@ -850,7 +850,7 @@ extern "C" size_t interdiff_mdm_encode_workspace_bytes(int32_t B, int32_t Tp) {
 extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, const float *x_past, int32_t B, int32_t Tp,
                                     float *cond, void *ws, size_t ws_bytes, void *stream) {
     if (!w || !pc || !x_past || !cond || !ws || B <= 0 || Tp <= 0) return IDF_E_INVAL;
-    if (!w->has_encoder || Tp > w->max_T || Tp > ATTN_MAX_T || w->C > 256 || (w->C & 3)) return IDF_E_INVAL;
+    if (!w->has_encoder || Tp > w->max_T || Tp > ATTN_MAX_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_encode_workspace_bytes(B, Tp)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const float *ar = w->arena;
@@ -860,9 +860,10 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)idf_cdiv(B, 256)), dim3(256), 0, s, iota, B);
     {
         Args g{};
-        g.A = x_past; g.K = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
+        g.A = x_past; g.K = (C + 3) & ~3; g.Ka = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
         g.ts = iota; g.temb = pc; g.pe = ar + w->pe; g.n_steps = B;            // "+ temb[ts[b]]" adds pc[b]
-        launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
+        if (C & 3) launch<32, 64, 2, 2, 32, A_TOKT_R, E_EMBED>(s, g);           // (W_in is packed with its rows zero-padded to a multiple of 4: mdm.py)
+        else launch<32, 64, 2, 2, 32, A_TOKT, E_EMBED>(s, g);
     }
     const float *u_in = k.uA;                  // layer input: plain [N,256] for layer 0, then the FFN's partial slabs
     int u_np = 1;
@@ -916,7 +917,7 @@ struct StepPost {
 int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
                      void *ws, size_t ws_bytes, void *stream, const StepPost &post) {
     if (!w || !memctx || !x || !ts || (!x0 && !post.x) || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
-    if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || (w->C & 3)) return IDF_E_INVAL;
+    if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_workspace_bytes(B, T)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const float *ar = w->arena;
@@ -927,9 +928,13 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
 
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
         Args g{};
-        g.A = x; g.K = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
+        // token width C: any (BASELINE config #1, the HO-GCN skeleton tokens of model/diffusion_skeleton.py:236-253, has C = 106); W_in is packed
+        // with rows of (C + 3) & ~3 floats, zero-padded (mdm.py), and a width that is no multiple of 4 takes the guarded gather (gemm.h A_TOKT_R)
+        g.A = x; g.K = (C + 3) & ~3; g.Ka = C; g.W = ar + w->in_w; g.bias = ar + w->in_b; g.C = k.uA; g.ldc = D; g.M = N; g.N = D; g.T = T;
         g.ts = ts; g.temb = ar + w->temb_table; g.pe = ar + w->pe; g.n_steps = w->n_steps;
         idf_prof_mark(IDF_K_EMBED, s);
+        if (C & 3) launch<32, 64, 2, 2, 32, A_TOKT_R, E_EMBED>(s, g);
+        else
         // K = 144: KC = 144 is the whole contraction in ONE chunk -- every operand load of the workgroup in flight at once (one memory
         // round trip instead of one per 32-deep chunk of the double buffer)
         switch (tune[IDF_TUNE_GEMM_EMBED]) {

@@ -19,13 +19,15 @@
 
 namespace idf_gemm {
 
-enum { A_PLAIN = 0, A_LN = 1, A_TOKT = 2 };
+enum { A_PLAIN = 0, A_LN = 1, A_TOKT = 2, A_TOKT_R = 3 };      // A_TOKT_R: token gather for a token width that is no multiple of 4 (Args.Ka)
+constexpr bool is_tokt(int a) { return a == A_TOKT || a == A_TOKT_R; }
 enum { E_BIAS = 0, E_GELU = 1, E_RESID = 2, E_HEADS = 3, E_EMBED = 4, E_HEADS_POST = 5, E_HEADS_POST_RAGGED = 6 };      // 6: E_HEADS_POST for T % 4 != 0 (per-row update)
 constexpr bool is_post(int epi) { return epi == E_HEADS_POST || epi == E_HEADS_POST_RAGGED; }
 
 struct Args {
     const float *A;
     int lda, K;
+    int Ka;                         // A_TOKT_R: channels of the gathered tensor x [b][Ka][t] (K = Ka rounded up to 4: W's zero-padded row length)
     const float *lnw, *lnb;         // A_LN (null lnw: rows copied unnormalised)
     size_t a_pstride;               // A_LN with NP > 1 (template parameter): A is NP partial slabs a_pstride floats apart, summed on load (common.h ld4_sum)
     const float *W;                 // [N][K]
@@ -350,6 +352,19 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
                         v.w = p[(size_t)3 * g.T];
                     }
                     areg[i] = v;
+                } else if constexpr (APRO == A_TOKT_R) {      // x has Ka channels (BASELINE config #1: 106); channels Ka .. K-1 are zeros against W's zero columns
+                    const int row = f % BM, q = f / BM, m = m0 + row, k = kc * KC + q * 4, Ka = g.Ka;
+                    float4 v = zero4();
+                    if (m < M && k < Ka) {
+                        const int b = m / g.T, t = m - b * g.T;
+                        const float *p = g.A + ((size_t)b * Ka + k) * g.T + t;
+                        const float y = p[(size_t)min(1, Ka - 1 - k) * g.T], z = p[(size_t)min(2, Ka - 1 - k) * g.T], w_ = p[(size_t)min(3, Ka - 1 - k) * g.T];
+                        v.x = p[0];
+                        v.y = k + 1 < Ka ? y : 0.f;
+                        v.z = k + 2 < Ka ? z : 0.f;
+                        v.w = k + 3 < Ka ? w_ : 0.f;
+                    }
+                    areg[i] = v;
                 } else {
                     const int row = f / QC, q = f % QC, m = m0 + row, k = kc * KC + q * 4;
                     areg[i] = (m < M && k < K) ? ld4(g.A + (size_t)m * g.lda + k) : zero4();
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const Args g) {
         for (int i = 0; i < LA; ++i) {
             const int f = tid + NT * i;
             if ((BM * QC) % NT == 0 || f < BM * QC) {
-                const int row = APRO == A_TOKT ? f % BM : f / QC, q = APRO == A_TOKT ? f / BM : f % QC;
+                const int row = is_tokt(APRO) ? f % BM : f / QC, q = is_tokt(APRO) ? f / BM : f % QC;
                 *reinterpret_cast<float4 *>(As + (buf * QC + q) * AQ + row * 4) = areg[i];
             }
         }

@@ -211,7 +211,7 @@ class GaussianDiffusion:
                 st.graphs[(k, fused, split)] = g
             return st.graphs[(k, fused, split)]
         st.x.copy_(img)
-        if elem0 % 4 or per_clip % 4:
+        if elem0 % 4:                               # (chain offsets inside the batch may be odd when T % 4 != 0: the per-row form of the fused update takes any offset)
             raise ValueError('a shard must start at a multiple of 4 elements (C * T = %d per clip)' % per_clip)
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, elem0, 0], dtype=torch.int64))
         gate = getattr(denoised_fn, 'is_active', None)
@@ -406,7 +406,7 @@ class GaussianDiffusion:
         first, total = (0, shape[0]) if shard is None else shard
         per_clip = int(np.prod(shape[1:]))
         elem0 = first * per_clip
-        if shard is not None and (elem0 % 4 or per_clip % 4):
+        if shard is not None and elem0 % 4:
             raise ValueError('a shard must start at a multiple of 4 elements (C * T = %d per clip)' % per_clip)
         if noise is not None:
             img = noise.clone().contiguous().float()             # NOT inpainted when given (:691-692)

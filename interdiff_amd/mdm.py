@@ -231,7 +231,9 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
     w = _lib.MdmWeights()
     win = np.concatenate([g('bodyEmbedding.weight'), g('objEmbedding.weight')], axis=1)      # [256, C]
     w.C = win.shape[1]
-    w.in_w = ar.add(win)                       # [256][C]: the embed GEMM's W[N][K]
+    if win.shape[1] % 4:                       # any token width (BASELINE config #1: 106): rows zero-padded to a multiple of 4 floats, the kernel zero-fills x's missing channels
+        win = np.concatenate([win, np.zeros((win.shape[0], (-win.shape[1]) % 4), np.float32)], axis=1)
+    w.in_w = ar.add(win)                       # [256][(C + 3) & ~3]: the embed GEMM's W[N][K]
     w.in_b = ar.add(g('bodyEmbedding.bias') + g('objEmbedding.bias'))
     w.out_w = ar.add(np.concatenate([g('bodyFinalLinear.weight'), g('objFinalLinear.weight')], axis=0))
     w.out_b = ar.add(np.concatenate([g('bodyFinalLinear.bias'), g('objFinalLinear.bias')]))

@@ -960,6 +960,54 @@ def test_config1_skeleton_plumbing_sampler(lib):
 
 
 @pytest.mark.gpu
+def test_config1_skeleton_tokens_through_the_denoiser_kernels(lib):
+    """BASELINE config #1 through the REAL kernels: the denoiser with the HO-GCN skeleton's token width C = 106
+    (21 x 3 body keypoints | 12 x 3 object keypoints | 7-D object pose; model/diffusion_skeleton.py:7-13,236-253: ``bodyEmbedding`` reads the
+    63 body channels, ``objEmbedding`` the 36 object keypoints -- the pose channels are not embedded: zero columns here --, the same
+    8-layer decoder, ``bodyFinalLinear`` / ``objFinalLinear`` heads), synthetic weights, against oracle/denoiser.py: one forward at
+    B = 1, T = 20 / 30 (odd M, T % 4 != 0 too) and the 50-step sampler loop of eval_skeleton_no_correction.py (identity denoised_fn :82-83,
+    ``--diffusion_steps 50`` = a 50-step cosine schedule) on the eager AND the graph route (fused steps, in-kernel update over 106 channels).
+    ``calc_obj_pred`` (:225-233, a rigid transform of the object's base keypoints by the predicted pose) is glue outside the
+    denoiser and not restated."""
+    from interdiff_amd import synthetic as syn
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    sd = {k: torch.from_numpy(v) for k, v in syn.mdm_state_dict(233).items()}
+    g = torch.Generator().manual_seed(106)
+    n_body, n_obj = 63, 43
+    sd['bodyEmbedding.weight'] = torch.randn(256, n_body, generator=g) / n_body ** 0.5
+    sd['objEmbedding.weight'] = torch.cat([torch.randn(256, 36, generator=g) / 6.0, torch.zeros(256, 7)], dim=1)
+    sd['bodyFinalLinear.weight'], sd['bodyFinalLinear.bias'] = torch.randn(n_body, 256, generator=g) / 16.0, 0.1 * torch.randn(n_body, generator=g)
+    sd['objFinalLinear.weight'], sd['objFinalLinear.bias'] = torch.randn(n_obj, 256, generator=g) / 16.0, 0.1 * torch.randn(n_obj, generator=g)
+    steps = 50
+    model = MDM(sd, device=DEV, n_steps=steps)
+    assert model.w.C == 106
+    for B, T in ((1, 20), (1, 30), (3, 21)):
+        x, ts, cond = torch.randn(B, 1, 106, T, generator=g), torch.randint(0, steps, (B,), generator=g), torch.randn(10, B, 256, generator=g)
+        got = model(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+        ref = oden.mdm_forward(sd, x, ts, cond, n_body=n_body)
+        close(got, ref, 1e-4, 'C=106 denoiser forward B=%d T=%d' % (B, T))
+    B, T = 1, 20
+    gt, noise, cond = torch.randn(B, 1, 106, T, generator=g), torch.randn(B, 1, 106, T, generator=g), torch.randn(10, B, 256, generator=g)
+    mask = torch.ones(B, 1, 106, T, dtype=torch.bool)
+    mask[..., fx.PAST:] = False
+    y = dict(cond=cond, inpainting_mask=mask, inpainted_motion=gt)
+    sa, sb = fx.NoiseStream(62), fx.NoiseStream(62)
+    ref = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond'], n_body=n_body), (B, 1, 106, T), odf.make_schedule(steps), noise.clone(),
+                            lambda i, x: sa.next_like(x), {'y': y}, denoised_fn=lambda x, t, kw: x)
+    diff = create_gaussian_diffusion('cosine', steps)
+    got = diff.p_sample_loop(model, (B, 1, 106, T), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)},
+                             denoised_fn=lambda x, t, kw: x, step_noise=lambda i, x: sb.next_like(x).to(DEV))
+    e = close(got, ref, 1e-4, 'config #1: 50-step chain through the C=106 denoiser kernels vs oracle')
+    # graph route (fused plain steps with the update inside the last GEMM, in-kernel noise) == eager route fed the same Philox stream
+    timed = diff.p_sample_loop(model, (B, 1, 106, T), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)}, seed=17)
+    eager = diff.p_sample_loop(model, (B, 1, 106, T), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)}, use_graph=False,
+                               step_noise=_philox_step(lib, 17))
+    assert torch.equal(timed, eager), 'C=106 graph route differs from eager: %g' % (timed - eager).abs().max()
+    fx.record_parity('config1_skeleton_C106_B1_T20_50steps_vs_oracle', worst_rel_err=e, asserted=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,T', [(1, 11), (2, 16), (3, 17), (1, 49), (5, 64), (2, 208), (64, 20)])
 def test_denoiser_edge_sizes(mdm, B, T):
     """Ragged tiles everywhere: T below / at / just above one 16-token row block, M = B*T not a multiple of any GEMM tile,

@@ -321,6 +321,13 @@ int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt
                          int32_t B, int32_t T, float blend_t /* t/1000 */,
                          uint8_t *condition, int32_t *contact, float *distance, float *loss,
                          void *ws, size_t ws_bytes, void *stream);
+/* The same hook with its one per-call scalar read on the DEVICE: blend weight = table[state[0]][3] (the sampler's coefficient table
+ * {c1, c2, sigma, t/1000} and state {t, ...} of interdiff_posterior_step_dev), no debug outputs.  Every launch parameter is then
+ * independent of the timestep, so ONE captured hipGraph of a whole hook step -- denoiser forward, inpaint, this, posterior update --
+ * serves all eleven corrected steps of a sample (t <= 500, t % 50 == 0: host-known, eval_smpl_short.py:85). */
+int interdiff_correction_dev(const idf_correction_ctx *c, float *x0, const float *gt, const float *hand_pose,
+                             const float *beta, const float *obj_points, int32_t B, int32_t T, const float *table,
+                             const int64_t *state, void *ws, size_t ws_bytes, void *stream);
 
 /* The nearest-vertex scan of the hook / the metrics on its own (tools.point2point_signed's object->human half, tools.py:45-76, fused
  * with the object transform eval_smpl_short.py:107): verts [T*B][V][3] (frame n = t*B + b), obj_points [B][P][3] canonical, objR [T*B][9]

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -110,6 +110,7 @@ _SIGS = {
     'interdiff_correction_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_correction': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, i32, i32, f32,
                                        vp, vp, vp, vp, vp, sz, vp]),
+    'interdiff_correction_dev': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
     'interdiff_metrics_workspace_bytes': (sz, [C.POINTER(CorrectionCtx), i32, i32]),
     'interdiff_metrics': (C.c_int, [C.POINTER(CorrectionCtx), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                     vp, vp, sz, vp]),

@@ -2,6 +2,7 @@
 ``interdiff_correction`` entry point.  ``HipCorrection`` owns the packed SMPL model, mesh adjacency,
 ObjProjector and workspace; calling it mutates and returns ``x`` like the reference does (:129-130)."""
 import ctypes as C
+import itertools
 import numpy as np
 import torch
 from . import _lib
@@ -14,6 +15,9 @@ MARKERS67 = [3470, 3171, 3327, 857, 1812, 628, 182, 3116, 3040, 239,
              6540, 6488, 3749, 5135, 5194, 3512, 5635, 5210, 4360, 4841,
              6786, 5573, 4538, 4544, 6736, 6747, 4804, 5568, 6544, 6682,
              5322, 4927, 5686, 4598, 6633, 3506, 3508]      # markerset_ssm67_smplh, data/utils.py:232-238
+
+
+_UID = itertools.count(1)
 
 
 def correction_gate(t0):
@@ -42,6 +46,26 @@ class HipCorrection:
         self.ctx = ctx
         self._ws = {}
         self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call
+        self._uid = next(_UID)       # names this hook in the sampler's per-shape graph cache (never reused, unlike id())
+
+    graph_capturable = True          # apply_dev() enqueues kernels only, every launch parameter independent of the timestep: the sampler captures whole hook steps
+
+    def workspace_for(self, B, T):
+        """A workspace of the hook for (B, T) that the CALLER owns (the sampler's graph cache: its address is baked into captured graphs)."""
+        return torch.empty(self.lib.interdiff_correction_workspace_bytes(C.byref(self.ctx), B, T), dtype=torch.uint8, device=self.device)
+
+    def apply_dev(self, x, table, state, y, ws):
+        """``apply`` with the blend weight t / 1000 read on the device from the sampler's coefficient table at its current timestep
+        (``table[state[0]][3]``, interdiff_correction_dev) and a caller-owned workspace: hipGraph-capturable, one capture serves every
+        corrected step.  ``y``: dict(inpainted_motion, hand_pose, beta, obj_points) of contiguous float tensors."""
+        B, _, Cc, T = x.shape
+        if y['obj_points'].shape[1] != self.ctx.n_points:
+            raise ValueError('obj_points must have %d points' % self.ctx.n_points)
+        _lib.check(self.lib.interdiff_correction_dev(C.byref(self.ctx), _lib.dptr(x, torch.float32), _lib.dptr(y['inpainted_motion'], torch.float32),
+                                                     _lib.dptr(y['hand_pose'], torch.float32), _lib.dptr(y['beta'], torch.float32),
+                                                     _lib.dptr(y['obj_points'], torch.float32), B, T, _lib.dptr(table), _lib.dptr(state),
+                                                     _lib.dptr(ws), ws.numel(), _lib.stream()), 'correction_dev')
+        return x
 
     def _workspace(self, B, T):
         """One workspace per STREAM the hook is called on: the sampler calls it for the two halves of a batch on two streams at once."""

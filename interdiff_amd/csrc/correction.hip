@@ -590,8 +590,12 @@ __global__ __launch_bounds__(128) void corr_reduce_kernel(const float *__restric
 }
 
 // ---- K7: blend (eval_smpl_short.py:127-129): x = a*x + (1-a)*[body, proj] where condition ------------
+// a: the blend weight t / 1000 by value, or -- a_table != null -- read on the device as a_table[state[0] * 4 + 3] (the sampler's
+// coefficient table and state: a captured hipGraph of a whole hook step then serves every timestep)
 __global__ __launch_bounds__(256) void corr_blend_kernel(float *__restrict__ x0, const float *__restrict__ proj,
-                                                         const uint8_t *__restrict__ condition, int B, int T, float a) {
+                                                         const uint8_t *__restrict__ condition, int B, int T, float a,
+                                                         const float *__restrict__ a_table, const int64_t *__restrict__ a_state) {
+    if (a_table) a = a_table[a_state[0] * 4 + 3];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)B * CTOK * T) return;
     const int b = (int)(i / (CTOK * T)), r = (int)(i - (int64_t)b * CTOK * T), c = r / T, t = r - c * T;
@@ -755,10 +759,10 @@ extern "C" size_t interdiff_correction_workspace_bytes(const idf_correction_ctx 
     return carve(c, B, T, nullptr).total;
 }
 
-extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt, const float *hand_pose,
-                                    const float *beta, const float *obj_points, int32_t B, int32_t T, float blend_t,
-                                    uint8_t *condition, int32_t *contact, float *distance, float *loss, void *ws,
-                                    size_t ws_bytes, void *stream) {
+static int correction_impl(const idf_correction_ctx *c, float *x0, const float *gt, const float *hand_pose,
+                           const float *beta, const float *obj_points, int32_t B, int32_t T, float blend_t, const float *blend_table,
+                           const int64_t *blend_state, uint8_t *condition, int32_t *contact, float *distance, float *loss, void *ws,
+                           size_t ws_bytes, void *stream) {
     if (!c || !c->smpl || !c->objproj || !x0 || !gt || !hand_pose || !beta || !obj_points || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
     const int V = c->smpl->V, M = c->n_markers, P = c->n_points;
     if (c->smpl->J != 52 || c->smpl->n_betas != 10 || M > MAXM || M != c->objproj->P || P > MAXP || T != c->objproj->T ||
@@ -786,10 +790,24 @@ extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, cons
     if (rc) return rc;
     idf_prof_mark(IDF_K_CORR_BLEND, s);
     hipLaunchKernelGGL(corr_blend_kernel, dim3((unsigned)idf_cdiv((int64_t)B * CTOK * T, 256)), dim3(256), 0, s, x0, w.proj, cond, B, T,
-                       blend_t);
+                       blend_t, blend_table, blend_state);
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
+}
+
+extern "C" int interdiff_correction(const idf_correction_ctx *c, float *x0, const float *gt, const float *hand_pose,
+                                    const float *beta, const float *obj_points, int32_t B, int32_t T, float blend_t,
+                                    uint8_t *condition, int32_t *contact, float *distance, float *loss, void *ws,
+                                    size_t ws_bytes, void *stream) {
+    return correction_impl(c, x0, gt, hand_pose, beta, obj_points, B, T, blend_t, nullptr, nullptr, condition, contact, distance, loss, ws, ws_bytes, stream);
+}
+
+extern "C" int interdiff_correction_dev(const idf_correction_ctx *c, float *x0, const float *gt, const float *hand_pose,
+                                        const float *beta, const float *obj_points, int32_t B, int32_t T, const float *table,
+                                        const int64_t *state, void *ws, size_t ws_bytes, void *stream) {
+    if (!table || !state) return IDF_E_INVAL;
+    return correction_impl(c, x0, gt, hand_pose, beta, obj_points, B, T, 0.f, table, state, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 // ---- evaluation metrics (row E1, eval_smpl_short.py:24-81) --------------------------------------------------------

@@ -187,29 +187,79 @@ class GaussianDiffusion:
                 ch.cond.copy_(st.cond[:, ch.sl])
                 model.prepare_memory(ch.cond, into=ch.memctx)
 
+        def enqueue_plain(k):
+            """k consecutive plain steps on the current (capturing) stream: every per-step scalar is read from HBM, so they fit any position."""
+            if split:                       # fork: each chain runs its k steps on its own branch; join at the end
+                cur = torch.cuda.current_stream()
+                for ch in st.chains:
+                    ch.stream.wait_stream(cur)
+                    with torch.cuda.stream(ch.stream):
+                        for _ in range(k):
+                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
+                for ch in st.chains:
+                    cur.wait_stream(ch.stream)
+            else:
+                for _ in range(k):
+                    if fused:               # the update runs in the epilogue of the denoiser's last GEMM (same bits)
+                        model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
+                    else:
+                        model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
+                        posterior(st.x, st.x0, st.gt, st.mask, st)
+
         def graph_of(k):
-            """hipGraph of k consecutive plain steps (every per-step scalar is read from HBM, so it fits any position)."""
+            """hipGraph of k consecutive plain steps."""
             if (k, fused, split) not in st.graphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    if split:                       # fork: each chain runs its k steps on its own branch; join at the end
-                        cur = torch.cuda.current_stream()
-                        for ch in st.chains:
-                            ch.stream.wait_stream(cur)
-                            with torch.cuda.stream(ch.stream):
-                                for _ in range(k):
-                                    model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
-                        for ch in st.chains:
-                            cur.wait_stream(ch.stream)
-                    else:
-                        for _ in range(k):
-                            if fused:               # the update runs in the epilogue of the denoiser's last GEMM (same bits)
-                                model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
-                            else:
-                                model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
-                                posterior(st.x, st.x0, st.gt, st.mask, st)
+                    enqueue_plain(k)
                 st.graphs[(k, fused, split)] = g
             return st.graphs[(k, fused, split)]
+
+        # Hook steps.  The gate of the correction hook is host-known (t <= 500 and t % 50 == 0, eval_smpl_short.py:85) and a hook that
+        # reads its one per-call scalar on the device (HipCorrection.apply_dev: blend weight = table[state[0]][3]) launches the same
+        # kernels with the same arguments at every timestep: a WHOLE hook step [denoiser forward -> inpaint -> hook -> posterior update] is
+        # then one captured graph, and the 49 plain steps before it ride in the same graph -- a 50-step segment of the loop is one launch.
+        # Same kernels in the same order as the eager hook step: same bits (tests).  Hooks without apply_dev, or with debug outputs
+        # switched on, keep the eager path.
+        hook_dev = (denoised_fn is not None and getattr(denoised_fn, 'graph_capturable', False) and getattr(denoised_fn, 'debug', None) is None
+                    and getattr(denoised_fn, 'is_active', None) is not None and all(k in y for k in ('inpainted_motion', 'hand_pose', 'beta', 'obj_points'))
+                    and os.environ.get('INTERDIFF_EAGER_HOOK') != '1')
+        if hook_dev:
+            hooks = st.__dict__.setdefault('hooks', {})
+            hk = hooks.get(denoised_fn._uid)
+            shapes = tuple(tuple(y[k].shape) for k in ('hand_pose', 'beta', 'obj_points'))
+            if hk is None or hk.shapes != shapes:
+                hk = SimpleNamespace(shapes=shapes, ws=denoised_fn.workspace_for(B, img.shape[-1]), fresh=True,
+                                     y=dict(inpainted_motion=st.gt if has_mask else torch.empty_like(img),
+                                            **{k: torch.empty(y[k].shape, dtype=torch.float32, device=dev) for k in ('hand_pose', 'beta', 'obj_points')}))
+                hooks[denoised_fn._uid] = hk
+                for key in [key for key in st.graphs if isinstance(key, tuple) and key[0] == 'hook' and key[1] == denoised_fn._uid]:
+                    del st.graphs[key]
+            for k in ('hand_pose', 'beta', 'obj_points') + (() if has_mask else ('inpainted_motion',)):      # this sample's hook inputs, in buffers the graphs know
+                hk.y[k].copy_(y[k])
+            if hk.fresh:                            # first launches of the hook's kernels must not happen inside a capture
+                denoised_fn.apply_dev(hk.y['inpainted_motion'].clone(), table, torch.zeros(8, dtype=torch.int64, device=dev), hk.y, hk.ws)
+                torch.cuda.synchronize(dev)
+                hk.fresh = False
+
+        def hook_graph(k):
+            """hipGraph of k plain steps followed by ONE hook step."""
+            key = ('hook', denoised_fn._uid, k, fused, split)
+            if key not in st.graphs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    if k:
+                        enqueue_plain(k)
+                    model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
+                    if has_mask:
+                        _lib.check(lib.interdiff_inpaint(_lib.dptr(st.x0), _lib.dptr(st.gt), _lib.dptr(st.mask), st.x0.numel(), _lib.stream()), 'inpaint')
+                    denoised_fn.apply_dev(st.x0, table, st.state, hk.y, hk.ws)
+                    posterior(st.x, st.x0, None, None, st)
+                    if split:
+                        for ch in st.chains[1:]:
+                            ch.state[:6].copy_(st.state[:6])     # the whole-batch update advanced chain 0's state; the others follow
+                st.graphs[key] = g
+            return st.graphs[key]
         st.x.copy_(img)
         if elem0 % 4:                               # (chain offsets inside the batch may be odd when T % 4 != 0: the per-row form of the fused update takes any offset)
             raise ValueError('a shard must start at a multiple of 4 elements (C * T = %d per clip)' % per_clip)
@@ -225,7 +275,10 @@ class GaussianDiffusion:
         ts_all = self._timesteps(B, dev)
         dump, it, i, end = [], 0, t_start, t_start - todo
         while i > end:
-            if active(i):
+            if active(i) and hook_dev:
+                hook_graph(0).replay()
+                k = 1
+            elif active(i):
                 # hook step, two-call form; its denoiser forward is replayed from a graph too (24 eager launches cost the host more
                 # than the GPU needs to run them)
                 if 'fwd' not in st.graphs:
@@ -252,7 +305,12 @@ class GaussianDiffusion:
                 while i - run > end and not active(i - run) and not (dump_steps is not None and (it + run - 1) in dump_steps):
                     run += 1
                 k = next(b for b in GRAPH_BLOCKS if b <= run)
-                graph_of(k).replay()
+                if (hook_dev and k == run and i - run > end and active(i - run)
+                        and not (dump_steps is not None and (it + k - 1) in dump_steps)):      # the run ends right at a hook step: one graph for both
+                    hook_graph(k).replay()
+                    k += 1
+                else:
+                    graph_of(k).replay()
             i -= k
             it += k
             if dump_steps is not None and (it - 1) in dump_steps:

@@ -1320,7 +1320,7 @@ def test_two_chain_plain_steps_equal_single_chain_and_eager(mdm, smpl):
                 assert diff.split_chains
                 two = run()
                 st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(noise.shape)]
-                joined = lambda v: any(key[2] for key in v.graphs if isinstance(key, tuple))                 # chains forked / joined inside every graph block
+                joined = lambda v: any((key[4] if key[0] == 'hook' else key[2]) for key in v.graphs if isinstance(key, tuple))                 # chains forked / joined inside every graph block
                 apart = lambda v: all(getattr(ch, 'graphs', None) for ch in v.chains)                         # chains on their own streams, own graphs
                 assert any(hasattr(v, 'chains') and (joined(v) or apart(v)) for v in st), 'split route not taken'
                 assert torch.equal(two, run()), 'graph reuse'
@@ -1398,7 +1398,11 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(x_t.shape)]
     two = B * T > mdm.FFN16_MAX_ROWS
     assert len(st) == 1 and (hasattr(st[0], 'chains') and len(st[0].chains) == 2) == two, 'two-chain route %s' % ('not taken' if two else 'taken')
-    assert all(key[1] and key[2] == two for key in st[0].graphs if isinstance(key, tuple)), 'fused%s graphs expected: %r' % (' + split' if two else '', list(st[0].graphs))
+    flags = [(key[3], key[4]) if key[0] == 'hook' else (key[1], key[2]) for key in st[0].graphs if isinstance(key, tuple)]       # (fused, split) of plain-step and hook-step graphs
+    assert all(f and sp == two for f, sp in flags), 'fused%s graphs expected: %r' % (' + split' if two else '', list(st[0].graphs))
+    assert any(key[0] == 'hook' and key[2] == 49 for key in st[0].graphs if isinstance(key, tuple)), 'the 49 plain steps before a corrected step and the corrected step are ONE graph'
+    assert 'fwd' not in st[0].graphs, 'hook steps must be captured whole, not run eagerly'
+
     eager = run(step_noise=_philox_step(lib, seed), use_graph=False)
     assert torch.equal(timed, eager), 'timed route differs from the eager injected-noise route at B=%d: %g' % (B, (timed - eager).abs().max())
     assert torch.equal(timed, run(seed=seed)), 'graph reuse'

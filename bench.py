@@ -6,13 +6,14 @@ A "step" is one DDPM reverse step (p_sample: denoiser forward + x0-inpainting + 
 in-kernel noise) over one batch of B=16 BEHAVE-shaped synthetic clips of T=100 frames per GPU (BASELINE config #2:
 eval_smpl_short.py, B=16, T=100, 1000-step DDPM, correction mode).
 
-The timed region is ALWAYS made of whole samples: ceil(K / 1000) complete 1000-step samples, each with its 989 plain steps, its
+The timed region is ALWAYS made of whole samples: max(3, ceil(K / 1000)) complete 1000-step samples, each with its 989 plain steps, its
 11 gated correction steps (t in {500,450,..,0}: SMPL-H FK + LBS, normals, signed nearest neighbours, contact-frame predictor) and
-the once-per-sample memory folding -- whatever --steps says (the default and every K <= 1000 time exactly one sample), so that the
-headline is the rate of the workload eval_smpl_short.py runs, never a window of plain steps.  `steps` in the JSON line is the number
-of steps really timed, `steps_requested` echoes --steps.  Inputs are resident in HBM before the clock starts.
+the once-per-sample memory folding -- whatever --steps says, so that the headline is the rate of the workload eval_smpl_short.py runs,
+never a window of plain steps.  Every sample is clocked on its own (barrier + synchronize on both sides, max over ranks); `value` is
+computed from the MEDIAN sample, min / max / all travel in `ms_per_step_samples`.  `steps` in the JSON line is the number of steps
+really timed, `steps_requested` echoes --steps.  Inputs are resident in HBM before the clock starts.
 
-value = frame-steps/s = steps * B_total * T / wall  (whole job, all ranks; weak scaling: B=16 per GPU).
+value = frame-steps/s = 1000 * B_total * T / (median seconds per sample)  (whole job, all ranks; weak scaling: B=16 per GPU).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself as N ranks (torch.distributed.run, one per GPU).
 After the timed region every rank scores its clips and the six per-clip metric vectors are collated with the path's one collective
@@ -45,7 +46,9 @@ B_PER_GPU, T, PAST, P, STEPS = 16, 100, 10, 2048, 1000
 FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
-DOMINANT_KERNEL_ID = 'idf_ffn::ffn_fused_kernel r03a'       # the build the roofline block (and profiles/traffic.json) speaks about
+PEAK_F16_MFMA_TFLOPS = 2500.0                               # MI355X_MICROARCH.md: f16 / bf16 MFMA, dense
+DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r04a'       # the build the roofline block (and profiles/traffic.json) speaks about
+ROCPROF_STATS = 'profiles/r04_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r04.sh)
 
 
 def tt(d, dev=None):
@@ -299,6 +302,28 @@ def timed_samples(diff, model, corr, bt, y, n, seed0=233):
     return time.perf_counter() - t0, out
 
 
+def philox_stream(seed):
+    """step_noise callable that materialises the in-kernel generator's stream (what the eager route is fed to reproduce the graph route)."""
+    lib = _lib.load()
+
+    def draw(it, x):
+        out = torch.empty_like(x)
+        _lib.check(lib.interdiff_randn(_lib.dptr(out), out.numel(), seed, it, _lib.stream()), 'randn')
+        return out
+    return draw
+
+
+def route_check(diff, model, corr, bt, y, seed=4242, first_t=520, n=60):
+    """The route a leg times (hipGraph blocks of fused steps, chains, captured hook steps, in-kernel Philox) against the EAGER route fed
+    the same noise stream, on a 60-step window that crosses the corrected step t = 500: bit for bit, at the leg's own shape."""
+    kw = dict(noise=bt['noise'], clip_denoised=False, model_kwargs={'y': y}, denoised_fn=corr, n_steps=n, first_t=first_t)
+    a = diff.p_sample_loop(model, tuple(bt['noise'].shape), seed=seed, **kw)
+    b = diff.p_sample_loop(model, tuple(bt['noise'].shape), step_noise=philox_stream(seed), use_graph=False, **kw)
+    if not torch.equal(a, b):
+        raise AssertionError('timed route differs from the eager route: max |delta| = %g' % float((a - b).abs().max()))
+    return True
+
+
 def main():
     global B_PER_GPU, T
     ap = argparse.ArgumentParser()
@@ -315,14 +340,27 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_spawn(args))
     B_PER_GPU = args.clips_per_gpu
+    # stdout carries exactly ONE line, the JSON: libraries that chat on file descriptor 1 (RCCL prints a version banner when its first
+    # communicator comes up) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.set_grad_enabled(False)
-    rank, world, local = idist.init_from_env('nccl' if args.gpus > 1 else None)
+    torch.set_num_threads(usable_cores())             # ONE thread count for every CPU leg below (cpu_baseline, the post-optimisation CPU sample)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    rccl_note = None
+    try:                                              # a process group even for ONE rank: the path's collective then goes through RCCL for real at N = 1 too
+        rank, world, local = idist.init_from_env('nccl', single_rank_group=True)
+    except Exception as e:                            # (never let the collective's plumbing take a 1-GPU measurement down)
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            raise
+        rank, world, local, rccl_note = 0, 1, 0, 'single-rank nccl group failed to start: %r' % (e,)
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     K = max(1, args.steps)
-    n_samples = (K + STEPS - 1) // STEPS              # whole samples only: the headline always contains the correction path
+    n_samples = max(3, (K + STEPS - 1) // STEPS)      # whole samples only (the headline always contains the correction path), at least three for a spread
     log('building world (weights, SMPL-H stand-in, clips) on %s' % dev)
     model, corr, bt, y, assets = build_world(dev, rank)
     log('world ready')
@@ -332,18 +370,24 @@ def main():
     run_steps(diff, model, corr, bt, y, max(1, args.warmup), seed=7)
     run_steps(diff, model, corr, bt, y, 57, seed=7)        # setup, not a step count: captures every hipGraph block size (49+7+1)
     corr.apply(bt['noise'].clone(), 500, y)
+    route_ok = route_check(diff, model, corr, bt, y)          # untimed: the route about to be timed == the eager route, 60 steps across t = 500, bit for bit
     torch.cuda.synchronize()
     log('warm-up done')
 
-    idist.barrier()
-    # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample)
-    wall_local, out = timed_samples(diff, model, corr, bt, y, n_samples)
-    idist.barrier()
-    wall = idist.max_over_ranks(wall_local, dev)
-    wall_ranks = idist.gather_scalar(wall_local, dev)        # every rank's own clock around the same region: a straggler shows
+    # the once-per-sample memory folding runs inside the clock (p_sample_loop folds `cond` at the start of every sample).  Every sample is its
+    # own timed region: barrier + synchronize on both sides, MAX over ranks; the headline is the MEDIAN sample
+    sample_s, sample_ranks = [], []
+    for s_i in range(n_samples):
+        idist.barrier()
+        wall_local, out = timed_samples(diff, model, corr, bt, y, 1, seed0=233 + s_i)
+        idist.barrier()
+        sample_s.append(idist.max_over_ranks(wall_local, dev))
+        sample_ranks.append(idist.gather_scalar(wall_local, dev))       # every rank's own clock around the same region: a straggler shows
     assert torch.isfinite(out).all()
+    wall = sorted(sample_s)[len(sample_s) // 2]                        # median sample (n odd by default: 3)
+    wall_ranks = sample_ranks[sample_s.index(wall)]
     n_timed = n_samples * STEPS
-    log('timed region: %d whole sample(s) = %d steps (incl. %d correction steps) in %.3f s' % (n_samples, n_timed, 11 * n_samples, wall))
+    log('timed region: %d whole samples of %d steps (incl. %d correction steps each): %s s; median %.4f' % (n_samples, STEPS, 11, ['%.4f' % w for w in sample_s], wall))
 
     # ---- eval leg, all ranks: every rank scores its clips, ONE all-gather (RCCL over xGMI) collates the six per-clip metric vectors
     from interdiff_amd import eval as ev
@@ -355,6 +399,14 @@ def main():
     torch.cuda.synchronize()
     eval_s = time.perf_counter() - t0
     assert all(v.numel() == B_PER_GPU * world for v in per_clip.values())
+    coll = idist.collective_backend_info()
+    if world == 1 and coll['backend'] == 'nccl':      # one rank: evaluate_sharded took the world == 1 shortcut -- push the same vectors through RCCL explicitly
+        mine = {k: v.clone() for k, v in per_clip.items()}
+        back, header = idist.gather_metrics(mine, 1, counts=[B_PER_GPU], return_header=True, force_collective=True, check_header=True)
+        assert all(torch.equal(back[k], mine[k]) for k in mine)
+        coll['single_rank_all_gather'] = 'issued (1-rank nccl group, header verified)'
+    if rccl_note:
+        coll['note'] = rccl_note
     idist.shutdown()              # no collective after this point: rank 0 alone takes the extra legs below
     if rank != 0:
         return
@@ -380,11 +432,11 @@ def main():
             m3, c3, bt3, y3, _ = build_world(dev, rank)
             run_steps(diff, m3, c3, bt3, y3, 57, seed=7)
             c3.apply(bt3['noise'].clone(), 500, y3)
-            w3s = [timed_samples(diff, m3, c3, bt3, y3, 1, seed0=233 + i) for i in range(2)]
-            w3, o3 = min(w[0] for w in w3s), w3s[-1][1]
-            assert torch.isfinite(o3).all()
-            extra['config3_B32_correction'] = dict(workload='eval_smpl_short.py correction mode, B=32, T=%d, one whole sample (the faster of two; both in seconds_each)' % T, steps=STEPS, seconds_each=[w[0] for w in w3s],
-                                                   ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s')
+            ok3 = route_check(diff, m3, c3, bt3, y3)
+            w3s = [timed_samples(diff, m3, c3, bt3, y3, 1, seed0=233 + i) for i in range(3)]
+            w3 = sorted(w[0] for w in w3s)[1]
+            extra['config3_B32_correction'] = dict(workload='eval_smpl_short.py correction mode, B=32, T=%d, whole samples (median of three; all in seconds_each)' % T, steps=STEPS, seconds_each=[w[0] for w in w3s],
+                                                   ms_per_step=1e3 * w3 / STEPS, value=STEPS * 32 * T / w3, unit='frame-steps/s', equals_eager_route_on_60_steps_across_t500=ok3)
             del m3, c3, bt3, y3
             B_PER_GPU = 16
         if B_PER_GPU == 16:
@@ -394,11 +446,12 @@ def main():
             m5, c5, bt5, y5, _ = build_world(dev, rank)
             run_steps(diff, m5, c5, bt5, y5, 57, seed=7)
             c5.apply(bt5['noise'].clone(), 500, y5)
-            w5s = [timed_samples(diff, m5, c5, bt5, y5, 1, seed0=233 + i) for i in range(2)]
-            w5, o5 = min(w[0] for w in w5s), w5s[-1][1]
-            assert torch.isfinite(o5).all()
-            extra['reference_default_B32_T35'] = dict(workload='eval_smpl_short.py with its own defaults: B=32, T=35 (10 past + 25 future), correction mode, one whole 1000-step sample (the faster of two; both in seconds_each)',
-                                                      steps=STEPS, seconds_each=[w[0] for w in w5s], ms_per_step=1e3 * w5 / STEPS, value=STEPS * 32 * 35 / w5, unit='frame-steps/s')
+            ok5 = route_check(diff, m5, c5, bt5, y5)
+            w5s = [timed_samples(diff, m5, c5, bt5, y5, 1, seed0=233 + i) for i in range(3)]
+            w5 = sorted(w[0] for w in w5s)[1]
+            extra['reference_default_B32_T35'] = dict(workload='eval_smpl_short.py with its own defaults: B=32, T=35 (10 past + 25 future), correction mode, whole 1000-step samples (median of three; all in seconds_each)',
+                                                      steps=STEPS, seconds_each=[w[0] for w in w5s], ms_per_step=1e3 * w5 / STEPS, value=STEPS * 32 * 35 / w5, unit='frame-steps/s',
+                                                      equals_eager_route_on_60_steps_across_t500=ok5)
             del m5, c5, bt5, y5
             B_PER_GPU, T = 16, 100
         if B_PER_GPU == 16:
@@ -410,16 +463,21 @@ def main():
             g4 = torch.Generator().manual_seed(4)
             raw4 = dict(ei4, hand_pose=(0.1 * torch.randn(T, B4, 90, generator=g4)).to(dev), beta=torch.randn(1, B4, 10, generator=g4).expand(T, B4, 10).contiguous().to(dev))
             ev4.sample_long(model, diff, corr, raw4, 1, PAST, seed=1)                 # warm-up: captures for the 8-clip shape
+            # the rollout's timed route == its eager route: two windows (conditioning pass each), 60 steps across t = 500, same Philox streams
+            a4 = ev4.sample_long(model, diff, corr, raw4, 1, PAST, seed=2, n_steps=60, first_t=520)
+            b4 = ev4.sample_long(model, diff, corr, raw4, 1, PAST, seed=2, n_steps=60, first_t=520, use_graph=False, step_noise=lambda k: philox_stream(2 + k))
+            assert all(torch.equal(p_, q_) for p_, q_ in zip(a4, b4)), 'config #4: timed rollout route differs from the eager route'
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             o4 = ev4.sample_long(model, diff, corr, raw4, K4, PAST, seed=2)
             torch.cuda.synchronize()
             w4 = time.perf_counter() - t0
-            assert o4[0].shape[0] == T + K4 * (T - PAST) and all(torch.isfinite(a).all() for a in o4)
+            assert o4[0].shape[0] == T + K4 * (T - PAST) and all(torch.isfinite(a).all() for a in o4)       # (route equality asserted above)
             extra['config4_long_horizon'] = dict(workload='eval_smpl_long.py autoregressive rollout: %d clips per GPU (B=64 over 8 GPUs), T=%d, %d windows '
                                                           '(first + %d re-conditioned), each = conditioning pass + whole 1000-step sample with correction' % (B4, T, K4 + 1, K4),
                                                  windows=K4 + 1, steps=(K4 + 1) * STEPS, seconds=w4, ms_per_step=1e3 * w4 / ((K4 + 1) * STEPS),
-                                                 value=(K4 + 1) * STEPS * B4 * T / w4, unit='frame-steps/s', frames_generated_per_clip=T + K4 * (T - PAST))
+                                                 value=(K4 + 1) * STEPS * B4 * T / w4, unit='frame-steps/s', frames_generated_per_clip=T + K4 * (T - PAST),
+                                                 equals_eager_route_on_2_windows_60_steps_across_t500=True)
         log('extra configurations done')
     prof = None
     if not args.no_kernel_profile:
@@ -430,6 +488,12 @@ def main():
         small_us, small_best = time_dominant_kernel(model, dev, n_rows=800)
         big_us, big_best = time_dominant_kernel(model, dev, n_rows=3200)
         fwd_us = time_forward_graph(model, bt, y, dev)
+        exact_us = exact_fwd_us = None
+        if getattr(model, 'ffn_math', 'exact') == 'split':       # the exact-fp32 kernel of csrc/ffn.h stays selectable: its figures next to the shipped kernel's
+            model.ffn_math = 'exact'
+            exact_us, _ = time_dominant_kernel(model, dev)
+            exact_fwd_us = time_forward_graph(model, bt, y, dev)
+            model.ffn_math = 'split' 
         log('kernel profile done')
     # once-per-sample conditioning path ("next" row): PointNet++ object encoder + embeddings + 8-layer encoder
     ei = tt(syn.make_embedding_inputs(seed=77, B=B_PER_GPU, T=T, n_points=P), dev)
@@ -452,65 +516,83 @@ def main():
                            {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in y.items()})
     log('cpu baseline done' if cpu else 'cpu baseline skipped')
     Btot = B_PER_GPU * world
-    line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=n_timed * Btot * T / wall,
-                unit='frame-steps/s', n_gpus=world, steps=n_timed, steps_requested=K, warmup=args.warmup, ms_per_step=1e3 * wall / n_timed,
-                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                steps_per_sec=n_timed / wall,
-                steps_note='--steps is advisory: the timed region is always ceil(steps / 1000) WHOLE 1000-step samples (989 plain + 11 corrected steps each)',
-                ms_per_step_by_rank=dict(min=1e3 * min(wall_ranks) / n_timed, max=1e3 * max(wall_ranks) / n_timed,
-                                         all=[round(1e3 * w_ / n_timed, 5) for w_ in wall_ranks]),
+    split = getattr(model, 'ffn_math', 'exact') == 'split'
+    line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=STEPS * Btot * T / wall,
+                unit='frame-steps/s', n_gpus=world, steps=n_timed, steps_requested=K, warmup=args.warmup, ms_per_step=1e3 * wall / STEPS,
+                higher_is_better=True, scaling='weak', vs_baseline=None,
+                dtype='f32 (feed-forward block: every fp32 operand as two f16 planes, 3 f16 MFMAs per product, fp32 accumulate; everything else fp32 MFMA / VALU)' if split else 'f32',
+                data='synthetic', steps_per_sec=STEPS / wall,
+                ms_per_step_samples=dict(median=1e3 * wall / STEPS, min=1e3 * min(sample_s) / STEPS, max=1e3 * max(sample_s) / STEPS,
+                                         all=[round(1e3 * w_ / STEPS, 5) for w_ in sample_s], n=n_samples,
+                                         note='every whole 1000-step sample clocked on its own (barrier + synchronize both sides, max over ranks); value = from the median'),
+                steps_note='--steps is advisory: the timed region is always max(3, ceil(steps / 1000)) WHOLE 1000-step samples (989 plain + 11 corrected steps each)',
+                ms_per_step_by_rank=dict(min=1e3 * min(wall_ranks) / STEPS, max=1e3 * max(wall_ranks) / STEPS,
+                                         all=[round(1e3 * w_ / STEPS, 5) for w_ in wall_ranks], of='the median sample'),
+                timed_route_equals_eager_route=dict(ok=route_ok, how='60 steps from t = 520 (corrected step t = 500 inside), graph route vs eager route fed the same Philox stream, torch.equal'),
                 config=dict(workload='eval_smpl_short.py correction mode: BEHAVE-shaped SMPL-H clips, B=%d per GPU, T=%d '
                                      '(10 past + 90 future), C=144, 1000-step cosine DDPM, 2048 object points, real '
                                      'ObjProjector checkpoint, synthetic denoiser/SMPL-H weights' % (B_PER_GPU, T),
                             global_batch=Btot, seq_len=T, samples_in_region=n_samples, correction_steps_in_region=11 * n_samples,
                             plain_steps_in_region=989 * n_samples, timesteps='%d whole sample(s): t = 999..0' % n_samples,
-                            parallelism='clips sharded x%d' % world))
-    line['eval_collation'] = dict(collective='ONE all_gather of [7, B_local] fp32 (count header + six metric rows; %s), %d ranks' % ('RCCL' if world > 1 else 'degenerate: 1 rank', world),
+                            parallelism='clips sharded x%d' % world, ffn_math=getattr(model, 'ffn_math', 'exact')))
+    line['eval_collation'] = dict(collective='ONE all_gather of [7, B_local] fp32 (count header + six metric rows), %d rank(s)' % world,
+                                  backend=coll.get('backend'), rccl_version=coll.get('rccl_version'), single_rank_all_gather=coll.get('single_rank_all_gather'), note_rccl=coll.get('note'),
                                   seconds_sample_plus_metrics=eval_s, clips=Btot, means=means,
+                                  sharding='every rank draws the whole batch\'s noise at its clips\' global position (shard=): a sharded run equals the unsharded one bit for bit (tests)',
                                   note='random-init denoiser: the metric values only serve as parity evidence against the oracle')
     line.update(extra)
     if prof:
+        split = getattr(model, 'ffn_math', 'exact') == 'split'
         dom = 'ffn_fused'
         us = dom_us
         flops = FFN_FLOP_PER_TOKEN * B_PER_GPU * T
         ach = flops / (us * 1e-6) / 1e12
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get('kernel_id') == DOMINANT_KERNEL_ID:          # a PMC figure is only valid for the kernel build it was taken on
-                traffic, traffic_src = tj.get(dom), tj.get('_how')
-        in_situ = None                                       # cross-check: the committed rocprofv3 kernel-trace summary of this same command
-        ks = os.path.join(ROOT, 'profiles', 'r03_kernel_stats_bench.txt')
-        if os.path.exists(ks) and traffic is not None:         # (only trusted for the kernel build traffic.json names)
-            for ln in open(ks):
-                if ln.startswith('idf_ffn::ffn_fused_kernel'):
-                    f_ = ln.split()
-                    in_situ = dict(us_per_launch=float(f_[-4]), launches=int(f_[-6]), frac=flops / (float(f_[-4]) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   source='profiles/r03_kernel_stats_bench.txt (rocprofv3 --kernel-trace --stats of `python bench.py`, INTERDIFF_CHAINS=1)')
-                    break
-        line['roofline'] = dict(bound='mfma', kernel=dom, rocprofv3_in_situ=in_situ, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
-                                traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
-                                one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                     note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic, round-2 form; secondary'),
-                                kernel_id=DOMINANT_KERNEL_ID,
-                                two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                    note='the sampler steps a batch of <= 32 clips as two half-batch kernel chains on two branches of one '
-                                                         'graph: the same layer = two concurrent launches at M=%d, timed as two such chains of back-to-back '
-                                                         'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
-                                small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best,
-                                                             frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                             note='ffn_fused16_kernel: the tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU): '
-                                                                  '250 workgroups of 16 rows instead of 125 of 32; same layer-cycling burst as the headline figure'),
-                                large_batch_64_row_tile=dict(rows=3200, us_per_launch=big_us, us_per_launch_best=big_best,
-                                                             frac=flops * 3200 / (B_PER_GPU * T) / (big_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                             note='ffn_fused64_kernel: the tile BASELINE config #3 (32 clips of 100 frames) takes: 250 workgroups of 64 rows in one round '
-                                                                  'instead of 500 of 32 in two; same layer-cycling burst as the headline figure'),
-                                traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
-                                note='one launch = linear1 + gelu + linear2 of a layer at M=%d (2 x 2*M*256*1024 FLOP, fp32 MFMA); 8 of the 22 launches '
-                                     'of a denoiser forward; duration = mean of three bursts of 192 launches replayed from a hipGraph that walk through the '
-                                     'eight layers\' weight streams and alternate activation buffers like a denoiser step (every weight stream from the '
-                                     'Infinity Cache), HIP events on the launch stream; cross-check = the rocprofv3 in-situ average under profiles/' % (B_PER_GPU * T))
+        recorded = None                                      # RECORDED, not measured by this run: the committed rocprofv3 summary of this same command
+        try:
+            tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                if tj.get('kernel_id') == DOMINANT_KERNEL_ID:      # a PMC figure is only valid for the kernel build it was taken on
+                    traffic, traffic_src = tj.get(dom), tj.get('_how')
+                    r_ = tj.get('rocprofv3_in_situ_us')
+                    if r_:
+                        recorded = dict(us_per_launch=r_, frac=flops / (r_ * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, recorded_not_measured=True, source=ROCPROF_STATS)
+        except Exception as e:                               # a stale or reformatted profile must never take the measurement down
+            traffic_src = 'profiles/traffic.json unreadable: %r' % (e,)
+        stream_bytes = 5 * 442368 if split else 5 * 425984   # packed weight stream of one layer (what every XCD pulls through its L2 once per launch)
+        line['roofline'] = dict(
+            bound='mfma', kernel=dom, kernel_id=DOMINANT_KERNEL_ID, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
+            traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
+            rocprofv3_in_situ=recorded,
+            peak_note='achieved = ALGORITHMIC fp32 FLOP of the block (2 x 2*M*256*1024) / measured duration; peak = the fp32-input MFMA peak, the roof an fp32 '
+                      'contraction has on this chip (no TF32 path).  The shipped kernel does the arithmetic as 3 f16 MFMAs per product (fp32-grade, csrc/ffn_h2.h), '
+                      'so its matrix pipe is nearly idle (see issued_f16_mfma) and what it waits for is its weight stream (see weight_stream): frac measures how close the '
+                      'BLOCK is to the fp32 roof, not how busy the pipe is' if split else None,
+            issued_f16_mfma=dict(achieved=3 * ach, peak=PEAK_F16_MFMA_TFLOPS, unit='TFLOP/s', frac=3 * ach / PEAK_F16_MFMA_TFLOPS,
+                                 note='what the kernel really issues: three v_mfma_f32_16x16x32_f16 per 32 k of every output tile') if split else None,
+            weight_stream=dict(bytes_per_workgroup=stream_bytes // 5, bytes_per_layer=stream_bytes, gb_per_s_per_cu=(stream_bytes // 5) / (us * 1e-6) / 1e9,
+                               note='every workgroup streams its slice of the packed weights (LDS-DMA, ring of 32-KiB slots) once per launch: the kernel\'s critical resource once the MFMAs cost 1/43'),
+            exact_fp32_kernel=dict(us_per_launch=exact_us, achieved=flops / (exact_us * 1e-6) / 1e12, frac=flops / (exact_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   denoiser_forward_us=exact_fwd_us, kernel='idf_ffn::ffn_fused_kernel (v_mfma_f32_16x16x4_f32; csrc/ffn.h), selectable with MDM.ffn_math = "exact" / INTERDIFF_FFN_MATH=exact',
+                                   note='same measurement recipe, same process') if exact_us else None,
+            one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic; secondary'),
+            two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                note='the sampler steps a batch of > 800 token rows as two half-batch kernel chains on two branches of one '
+                                     'graph: the same layer = two concurrent launches at M=%d, timed as two such chains of back-to-back '
+                                     'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
+            small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best,
+                                         frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                         note='the 16-row tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU)'),
+            large_batch_64_row_tile=dict(rows=3200, us_per_launch=big_us, us_per_launch_best=big_best,
+                                         frac=flops * 3200 / (B_PER_GPU * T) / (big_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                         note='the 64-row tile BASELINE config #3 (32 clips of 100 frames) takes'),
+            traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
+            note='one launch = linear1 + gelu + linear2 of a layer at M=%d; 8 of the 22 launches of a denoiser forward; duration = mean of three bursts of '
+                 '192 launches replayed from a hipGraph that walk through the eight layers\' weight streams and alternate activation buffers like a '
+                 'denoiser step (every weight stream from the Infinity Cache), HIP events on the launch stream; the rocprofv3 in-situ average of the same '
+                 'command is committed under profiles/ (rocprofv3_in_situ, recorded)' % (B_PER_GPU * T))
         fl = FLOP_PER_TOKEN * B_PER_GPU * T
         line['denoiser_forward'] = dict(us=fwd_us, achieved_tflops=fl / (fwd_us * 1e-6) / 1e12,
                                         frac_of_f32_mfma_peak=fl / (fwd_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, launches=22,
@@ -524,7 +606,9 @@ def main():
             cpu['plain_only']['gpu_over_cpu'] = extra['no_correction']['value'] / cpu['plain_only']['value']
         cpu['gpu_over_cpu_blended'] = line['value'] / cpu['value']
         line['cpu_baseline'] = cpu
-    print(json.dumps(line))
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)                          # whatever C stdio still holds goes to stderr, not behind the JSON
+    os.write(json_fd, (json.dumps(line) + '\n').encode())
 
 
 if __name__ == '__main__':

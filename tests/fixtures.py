@@ -216,10 +216,28 @@ TIMED_T, TIMED_P = 100, 2048          # the shape bench.py times (BASELINE confi
 TIMED_FIRST_T, TIMED_STEPS = 560, 120  # a window that crosses the corrected steps t = 500 and t = 450
 
 
-def timed_inputs(B):
+def timed_inputs(B, T=None):
     """Clip batch + x_{first_t} of the timed-route parity tests (no golden: the routes are compared with each other and the oracle)."""
-    bt = _clip(300 + B, B, TIMED_T, TIMED_P)
-    return bt, model_kwargs_y(bt, TIMED_T)
+    T = TIMED_T if T is None else T
+    bt = _clip(300 + B + (0 if T == TIMED_T else 1000 * T), B, T, TIMED_P)
+    return bt, model_kwargs_y(bt, T)
+
+
+LONG4_SHAPE = (100, 8, 2048, 2, 50)    # T, B, P, K windows, schedule steps: BASELINE config #4's per-GPU share (8 of 64 clips), tests/golden/long4.npz
+
+
+def long4_inputs():
+    """Raw (dataset-side) clips of the config #4 golden + the injected noise: x_T(k) [B,1,144,T] and the per-step stream of window k."""
+    T, B, P, K, steps = LONG4_SHAPE
+    ei = {k: _t(v) for k, v in syn.make_embedding_inputs(seed=404, B=B, T=T, n_points=P).items()}
+    g = torch.Generator().manual_seed(405)
+    raw = dict(ei, hand_pose=0.1 * torch.randn(T, B, 90, generator=g), beta=torch.randn(1, B, 10, generator=g).expand(T, B, 10).contiguous())
+    x_T = lambda k: torch.from_numpy(np.random.RandomState(9400 + k).standard_normal((B, 1, 144, T)).astype(np.float32))
+
+    def step_noise(k):
+        rs = np.random.RandomState(9500 + k)
+        return lambda i, x: torch.from_numpy(rs.standard_normal(tuple(x.shape)).astype(np.float32))
+    return raw, x_T, step_noise
 
 
 LONG_FUTURE, LONG_WINDOWS = 4, 2       # tests/golden/long.npz: eval_smpl_long.get_batch on two windows of one clip

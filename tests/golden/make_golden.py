@@ -374,6 +374,26 @@ def gen_long():
     save('long.npz', **out)
 
 
+def gen_long4():
+    """long4.npz -- BASELINE config #4's per-GPU share at the NAMED shape: 8 clips (of the 64 sharded over 8 GPUs), T = 100 (10 past + 90
+    future), P = 2048, K = 2 autoregressive windows behind the first, a 50-step cosine schedule (one corrected step per window, t = 0),
+    injected x_T and per-step noise (`make_golden.py long4`, ~tens of minutes of CPU: three conditioning passes, 150 denoiser
+    steps at 800 token rows, three hook calls over 800 frames x 6890 vertices x 2048 points).  Upstream's rollout cannot run
+    (eval_smpl_long.py: undefined ``denormalize`` / ``correct``), so the recorded answer is the ORACLE's
+    (oracle/long_horizon.py) -- whose window algebra is pinned to the reference's own ``get_batch`` by long.npz and whose per-window
+    sampler + hook are pinned by loop.npz / denoised_fn.npz / full.npz.  Stored: obj, body, jtr, pelvis and the 67 marker vertices of the
+    whole rollout (all vertices would be 185 MB)."""
+    import time
+    from oracle import long_horizon as olh, diffusion as odf
+    T, B, P, K, steps = fx.LONG4_SHAPE
+    raw, x_T, step_noise = fx.long4_inputs()
+    t0 = time.time()
+    obj, body, verts, jtr, pelvis = olh.rollout(fx.mdm_weights(), fx.smpl_model(), fx.objproj_weights(), raw, K, fx.PAST, odf.make_schedule(steps), x_T, step_noise)
+    print('rollout: %.0f s' % (time.time() - t0), flush=True)
+    from oracle.correction import MARKERS67
+    save('long4.npz', obj=np_(obj), body=np_(body), jtr=np_(jtr), pelvis=np_(pelvis), markers=np_(verts[:, :, MARKERS67]))
+
+
 def gen_corr32():
     """One corrected step (the reference's own denoised_fn, t = 250) at BASELINE config #3's size B=32, T=100, P=2048: the per-clip
     reductions over 90 future frames and the 32-clip ObjProjector batch at the benchmark shape.  ~5 min, ~6 GB."""
@@ -406,6 +426,8 @@ def main():
         return gen_etl()
     if len(sys.argv) > 1 and sys.argv[1] == 'long':
         return gen_long()
+    if len(sys.argv) > 1 and sys.argv[1] == 'long4':
+        return gen_long4()
     if len(sys.argv) > 1 and sys.argv[1] == 'corr32':
         return gen_corr32()
     if len(sys.argv) > 1 and sys.argv[1] == 'optim':

@@ -1375,19 +1375,21 @@ def _philox_step(lib_, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B', [8, 12, 16, 32])
-def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
+@pytest.mark.parametrize('B,T', [(8, 100), (12, 100), (16, 100), (32, 100), (17, 100), (25, 100), (32, 35)])
+def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B, T):
     """What bench.py times -- hipGraph blocks of fused plain steps (interdiff_mdm_forward_step), two half-batch chains whose 32-row
     tiles straddle clips at T = 100, in-kernel Philox, whole-batch hook steps in between -- against the EAGER route (one launch
     sequence per step, two-call update, noise INJECTED from the materialised Philox stream) at BASELINE configs #2 / #3:
     B = 16 / 32, T = 100, P = 2048, 120 steps from t = 560 (corrected steps t = 500 and t = 450 inside).  Bit for bit.
     B = 12: chains of 600 rows inside a batch of 1200 -- every launch must take the feed-forward tile picked for the BATCH (32 rows),
     not the one a 600-row launch would pick for itself (MDM._pick_ffn_tile).  B = 8 (config #4's share of a GPU): 800 rows, the
-    16-row feed-forward kernel, one chain.  Reference loop: diffusion/gaussian_diffusion.py:663-736."""
+    16-row feed-forward kernel, one chain.  B = 17 / 25: ODD batches, chains of 9 + 8 / 13 + 12 clips (bench.py's batch-scaling leg).
+    B = 32, T = 35: the reference's own default shape (eval_smpl_short.py:376-380; bench.py ``reference_default_B32_T35``): T % 4 != 0,
+    the per-row form of the fused update, chains of 560 rows.  Reference loop: diffusion/gaussian_diffusion.py:663-736."""
     from interdiff_amd.diffusion import create_gaussian_diffusion
     diff = create_gaussian_diffusion('cosine', 1000)
-    T, P = fx.TIMED_T, fx.TIMED_P
-    bt, y = fx.timed_inputs(B)
+    P = fx.TIMED_P
+    bt, y = fx.timed_inputs(B, T)
     y, x_t = dev(y), bt['noise'].to(DEV)
     corr = make_correction(smpl, T, P)
     seed = 1234 + B
@@ -1396,7 +1398,7 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     assert diff.fuse_plain_step and diff.split_chains
     timed = run(seed=seed)
     st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(x_t.shape)]
-    two = B * T > mdm.FFN16_MAX_ROWS
+    two = B * T > mdm.FFN16_MAX_ROWS and B >= 4
     assert len(st) == 1 and (hasattr(st[0], 'chains') and len(st[0].chains) == 2) == two, 'two-chain route %s' % ('not taken' if two else 'taken')
     flags = [(key[3], key[4]) if key[0] == 'hook' else (key[1], key[2]) for key in st[0].graphs if isinstance(key, tuple)]       # (fused, split) of plain-step and hook-step graphs
     assert all(f and sp == two for f, sp in flags), 'fused%s graphs expected: %r' % (' + split' if two else '', list(st[0].graphs))
@@ -1406,11 +1408,12 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B):
     eager = run(step_noise=_philox_step(lib, seed), use_graph=False)
     assert torch.equal(timed, eager), 'timed route differs from the eager injected-noise route at B=%d: %g' % (B, (timed - eager).abs().max())
     assert torch.equal(timed, run(seed=seed)), 'graph reuse'
-    diff.stagger_steps = 7                   # the optional staggered form (chains on their own streams, hook per half batch): same bits
-    assert torch.equal(timed, run(seed=seed)), 'staggered chains differ from the joined form (whole-batch hook steps)'
-    diff.stagger_steps = 0
+    if B % 2 == 0:
+        diff.stagger_steps = 7               # the optional staggered form (equal chains on their own streams, hook per half batch): same bits
+        assert torch.equal(timed, run(seed=seed)), 'staggered chains differ from the joined form (whole-batch hook steps)'
+        diff.stagger_steps = 0
     assert torch.isfinite(timed).all()
-    fx.record_parity('timed_route_vs_eager_B%d_T100_P2048_120steps_from_t560' % B, bit_identical=1.0, corrected_steps_inside=2)
+    fx.record_parity('timed_route_vs_eager_B%d_T%d_P2048_120steps_from_t560' % (B, T), bit_identical=1.0, corrected_steps_inside=2)
 
 
 @pytest.mark.gpu
@@ -1593,3 +1596,48 @@ def test_dataset_batch_form_is_a_drop_in(mdm, smpl):
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     ma, mb = ev.evaluate_batch(model, diff, corr, clip, past, seed=6), ev.evaluate_batch(model, diff, corr, ds_batch, past, seed=6)
     assert all(torch.equal(ma[k], mb[k]) for k in ma)
+
+
+@pytest.mark.gpu
+def test_config4_long_horizon_named_shape_golden(mdm, smpl):
+    """BASELINE config #4 at its NAMED per-GPU shape: 8 clips (64 sharded over 8 GPUs), T = 100, P = 2048, the first window
+    + K = 2 autoregressive windows, a 50-step schedule with one corrected step per window, injected x_T and per-step noise
+    (tests/golden/long4.npz, recorded offline by `make_golden.py long4` from oracle/long_horizon.py, 383 s of CPU; upstream's own
+    rollout cannot run, see there) against ``eval.sample_long`` on the HIP path: conditioning pass (PointNet++ + 8-layer encoder) per
+    window, sampler + hook, window algebra, at 800 token rows (the 16-row feed-forward tile), under both feed-forward arithmetics.  1e-4 on translations / joints /
+    markers, rotations compared as rotation matrices (1e-3, see below)."""
+    from interdiff_amd import eval as ev
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    T, B, P, K, steps = fx.LONG4_SHAPE
+    raw, x_T, step_noise = fx.long4_inputs()
+    g = fx.golden('long4.npz')
+    model = MDM(fx.mdm_weights(), device=DEV, n_steps=steps)
+    corr = make_correction(smpl, T, P)
+    diff = create_gaussian_diffusion('cosine', steps)
+
+    def sn(k):
+        f = step_noise(k)
+        return lambda i, x: f(i, x).to(DEV)
+    worst = {}
+    for math in ('exact', 'split'):
+        model.ffn_math = math
+        obj, body, verts, jtr, pelvis = ev.sample_long(model, diff, corr, dev(raw), K, fx.PAST, x_T=lambda k: x_T(k).to(DEV), step_noise=sn)
+        assert obj.shape == (T + K * (T - fx.PAST), B, 6)
+        errs = {}
+        for n, a, nr in (('obj', obj, 3), ('body', body, 66)):
+            b = torch.from_numpy(g[n])
+            errs[n + '_rot'] = rel(R.axis_angle_to_matrix(a[..., :nr].reshape(*a.shape[:2], -1, 3).cpu()), R.axis_angle_to_matrix(b[..., :nr].reshape(*b.shape[:2], -1, 3)))
+            errs[n + '_rest'] = rel(a[..., nr:], b[..., nr:])
+        errs['jtr'], errs['pelvis'], errs['markers'] = rel(jtr, g['jtr']), rel(pelvis, g['pelvis']), rel(verts[:, :, ocor.MARKERS67], g['markers'])
+        fx.record_parity('config4_long_horizon_B8_T100_P2048_K2_50steps_vs_offline_golden_%s' % math, asserted_translations_joints_markers=1e-4, asserted_rotations=1e-3, **errs)
+        worst[math] = errs
+    # translations, joints, markers (what the rotations are FOR): north_star's 1e-4 (measured 2e-6 .. 8e-5).  Rotation MATRICES: 1e-3 -- the
+    # rot6d -> matrix Gram-Schmidt of a random-init denoiser's output amplifies an fp32-level difference of two samples ~50x, and the golden is
+    # itself an fp32 run (the same effect, at the same size, as in test_full_size_end_to_end_golden, where the fp64 twin shows the REFERENCE's own
+    # fp32 run 1.0e-3 from exact on body rotations); three chained windows compound it.  Measured: body 4.9e-4 (exact-fp32 feed-forward) /
+    # 3.0e-4 (split-f16), object 1.6e-4 / 1.1e-4.
+    for math, errs in worst.items():
+        for k, v in errs.items():
+            assert v <= (1e-3 if k.endswith('_rot') else 1e-4), 'config #4 (%s) %s: rel err %.3e' % (math, k, v)
+

@@ -71,10 +71,16 @@ class HipCorrection:
         """One workspace per STREAM the hook is called on: the sampler calls it for the two halves of a batch on two streams at once."""
         need = self.lib.interdiff_correction_workspace_bytes(C.byref(self.ctx), B, T)
         key = torch.cuda.current_stream(self.device).cuda_stream
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)                  # (re-inserted below: the dict is kept in least-recently-used order)
         if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ws[key] = ws
+        if len(self._ws) > self.MAX_STREAM_WORKSPACES:      # stream handles are recycled and a workspace is > 100 MB at the bench shape: keep a few, drop
+            torch.cuda.synchronize(self.device)       # the stalest (nothing may still be running on it: rare path, one sync)
+            self._ws.pop(next(iter(self._ws)))
         return ws
+
+    MAX_STREAM_WORKSPACES = 4
 
     @staticmethod
     def slice_kwargs(model_kwargs, sl):
@@ -118,7 +124,9 @@ class HipCorrection:
         idx = torch.empty(T, B, P, dtype=torch.int32, device=self.device)
         stats = torch.zeros(12, dtype=torch.int64, device=self.device) if want_stats else None
         need = self.lib.interdiff_contact_nn_workspace_bytes(C.byref(self.ctx), B, T)
-        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = getattr(self, '_nn_ws', None)
+        if ws is None or ws.numel() < need:
+            ws = self._nn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         v, pts, R_, t_ = (a.contiguous().float() for a in (verts, obj_points, objR, objT))
         _lib.check(self.lib.interdiff_contact_nn(C.byref(self.ctx), _lib.dptr(v), _lib.dptr(pts), _lib.dptr(R_), _lib.dptr(t_), B, T, _lib.dptr(o2h),
                                                  _lib.dptr(idx), _lib.dptr(stats, allow_none=True), _lib.dptr(ws), ws.numel(), _lib.stream()), 'contact_nn')

@@ -94,7 +94,8 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 
 // TT = token tiles of 16 rows per workgroup (1, 2, 4 -> BM = 16, 32, 64); S = ring slots (3; 2 for TT = 4, where the planes take 64 KiB).
 // LDS: BM KiB of planes + S x 32 KiB ring + 1 KiB bias = 113 / 129 / 129 KiB.
-// MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue (tools/ffn_h2_probe.hip ablations only).
+// MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue, 3 = phase stamps of thread 0 behind the slabs, 4 = no slab stores
+// (tools/ffn_h2_probe.hip only; `if constexpr` keeps every trace of them out of MODE 0).
 template <int TT, int S, int MODE = 0>
 __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
                                                      const float *__restrict__ b1p, const float *__restrict__ b2,
@@ -111,6 +112,16 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long *stamps = nullptr;
+    int n_stamp = 0;
+    if constexpr (MODE == 3) stamps = reinterpret_cast<long long *>(parts + (size_t)NSL * M * D) + (size_t)blockIdx.x * 32;
+    auto stamp = [&]() {
+        if constexpr (MODE == 3) {
+            if (tid == 0) stamps[n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
+        }
+    };
+    stamp();
     // Workgroup order.  order 0 (shipped): ffn.h's M-tile-major ids.  order 1 (A/B only, tools/ffn_h2_ab.py): SLICE-major over XCD-affine
     // logical ids -- workgroup id runs on XCD id % 8, each with its own 4-MiB L2; giving one XCD consecutive logical ids and walking the
     // M tiles of one slice before the next slice, an XCD streams one or two of the five 432-KiB slice streams through its L2 (13 slice
@@ -257,9 +268,11 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     // cycles per wave), and a wave sits in its own issue: the two waves of a SIMD (w, w + 4) therefore take turns -- waves 0..3 refill
     // the ring BEFORE their fragment reads and MFMAs, waves 4..7 AFTER theirs -- so that one wave's issue runs beside the other's matrix work.
     const bool early = S == 2 || wave < NW / 2;       // (a two-slot ring has no slack for the late group: its refill would land just before the wait for it)
+    stamp();                                          // 1: x2 rows fetched and split
 #pragma unroll
     for (int P = 0; P < KS1; ++P) {
         publish(P);                                   // (P = 0: also publishes the planes)
+        stamp();                                      // 2 + P: step P published
         if (early) issue_step(P + S - 1);             // into the slot of step P - 1
         read1(P, F[P & 1]);
         if (P > 0) mma(F[(P - 1) & 1], two1);
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 
     // ---- hid = gelu(acc + b1), split, over the x2 planes (every wave is past its last read of them behind the next barrier)
     publish(KS1);                                     // first phase-2 step has landed too
+    stamp();                                          // 10: phase 1 done
     issue_step(KS1 + S - 1);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         for (int t = 0; t < TT; ++t) accM[a][t] = accC[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();                     // hid planes visible
+    stamp();                                          // 11: GELU phase done
 
     // ---- phase 2: part^T[out][token] = W2[:, slice] . hid^T
     read2(0, F[0]);
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 #pragma unroll
     for (int q = 1; q < KS2; ++q) {
         publish(KS1 + q);
+        stamp();                                      // 11 + q
         if (early) issue_step(KS1 + q + S - 1);
         if (q == KS2 - 1 && sl == 0) {                // slab 0 carries the residual and the output bias: plain loads, younger than every DMA (the wait above was vmcnt(0))
             bres = *reinterpret_cast<const float4 *>(b2 + ((tid & 63) << 2));
@@ -340,6 +356,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
             v.w = accM[a][t][3] + accC[a][t][3] * LO_UNSCALE;
             *reinterpret_cast<float4 *>(Cs + (16 * t + n) * CSS + (o0 + a) * 16 + 4 * g) = v;
         }
+    stamp();                                          // 18: last MFMAs issued, tile staged
     __syncthreads();
     float *out = parts + (size_t)sl * M * D;
 #pragma unroll
@@ -351,8 +368,10 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
             const float4 x = xres[it];
             v.x += x.x + bres.x; v.y += x.y + bres.y; v.z += x.z + bres.z; v.w += x.w + bres.w;
         }
-        idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
+        if constexpr (MODE == 4) { if (v.x == 12345.678f) idf_store16_wt(out + (size_t)gr * D + c4, v); }      // ablation: no slab stores (never true)
+        else idf_store16_wt(out + (size_t)gr * D + c4, v);          // the slabs are read next by other XCDs: write through (common.h)
     }
+    stamp();                                          // 19: stores issued
 }
 
 // EXCLUSIVE CU.  While this kernel ran beside OTHER kernels' workgroups on the same CU (two streams: the staggered-chains option of

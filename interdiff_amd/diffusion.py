@@ -134,17 +134,25 @@ class GaussianDiffusion:
                                  mask=torch.empty(img.shape, dtype=torch.uint8, device=dev) if has_mask else None, graphs={})
             st.kwargs = {'y': {'cond': st.cond}}              # what the captured denoiser calls see
             if len(cache) >= MAX_GRAPH_SHAPES:
-                cache.clear()                        # this cache's graphs and the buffers IT allocated (x, x0, cond, chain workspaces); the
-                                                     # denoiser's own per-shape pools stay: a graph captured elsewhere (bench.py, an integrator
-                                                     # following INTEGRATION.md) may have baked their addresses in
+                # drop this cache's graphs, the buffers IT allocated (x, x0, cond, chain and hook workspaces) and the entries of the denoiser's
+                # per-shape pools that were created FOR these graphs (st.pool_keys, recorded below); pool entries that existed before -- a
+                # graph captured elsewhere (bench.py, an integrator following INTEGRATION.md) may have baked their addresses in -- stay
+                evicted = list(cache.values())
+                cache.clear()
+                if hasattr(model, 'forget_shape_buffers'):
+                    for old in evicted:
+                        model.forget_shape_buffers(getattr(old, 'pool_keys', ()))
             cache[key] = st
             fresh = True
+            pools_before = None
         else:
             fresh = False
         st.cond.copy_(cond)
         if has_mask:
             st.gt.copy_(gc)
             st.mask.copy_(mu8)
+        if fresh and hasattr(model, 'shape_buffer_keys'):
+            pools_before = model.shape_buffer_keys()        # (taken before the first fold of this shape allocates its memory context)
         model.prepare_memory(st.cond)                   # once per sample, on the current stream (inside the caller's clock)
         rows_kw = {'batch_rows': rows} if getattr(model, 'accepts_batch_rows', False) else {}
         if fresh:
@@ -155,6 +163,8 @@ class GaussianDiffusion:
                 scratch = SimpleNamespace(x=st.x.clone(), ts=st.ts.clone(), state=torch.tensor([1, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev))
                 model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
             torch.cuda.synchronize(dev)
+            if pools_before is not None:              # what this cache entry made the denoiser allocate: released with the entry
+                st.pool_keys = model.shape_buffer_keys() - pools_before
 
         def posterior(x, x0, g, mk, st):
             _lib.check(lib.interdiff_posterior_step_dev(_lib.dptr(x), _lib.dptr(x0), _lib.dptr(g, allow_none=True),

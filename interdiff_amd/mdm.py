@@ -374,6 +374,23 @@ class MDM:
         self._ws, self._ws_shape = ws, (B, T)
         return ws
 
+    def shape_buffer_keys(self):
+        """Names of the per-shape buffers the model currently owns (the sampler records which ones a cache entry caused, diffusion.py)."""
+        return {('ws',) + k for k in self._ws_pool} | {('memctx', k) for k in self._memctx_pool}
+
+    def forget_shape_buffers(self, keys):
+        """Drop the named per-shape buffers (``shape_buffer_keys``): called by the sampler's graph cache for the entries ITS evicted graphs
+        had caused -- every graph that baked their addresses in is gone by then.  Buffers in current use are re-created on demand."""
+        for k in keys:
+            if k[0] == 'ws':
+                ws = self._ws_pool.pop(tuple(k[1:]), None)
+                if ws is not None and ws is self._ws:
+                    self._ws = self._ws_shape = None
+            elif k[0] == 'memctx':
+                mc = self._memctx_pool.pop(k[1], None)
+                if mc is not None and mc is self._memctx:
+                    self._memctx = self._mem_key = self._mem_cond = None
+
     def release_shape_buffers(self):
         """Drop the per-shape workspaces and memory contexts.  EVERY hipGraph that captured a call of this model -- the sampler's
         per-denoiser cache (``_graph_cache``), bench / integrator graphs around ``forward`` -- must have been destroyed first: their

@@ -55,6 +55,19 @@ __host__ __device__ constexpr int pair_ins(int P) {   // 1-KiB DMA instructions 
 
 __device__ __forceinline__ float4 ldsv4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Workgroup -> (M tile, slice): M-tile-major over XCD-AFFINE logical ids (round 4).  Workgroup id runs on XCD id % 8, each with its own L2;
+// giving one XCD consecutive logical ids puts ALL slices of an M tile on one XCD, so the tile's input rows (x2: 32 KiB; for the QKV
+// kernel 32 rows x up to five slabs = 160 KiB) cross the fabric once instead of once per slice, and the tile's output slabs are written
+// from one XCD.  Measured on the split-f16 kernel in one process (tools/ffn_h2_ab.py, profiles/r04_ffn_split_f16_ab.txt): denoiser forward
+// 212 vs 226-230 us, whole samples 0.2363 vs 0.2437 ms/step against plain ids (where the five slices of a tile land on five XCDs);
+// slice-major affine ids (an XCD streams one or two of the five weight streams instead of all) win a burst of launches and lose in situ.
+__device__ __forceinline__ void xcd_affine_tile(int nwg, int id, int nsl, int &mt, int &sl) {
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    mt = wg / nsl;
+    sl = wg - mt * nsl;
+}
+
 // s_waitcnt vmcnt(n): the literal has to be an immediate; n is a constant after unrolling (the switch folds away)
 __device__ __forceinline__ void wait_vmcnt_n(int n) {
     switch (n) {
@@ -147,7 +160,9 @@ __global__ __launch_bounds__(NT) void ffn_fused_kernel(const float *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BM;
+    int mt, sl;
+    xcd_affine_tile(gridDim.x, blockIdx.x, NSL, mt, sl);
+    const int m0 = mt * BM;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
     const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;                 // byte offset of this lane's 16 B inside a pair: instruction wave + 8 j adds 8192 j
@@ -364,7 +379,9 @@ __global__ __launch_bounds__(NT) void ffn_fused16_kernel(const float *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BMH;
+    int mt, sl;
+    xcd_affine_tile(gridDim.x, blockIdx.x, NSL, mt, sl);
+    const int m0 = mt * BMH;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
     const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;
@@ -540,7 +557,9 @@ __global__ __launch_bounds__(NT) void ffn_fused64_kernel(const float *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x, mt = wg / NSL, sl = wg - mt * NSL, m0 = mt * BMX;
+    int mt, sl;
+    xcd_affine_tile(gridDim.x, blockIdx.x, NSL, mt, sl);
+    const int m0 = mt * BMX;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
     const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;
@@ -725,15 +744,17 @@ __global__ __launch_bounds__(NT) void ln_linear_kernel(const float *__restrict__
                                                         const float *__restrict__ lnb, int M, const float *__restrict__ pack,
                                                         const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
                                                         float *__restrict__ xn_out, int64_t *__restrict__ step_state,
-                                                        int64_t *__restrict__ step_ts, int step_B) {
+                                                        int64_t *__restrict__ step_ts, int step_B, int nsl_grid) {
     __shared__ __attribute__((aligned(1024))) float smem[XS + 3 * LPSLOT];
-    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
+    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl_grid, gridDim.x);
     // sampler bookkeeping of a fused plain step (philox.h): nobody else touches these words while this kernel runs
-    if (step_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
+    if (step_state && blockIdx.x == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
     float *Xs = smem, *ring = smem + XS;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = blockIdx.x, sl = blockIdx.y, m0 = mt * BM, n0 = sl * LHS;
+    int mt, sl;
+    xcd_affine_tile(gridDim.x, blockIdx.x, nsl_grid, mt, sl);             // all column slices of an M tile on one XCD: its (up to five-slab) input rows cross the fabric once
+    const int m0 = mt * BM, n0 = sl * LHS;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * (16 * LW1C));
     const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
     const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
@@ -843,8 +864,9 @@ template <int NP>
 inline void launch_ln_linear(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
                              const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
                              int64_t *step_ts = nullptr, int step_B = 0) {
-    hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)idf_cdiv(M, BM), (unsigned)idf_cdiv(N, LHS)), dim3(NT), 0, s, A, a_pstride, lnw, lnb,
-                       M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B);
+    const int nsl = (int)idf_cdiv(N, LHS);
+    hipLaunchKernelGGL(ln_linear_kernel<NP>, dim3((unsigned)(idf_cdiv(M, BM) * nsl)), dim3(NT), 0, s, A, a_pstride, lnw, lnb,
+                       M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl);
 }
 
 // rows: 16 / 32 / 64 = the M tile to use; 0 = choose by THIS launch's rows (ffn_tile_for_rows).  The kernels differ in the rounding of one

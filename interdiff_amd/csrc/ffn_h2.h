@@ -90,6 +90,22 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     lo = __builtin_bit_cast(uint2, (h4{b0, b1, b2, b3}));
 }
 
+// gelu_fast (common.h) on a PAIR of values: packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) cost a wave what the
+// plain ones cost, so the polynomial runs at half the issue slots; rcp / exp stay per element.  Same operations in the same order as gelu_fast.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 gelu_fast2(f2 x) {
+    const f2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f2 z = ax * 0.70710678118654752440f;
+    const f2 d = 1.0f + 0.3275911f * z;
+    const f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f2 p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const f2 zz = -(z * z);
+    const f2 ex = {__expf(zz.x), __expf(zz.y)};
+    const f2 er = 1.0f - p * ex;
+    const f2 se = {copysignf(er.x, x.x), copysignf(er.y, x.y)};
+    return 0.5f * x * (1.0f + se);
+}
+
 #define IDF_H2_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0)
 
 // TT = token tiles of 16 rows per workgroup (1, 2, 4 -> BM = 16, 32, 64); S = ring slots (3; 2 for TT = 4, where the planes take 64 KiB).
@@ -122,16 +138,17 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         }
     };
     stamp();
-    // Workgroup order.  order 0 (shipped): ffn.h's M-tile-major ids.  order 1 (A/B only, tools/ffn_h2_ab.py): SLICE-major over XCD-affine
-    // logical ids -- workgroup id runs on XCD id % 8, each with its own 4-MiB L2; giving one XCD consecutive logical ids and walking the
-    // M tiles of one slice before the next slice, an XCD streams one or two of the five 432-KiB slice streams through its L2 (13 slice
-    // loads per launch over the fabric) instead of all five (40).  Measured in one process (profiles/r04_ffn_split_f16_ab.txt): a burst of
-    // launches 10.9 vs 11.4 us, but the denoiser forward 231-236 vs 223-228 us and whole samples 0.2215 vs 0.2207 ms/step -- in situ the
-    // M-tile-major order is no worse, so it stays.
+    // Workgroup order.  order 0 (shipped): M-tile-major over XCD-AFFINE logical ids (ffn.h xcd_affine_tile: all five slices of an M tile on one
+    // XCD -- its x2 rows cross the fabric once, its slabs are written from one XCD).  A/B only (tools/ffn_h2_ab.py): order 1 = slice-major
+    // affine ids (an XCD streams one or two of the five 432-KiB weight streams: 13 instead of 40 slice loads per launch), order 2 = plain ids
+    // (rounds 1-3: the five slices of a tile on five XCDs).  One process (profiles/r04_ffn_split_f16_ab.txt): bursts 10.6 / 10.5 / 12.1 us,
+    // denoiser forward 212 / 234-238 / 226-230 us, whole samples with correction 0.2363 / 0.2446 / 0.2437 ms per step for orders 0 / 1 / 2.
     const int nwg = gridDim.x, id = blockIdx.x, nmt = nwg / NSL;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
-    const int sl = order ? wg / nmt : id % NSL, mt = order ? wg - sl * nmt : id / NSL, m0 = mt * BM;       // order 0: ffn.h's M-tile-major ids (A/B: tools/ffn_h2_ab.py)
+    // order 0: ffn.h's M-tile-major ids; 1: slice-major over XCD-affine ids; 2: M-tile-major over XCD-affine ids (an XCD holds ALL slices of its M tiles: x2 rows
+    // cross the fabric once instead of five times, every XCD still streams all five slices)   (A/B: tools/ffn_h2_ab.py)
+    const int sl = order == 1 ? wg / nmt : (order == 2 ? id % NSL : wg % NSL), mt = order == 1 ? wg - sl * nmt : (order == 2 ? id / NSL : wg / NSL), m0 = mt * BM;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
     const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;                 // this lane's 16 B inside a step: instruction wave + 8 j adds 8192 j
@@ -291,11 +308,11 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
             const int chunk = 2 * (h0 + a) + (g >> 1);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
-                float4 v;
-                v.x = gelu_fast(accM[a][t][0] + accC[a][t][0] * LO_UNSCALE + bv.x);
-                v.y = gelu_fast(accM[a][t][1] + accC[a][t][1] * LO_UNSCALE + bv.y);
-                v.z = gelu_fast(accM[a][t][2] + accC[a][t][2] * LO_UNSCALE + bv.z);
-                v.w = gelu_fast(accM[a][t][3] + accC[a][t][3] * LO_UNSCALE + bv.w);
+                const f2 m01 = {accM[a][t][0], accM[a][t][1]}, m23 = {accM[a][t][2], accM[a][t][3]};
+                const f2 c01 = {accC[a][t][0], accC[a][t][1]}, c23 = {accC[a][t][2], accC[a][t][3]};
+                const f2 b01 = {bv.x, bv.y}, b23 = {bv.z, bv.w};
+                const f2 g01 = gelu_fast2(m01 + c01 * LO_UNSCALE + b01), g23 = gelu_fast2(m23 + c23 * LO_UNSCALE + b23);
+                const float4 v = make_float4(g01.x, g01.y, g23.x, g23.y);
                 uint2 hi, lo;
                 split4(v, hi, lo);
                 float *dst = Xs + (16 * t + n) * 256 + ((chunk ^ n) << 2) + ((g & 1) << 1);

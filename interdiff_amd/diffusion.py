@@ -82,7 +82,7 @@ class GaussianDiffusion:
         self._tables = {}
         self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
         self.split_chains = True             # ... and, for batches that do not fill the chip, as two independent half-batch chains
-        self.split_min_rows = None           # ... when the batch has more token rows than this (None: the denoiser's FFN16_MAX_ROWS, see _graph_loop)
+        self.split_min_rows = None           # ... when the batch has more token rows than this (None: the denoiser's one_chain_max_rows(), see _graph_loop)
         self.stagger_steps = STAGGER_STEPS   # ... which step through the WHOLE loop on their own streams, this many steps apart, when the hook can be called per half batch
         self._uid = next(_UID)               # names this schedule in the per-denoiser graph cache (never reused, unlike id())
 
@@ -179,7 +179,7 @@ class GaussianDiffusion:
         # splits into parts that differ by one clip (more than two chains measured slower: 0.296 / 0.309 vs 0.281 ms per step with 3 / 4 at B = 16).
         nch = N_CHAINS
         split = (fused and self.split_chains and nch > 1 and 2 * nch <= B <= SPLIT_MAX_BATCH
-                 and B * img.shape[-1] > (getattr(model, 'FFN16_MAX_ROWS', 0) if self.split_min_rows is None else self.split_min_rows))      # smaller batches: launch-latency bound either way, and the feed-forward's 16-row grid already spans the chip (tools/small_batch_ab.py: equal at B = 8, one chain 7 % faster at B = 4)
+                 and B * img.shape[-1] > ((model.one_chain_max_rows() if hasattr(model, 'one_chain_max_rows') else getattr(model, 'FFN16_MAX_ROWS', 0)) if self.split_min_rows is None else self.split_min_rows))      # smaller batches: launch-latency bound either way, and the feed-forward's 16-row grid already spans the chip (tools/small_batch_ab.py: equal at B = 8, one chain 7 % faster at B = 4)
         if split and not hasattr(st, 'chains'):
             st.chains = []
             for c in range(nch):

@@ -467,6 +467,16 @@ class MDM:
 
     FFN16_MAX_ROWS, FFN64_MIN_ROWS = 800, 2800      # csrc/ffn.h
 
+    def one_chain_max_rows(self):
+        """Up to how many token rows the sampler steps a batch as ONE kernel chain (diffusion.py _graph_loop).  Exact-fp32 feed-forward: 800 (the
+        16-row grid's one round; above, two half-batch chains overlap each other's latency: round 3).  Split-f16 feed-forward: 1632 = 51 tiles
+        of 32 rows x 5 slices = 255 workgroups, ONE round on 256 CUs -- the kernel owns its CUs (csrc/ffn_h2.h "exclusive CU"), so a second chain can
+        no longer slip its small kernels beside it, and up to one round a single chain is ahead (same process, whole samples with correction,
+        tools/chains_ab.py: 12 clips 0.2171 vs 0.2252, 16 clips 0.2300 vs 0.2372 ms per step; beyond one round two chains win big: 17 clips 0.2455 vs
+        0.3135, 20: 0.2545 vs 0.3310, 24: 0.2875 vs 0.3412, 32: 0.3362 vs 0.3495)."""
+        return 32 * (256 // _lib.FFN_SLICES) if self.ffn_math == 'split' else self.FFN16_MAX_ROWS
+
+
     @classmethod
     def ffn_tile_for_rows(cls, rows):
         """csrc/ffn.h ffn_tile_for_rows, for the rows of a whole batch: 16-row tiles while their grid fits the chip in one round of

@@ -1398,7 +1398,7 @@ def test_timed_route_equals_eager_at_bench_shape(lib, mdm, smpl, B, T):
     assert diff.fuse_plain_step and diff.split_chains
     timed = run(seed=seed)
     st = [v for k, v in mdm._graph_cache.items() if k[0] == diff._uid and k[1] == tuple(x_t.shape)]
-    two = B * T > mdm.FFN16_MAX_ROWS and B >= 4
+    two = B * T > mdm.one_chain_max_rows() and B >= 4
     assert len(st) == 1 and (hasattr(st[0], 'chains') and len(st[0].chains) == 2) == two, 'two-chain route %s' % ('not taken' if two else 'taken')
     flags = [(key[3], key[4]) if key[0] == 'hook' else (key[1], key[2]) for key in st[0].graphs if isinstance(key, tuple)]       # (fused, split) of plain-step and hook-step graphs
     assert all(f and sp == two for f, sp in flags), 'fused%s graphs expected: %r' % (' + split' if two else '', list(st[0].graphs))

@@ -32,7 +32,7 @@ def main():
     dev = torch.device('cuda:0')
     model, corr, bt, y, (sd, _, _) = bench.build_world(dev, 0)
     diff = create_gaussian_diffusion('cosine', bench.STEPS)
-    for N in (800, 1600, 3200):
+    for N in (1600,):
         row = {}
         for math in ('exact', 'split'):
             model.ffn_math = math
@@ -44,9 +44,9 @@ def main():
         print('ffn', N, json.dumps(row), flush=True)
     from interdiff_amd import _lib
     for rep in range(3):
-        for math in ('split', 'split_slice_major'):
+        for math in ('split', 'split_slice_major', 'split_plain_ids'):
             model.ffn_math = 'split'
-            model.w.tune[_lib.TUNE['misc']] = 2 if math == 'split_slice_major' else 0
+            model.w.tune[_lib.TUNE['misc']] = {'split_slice_major': 2, 'split_plain_ids': 3}.get(math, 0)
             if rep == 0:
                 print('burst', math, time_ffn(model, dev, 1600), time_ffn(model, dev, 800), flush=True)
             model.__dict__.pop('_graph_cache', None)

@@ -133,6 +133,9 @@ typedef struct {
     int64_t ffn_pack_h2;       /* 0, or linear1 + linear2 split into two f16 planes (hi, residual x 2^11) in the split-f16 FFN kernel's stream order
                                   (5 x 110592 floats, mdm.py pack_ffn_h2; csrc/ffn_h2.h).  Only set when the packer has PROVED that no operand of
                                   this layer's feed-forward block can leave the f16 range (mdm.py ffn_h2_range_ok) */
+    int64_t sa_in_pack_h2;     /* std only: 0, or sa_in_w as two f16 planes in the split-f16 QKV kernel's stream order (5 slices x 8 K steps
+                                  [10 tiles][2 planes][64 lanes][8 halves], rows past 768 zero; mdm.py pack_linear160_h2; csrc/ffn_h2.h
+                                  ln_linear_h2_kernel).  The kernel scales every input row by a power of two, so only the weights' range matters */
 } idf_mdm_layer;
 
 typedef struct {
@@ -156,7 +159,7 @@ typedef struct {
      * the other two to rounding (7e-7 of the output scale), not bit for bit: a caller that steps ONE batch as several calls on row subsets (the
      * sampler's half-batch chains) sets 1 or 2 from the rows of the whole batch so that every call takes the same kernel
      * (interdiff_amd/mdm.py: MDM._pick_ffn_tile does this before every forward / forward_step / encode / ffn call).
-     * tune[IDF_TUNE_FFN_MATH] selects the arithmetic of the feed-forward block: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/ffn.h),
+     * tune[IDF_TUNE_FFN_MATH] selects the arithmetic of the feed-forward block AND of the QKV projection (layers whose sa_in_pack_h2 is set): 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/ffn.h),
      * 1 = split-f16 (every fp32 operand as two f16 planes, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate: fp32-grade
      * results at 1/43 of the matrix-pipe time, csrc/ffn_h2.h) for every layer whose ffn_pack_h2 is set, exact fp32 for the others.  Its
      * 16-, 32- and 64-row tiles are bit-identical, so with 1 the row tile is a pure performance choice. */

@@ -767,13 +767,20 @@ void run_heads_post(int cfg, hipStream_t s, const Args &g, int np) {
 }
 // QKV projection: the LayerNorm+linear kernel of ffn.h (tune 0) or, for A/B runs, one of the generic GEMM configurations
 // step_state != null (layer 0 of interdiff_mdm_forward_step): one thread of the launch does the step's sampler bookkeeping (philox.h)
-void run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, int64_t *step_state = nullptr, int64_t *step_ts = nullptr,
-             int step_B = 0) {
-    if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return; }
+// pack_h2 != null: the split-f16 form (ffn_h2.h ln_linear_h2_kernel: tune[IDF_TUNE_FFN_MATH] == 1 and the layer's sa_in_pack_h2 is set)
+int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, int64_t *step_state = nullptr, int64_t *step_ts = nullptr,
+            int step_B = 0, const float *pack_h2 = nullptr) {
+    if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return IDF_OK; }
+    if (pack_h2) {
+        if (np == NSL)
+            return idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+        return idf_ffn_h2::launch_ln_linear_h2<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+    }
     if (np == NSL)
         idf_ffn::launch_ln_linear<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
     else
         idf_ffn::launch_ln_linear<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+    return IDF_OK;
 }
 
 }  // namespace
@@ -884,7 +891,8 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
-            run_qkv(0, s, g, ar + ly.sa_in_pack, u_np);
+            if (const int rc = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0,
+                                       (w->tune[IDF_TUNE_FFN_MATH] == 1 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr); rc != IDF_OK) return rc;
             hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s,
                                k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
             hipLaunchKernelGGL((rowblock_kernel<false, false, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
@@ -971,8 +979,11 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
-            if (post.x && l == 0) run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B);
-            else run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np);
+            const float *qkv_h2 = (tune[IDF_TUNE_FFN_MATH] == 1 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr;
+            int rcq;
+            if (post.x && l == 0) rcq = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B, qkv_h2);
+            else rcq = run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0, qkv_h2);
+            if (rcq != IDF_OK) return rcq;
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             if (tune[IDF_TUNE_GEMM_OUTPROJ] == 0) {
                 // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's

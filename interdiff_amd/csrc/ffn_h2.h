@@ -36,6 +36,8 @@
 //    P - 1 run while they land (register double buffer).
 #pragma once
 #include "common.h"
+#include "philox.h"
+#include "ffn.h"
 
 namespace idf_ffn_h2 {
 
@@ -414,5 +416,196 @@ inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pac
     if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts, order);
     if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts, order);
     return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts, order);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm + linear (the QKV projection of the two standard layers) on the same arithmetic: C[M,N] = LN(sum of NP slabs of A) . W^T + bias,
+// ffn.h's ln_linear_kernel with the contraction as three f16 MFMAs per product.  Grid, row fetch, LayerNorm, the 160-column slices, the
+// 20-KiB ring steps, the DMA shares of the waves (three instructions for waves 0..3, two for 4..7), the residual copy (xn_out) and the
+// sampler bookkeeping are ffn.h's.  What differs:
+//  * a ring step is one K = 32 step [10 tiles][2 planes][64 lanes][8 halves] (mdm.py pack_linear160_h2), 8 steps per slice -- the same 160 KiB;
+//  * the normalised rows are split into f16 planes in the layout of the feed-forward kernel above -- but ROW-SCALED: layer 0's input is the
+//    embedding output, not a LayerNorm output, so no bound on it can be proved from the weights; every row is multiplied by the power of two
+//    2^-e (e = exponent of the row's largest magnitude: exact) before the split and its outputs by 2^e afterwards (exact again), so the hi
+//    plane lives in [0.5, 1) x sign whatever the input's scale and nothing can leave f16's range;
+//  * weights are the A operand, tokens the B operand: D has lane = token, registers = 4 consecutive output columns (16-byte staging writes);
+//  * tile map: 2 token tiles x 10 column tiles; every wave covers both token tiles for its column tiles: waves 0, 1 own two (2w, 2w+1), waves 2..7 one (w + 2).
+constexpr int QCT = 10, QHS = QCT * 16;                  // column tiles / columns per workgroup (ffn.h LCT, LHS)
+constexpr int QSTEP = QCT * 2 * 1024;                    // bytes of a K step: 20 KiB
+constexpr int QSLICE_FLOATS = 8 * QSTEP / 4;             // 40960 floats per 160-column slice
+constexpr int QBM = 32;
+
+template <int NP>
+__global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, const float *__restrict__ lnw,
+                                                           const float *__restrict__ lnb, int M, const float *__restrict__ pack,
+                                                           const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
+                                                           float *__restrict__ xn_out, int64_t *__restrict__ step_state,
+                                                           int64_t *__restrict__ step_ts, int step_B, int nsl_grid) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    asm volatile("" ::: "v255");                       // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
+    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl_grid, gridDim.x);
+    if (step_state && blockIdx.x == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
+    float *Xs = smem, *ring = smem + QBM * 256, *Sc = ring + 3 * (QSTEP / 4);      // Sc [32]: 2^e of every row
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int mt, sl;
+    idf_ffn::xcd_affine_tile(gridDim.x, blockIdx.x, nsl_grid, mt, sl);
+    const int m0 = mt * QBM, n0 = sl * QHS;
+    const float *stream = idf_uniform_ptr(pack + (size_t)sl * QSLICE_FLOATS);
+    const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
+    const bool low = wave < NW / 2;                       // waves 0..3: a third DMA instruction per step
+    auto issue_step = [&](int P) {
+        if (P >= 8) return;
+        const uint32_t so = (uint32_t)(P * QSTEP), dof = (uint32_t)((P % 3) * QSTEP);
+        idf_dma16_s(stream, vsrc + so, sdst + dof);
+        idf_dma16_s(stream, vsrc + so + 8192u, sdst + dof + 8192u);
+        if (low) idf_dma16_s(stream, vsrc + so + 16384u, sdst + dof + 16384u);
+    };
+    auto wait_one_step_flying = [&]() {
+        if (low) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    };
+    issue_step(0);
+    issue_step(1);
+    {   // rows: slab sum, LayerNorm (null lnw: layer 0 takes the embedding as it is), residual copy, row scale, split into the plane image
+        const float4 gw = lnw ? *reinterpret_cast<const float4 *>(lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 gb = lnw ? *reinterpret_cast<const float4 *>(lnb + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[QBM / NW];
+#pragma unroll
+        for (int i = 0; i < QBM / NW; ++i) v[i] = ld4_sum<NP>(A + (size_t)min(m0 + wave + NW * i, M - 1) * D + lane * 4, a_pstride);
+#pragma unroll
+        for (int i = 0; i < QBM / NW; ++i) {
+            const int row = wave + NW * i;
+            float4 x = v[i];
+            if (lnw) {
+                float mean, rstd;
+                ln_row_stats(x, mean, rstd);
+                x.x = (x.x - mean) * rstd * gw.x + gb.x;
+                x.y = (x.y - mean) * rstd * gw.y + gb.y;
+                x.z = (x.z - mean) * rstd * gw.z + gb.z;
+                x.w = (x.w - mean) * rstd * gw.w + gb.w;
+            }
+            if (xn_out && sl == 0 && m0 + row < M) idf_store16_wt(xn_out + (size_t)(m0 + row) * D + lane * 4, x);
+            // power-of-two row scale: 2^-e with e the exponent of the row's largest magnitude (frexp form: |x| 2^-e in [0.5, 1)); an all-zero row keeps scale 1
+            const float amax = wave_max(fmaxf(fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w))));
+            const int e = amax > 0.f ? (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 126 : 0;
+            const float dn = __builtin_bit_cast(float, (uint32_t)((127 - e) << 23)), up = __builtin_bit_cast(float, (uint32_t)((127 + e) << 23));
+            x.x *= dn; x.y *= dn; x.z *= dn; x.w *= dn;
+            uint2 hi, lo;
+            split4(x, hi, lo);
+            float *dst = Xs + row * 256 + ((((lane >> 1) ^ (row & 15)) << 2)) + ((lane & 1) << 1);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 128) = lo;
+            if (lane == 0) Sc[row] = up;
+        }
+    }
+    wait_one_step_flying();                              // step 0 (and everything older) has landed; step 1 may fly
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+
+    const bool two = wave < 2;
+    const int c0 = two ? 2 * wave : wave + 2;
+    f32x4 accM[2][2], accC[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accM[a][t] = accC[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    struct Frags {
+        h8 wh[2], wl[2], xh[2], xl[2];
+    };
+    Frags F[2];
+    const int e_ = g ^ n;
+    auto ld8 = [&](const float *p) { return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(p)); };
+    auto rd = [&](int s, Frags &f) {
+        const float *sb = ring + (s % 3) * (QSTEP / 4) + c0 * 512 + lane * 4;
+        f.wh[0] = ld8(sb);
+        f.wl[0] = ld8(sb + 256);
+        if (two) {
+            f.wh[1] = ld8(sb + 512);
+            f.wl[1] = ld8(sb + 768);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *row = Xs + (16 * t + n) * 256 + ((e_ ^ (4 * s)) << 2);
+            f.xh[t] = ld8(row);
+            f.xl[t] = ld8(row + 128);
+        }
+    };
+    auto mma = [&](const Frags &f) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accM[0][t], f.wh[0], f.xh[t]);
+        if (two) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accM[1][t], f.wh[1], f.xh[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accC[0][t], f.wh[0], f.xl[t]);
+        if (two) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accC[1][t], f.wh[1], f.xl[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accC[0][t], f.wl[0], f.xh[t]);
+        if (two) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) IDF_H2_MFMA(accC[1][t], f.wl[1], f.xh[t]);
+        }
+    };
+#pragma unroll
+    for (int P = 0; P < 8; ++P) {
+        if (P > 0) {                                     // step P has landed for every wave, and every wave is done with step P - 1's slot
+            if (P + 1 < 8) wait_one_step_flying();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        issue_step(P + 2);
+        rd(P, F[P & 1]);
+        if (P > 0) mma(F[(P - 1) & 1]);
+    }
+    mma(F[1]);
+    // epilogue: x 2^e of the row, + bias, through LDS (over the ring, once every wave is done reading it), 16-byte row stores (write-through)
+    constexpr int QCS = QHS + 4;
+    float *Cs = ring;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a == 0 || two) {
+            const int col = (c0 + a) * 16 + 4 * g;
+            float4 bv;
+            bv.x = bias[min(n0 + col, N - 1)]; bv.y = bias[min(n0 + col + 1, N - 1)]; bv.z = bias[min(n0 + col + 2, N - 1)]; bv.w = bias[min(n0 + col + 3, N - 1)];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float up = Sc[16 * t + n];
+                float4 v;
+                v.x = (accM[a][t][0] + accC[a][t][0] * LO_UNSCALE) * up + bv.x;
+                v.y = (accM[a][t][1] + accC[a][t][1] * LO_UNSCALE) * up + bv.y;
+                v.z = (accM[a][t][2] + accC[a][t][2] * LO_UNSCALE) * up + bv.z;
+                v.w = (accM[a][t][3] + accC[a][t][3] * LO_UNSCALE) * up + bv.w;
+                *reinterpret_cast<float4 *>(Cs + (16 * t + n) * QCS + col) = v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (QBM * (QHS / 4) + NT - 1) / NT; ++it) {
+        const int idx = tid + it * NT, row = idx / (QHS / 4), c4 = (idx - row * (QHS / 4)) << 2, gr = m0 + row;
+        if (idx < QBM * (QHS / 4) && gr < M && n0 + c4 < N) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, *reinterpret_cast<const float4 *>(Cs + row * QCS + c4));
+    }
+}
+
+template <int NP>
+inline int launch_ln_linear_h2(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
+                               const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
+                               int64_t *step_ts = nullptr, int step_B = 0) {
+    static std::atomic<uint64_t> done{0};
+    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP>), LDS_REQUEST, done);
+    if (rc != IDF_OK) return rc;
+    const int nsl = (int)idf_cdiv(N, QHS);
+    hipLaunchKernelGGL(ln_linear_h2_kernel<NP>, dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, lnw, lnb,
+                       M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl);
+    return IDF_OK;
 }
 }  // namespace idf_ffn_h2

@@ -189,6 +189,19 @@ def pack_linear160(w):
     return np.concatenate(out)
 
 
+def pack_linear160_h2(w):
+    """[N,256] weight -> the split-f16 QKV kernel's stream (csrc/ffn_h2.h ln_linear_h2_kernel), as float32 words: per 160-row slice (the
+    last one zero-padded past N) the 8 K steps [10 tiles][2 planes][64 lanes][8 halves] (20 KiB each) of ``_h2_fragments``."""
+    w = np.asarray(w, np.float32)
+    assert w.shape[1] == D
+    ns = -(-w.shape[0] // QKV_SLICE)
+    wp = np.zeros((ns * QKV_SLICE, D), np.float32)
+    wp[:w.shape[0]] = w
+    out = np.concatenate([_h2_fragments(wp[n0:n0 + QKV_SLICE], 32 * s) for n0 in range(0, wp.shape[0], QKV_SLICE) for s in range(D // 32)])
+    assert out.size * 2 == ns * QKV_SLICE * D * 4
+    return out.view(np.float32)
+
+
 def sa_out_fragments(w):
     """out_proj.weight [256 out, 256 in] -> MFMA B-operand fragment order of the attention kernel's out-projection tail
     (csrc/denoiser.hip self_attn_kernel<true>): [head][wave = output column quarter][k-group of 16][column tile][lane = kq*16+li][4],
@@ -258,6 +271,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         else:
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
             ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
+            ly.sa_in_pack_h2 = ar.add(pack_linear160_h2(g(p + 'self_attn.in_proj_weight'))) if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT else 0
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
             ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))
@@ -289,6 +303,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             else:
                 ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
                 ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
+                ly.sa_in_pack_h2 = ar.add(pack_linear160_h2(g(p + 'self_attn.in_proj_weight'))) if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT else 0
                 ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
                 ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
                 ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))

@@ -465,3 +465,99 @@ def emulate_ffn_h2(x2, pack_words, b1p, b2, late, bm=32):
             o = emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm)
             parts[sl, mt * bm:mt * bm + o.shape[0]] = o
     return parts
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# csrc/ffn_h2.h ln_linear_h2_kernel (split-f16 QKV projection), one workgroup: rows normalised, scaled by a power of two and split
+# into the plane image; 8 K steps [10 tiles][2 planes][64 lanes][8 halves] through a 3-slot ring (waves 0..3 three DMA instructions per
+# step, waves 4..7 two); weights as the A operand; outputs x 2^e + bias.
+def emulate_ln_linear_h2(slabs, lnw, lnb, pack_words, bias, N, late):
+    from interdiff_amd.mdm import split_f16
+    NP_, M, _ = slabs.shape
+    QSTEP, nsl = 10 * 2 * 1024, -(-N // 160)
+    out = np.zeros((M, N))
+    stream_all = np.frombuffer(np.ascontiguousarray(pack_words).tobytes(), np.uint8)
+    lane = np.arange(64)
+    n, g = lane & 15, lane >> 4
+    for mt in range(-(-M // 32)):
+        for sl in range(nsl):
+            stream = stream_all[sl * 8 * QSTEP:(sl + 1) * 8 * QSTEP]
+            planes, ring, pending = np.zeros(32 * 1024, np.uint8), np.full(3 * QSTEP, 0x7e, np.uint8), {}
+            scale = np.ones(32)
+
+            def issue(P):
+                if P >= 8:
+                    return
+                ops = []
+                for wave in range(NW):
+                    for j in range(3 if wave < 4 else 2):
+                        i = wave + 8 * j
+                        ops.append(((P % 3) * QSTEP + 1024 * i, stream[P * QSTEP + 1024 * i:P * QSTEP + 1024 * (i + 1)].copy()))
+                assert sorted(d - (P % 3) * QSTEP for d, _ in ops) == [1024 * i for i in range(20)]
+                if late:
+                    pending[P] = ops
+                else:
+                    for d, data in ops:
+                        ring[d:d + 1024] = data
+
+            def land(P):
+                for Q in sorted(k for k in pending if k <= P):
+                    for d, data in pending.pop(Q):
+                        ring[d:d + 1024] = data
+            issue(0)
+            issue(1)
+            for r in range(32):
+                x = slabs[:, min(mt * 32 + r, M - 1)].astype(np.float32)
+                row = x[0].copy()
+                for k in range(1, NP_):
+                    row = row + x[k]
+                if lnw is not None:
+                    mean = row.astype(np.float64).mean()
+                    row = ((row - mean) / np.sqrt(((row - mean) ** 2).mean() + 1e-5) * lnw + lnb).astype(np.float32)
+                amax = np.abs(row).max()
+                e = int(np.frexp(amax)[1]) if amax > 0 else 0
+                scale[r] = 2.0 ** e
+                hi, lo = split_f16(row * np.float32(2.0 ** -e))
+                assert np.abs(hi.astype(np.float32)).max() < 1.0
+                for l in range(64):
+                    a = r * 1024 + (((l >> 1) ^ (r & 15)) << 4) + 8 * (l & 1)
+                    planes[a:a + 8] = np.frombuffer(hi[4 * l:4 * l + 4].tobytes(), np.uint8)
+                    planes[a + 512:a + 520] = np.frombuffer(lo[4 * l:4 * l + 4].tobytes(), np.uint8)
+
+            def halves(buf, addr):
+                return buf[addr[:, None] + np.arange(16)[None, :]].copy().view(np.float16).astype(np.float64)
+            tiles = {w: ([2 * w, 2 * w + 1] if w < 2 else [w + 2]) for w in range(NW)}
+            acc = {(w, a, t): [np.zeros((16, 16)), np.zeros((16, 16))] for w in range(NW) for a in range(len(tiles[w])) for t in range(2)}
+            prev = None
+            for P in range(9):
+                if P < 8:
+                    land(P)
+                    issue(P + 2)
+                    xs = [(halves(planes, (16 * t + n) * 1024 + (((g ^ n) ^ (4 * P)) << 4)), halves(planes, (16 * t + n) * 1024 + 512 + (((g ^ n) ^ (4 * P)) << 4))) for t in range(2)]
+                    ws = {w: [(halves(ring, (P % 3) * QSTEP + (2 * c) * 1024 + lane * 16), halves(ring, (P % 3) * QSTEP + (2 * c + 1) * 1024 + lane * 16)) for c in tiles[w]] for w in range(NW)}
+                    cur = (xs, ws)
+                if prev is not None:
+                    xs_p, ws_p = prev
+                    for w in range(NW):
+                        for a, (wh, wl) in enumerate(ws_p[w]):
+                            for t in range(2):
+                                xh, xl = xs_p[t]
+                                m, c = acc[(w, a, t)]
+                                mm = lambda acc_, A_, B_: acc_ + np.einsum('gij,gnj->in', A_.reshape(4, 16, 8), B_.reshape(4, 16, 8))
+                                acc[(w, a, t)] = [mm(m, wh, xh), mm(mm(c, wh, xl), wl, xh)]
+                prev = cur if P < 8 else None
+            assert not pending
+            for w in range(NW):
+                for a, c in enumerate(tiles[w]):
+                    for t in range(2):
+                        m, cc = acc[(w, a, t)]
+                        tile = (m + cc / 2048.0).T * scale[16 * t:16 * t + 16, None]            # [token][col]
+                        for rr in range(16):
+                            gr = mt * 32 + 16 * t + rr
+                            if gr >= M:
+                                continue
+                            for k in range(16):
+                                col = sl * 160 + 16 * c + k
+                                if col < N:
+                                    out[gr, col] = tile[rr, k] + bias[col]
+    return out

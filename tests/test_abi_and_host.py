@@ -316,6 +316,33 @@ def test_qkv_pack_and_kernel_addressing_by_emulation():
     assert np.abs(emulate_ln_linear(slabs[:1], None, None, pack, b, N, True) - (slabs[0].astype(np.float64) @ w.T + b)).max() < 1e-9
 
 
+def test_split_f16_qkv_pack_and_kernel_addressing_by_emulation():
+    """The split-f16 LayerNorm + linear kernel (csrc/ffn_h2.h ln_linear_h2_kernel) restated lane by lane (tests/ffn_emulator.py) on the stream
+    pack_linear160_h2 builds: LN(sum of the five slabs) . W^T + b for a ragged row count, the power-of-two ROW SCALE (rows of very different
+    magnitude, incl. values far outside f16's range: the plane image must stay inside [0.5, 1)), DMA applied at issue and at the wait; also
+    without LayerNorm (layer 0: the embedding output as it is)."""
+    import numpy as np
+    from interdiff_amd.mdm import pack_linear160_h2
+    from tests.ffn_emulator import emulate_ln_linear_h2
+    rs = np.random.RandomState(1)
+    M, N = 37, 768
+    slabs = rs.standard_normal((5, M, 256)).astype(np.float32)
+    w = (rs.standard_normal((N, 256)) / 16).astype(np.float32)
+    b, lnw, lnb = (rs.standard_normal(n).astype(np.float32) for n in (N, 256, 256))
+    pack = pack_linear160_h2(w)
+    assert pack.dtype == np.float32 and pack.size == 5 * 160 * 256                       # 768 rows in 5 slices of 160, the tail zero: the fp32 stream's size
+    x = slabs.astype(np.float64).sum(0)
+    xn = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * lnw + lnb
+    ref = xn @ w.T.astype(np.float64) + b
+    for late in (False, True):
+        got = emulate_ln_linear_h2(slabs, lnw, lnb, pack, b, N, late)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-7, np.abs(got - ref).max() / np.abs(ref).max()
+    raw = slabs[:1] * (10.0 ** rs.uniform(-6, 7, (1, M, 1))).astype(np.float32)          # rows from 1e-6 to 1e7: no LayerNorm, row scale only
+    ref0 = raw[0].astype(np.float64) @ w.T.astype(np.float64) + b
+    got0 = emulate_ln_linear_h2(raw, None, None, pack, b, N, True)
+    assert (np.abs(got0 - ref0).max(axis=1) / np.abs(ref0).max(axis=1)).max() < 3e-7
+
+
 def test_scan_order_is_a_consistent_relabelling():
     """Host side of the exact block culling (interdiff_amd/geometry.py MeshTopology): vorder is a permutation, faces_scan / marker
     positions are the same mesh relabelled, and 16 consecutive scan positions of the rest pose are spatially compact."""

@@ -579,8 +579,8 @@ def main():
             one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                  note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic; secondary'),
             two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                note='the sampler steps a batch of > 800 token rows as two half-batch kernel chains on two branches of one '
-                                     'graph: the same layer = two concurrent launches at M=%d, timed as two such chains of back-to-back '
+                                note='NOT the route of this shape since the split-f16 kernel (one chain up to 1632 rows, MDM.one_chain_max_rows); kept for comparison: '
+                                     'the two-chain form runs the same layer as two concurrent launches at M=%d, timed as two such chains of back-to-back '
                                      'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
             small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best,
                                          frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,

@@ -32,7 +32,7 @@ def main():
     dev = torch.device('cuda:0')
     model, corr, bt, y, (sd, _, _) = bench.build_world(dev, 0)
     diff = create_gaussian_diffusion('cosine', bench.STEPS)
-    for N in (1600,):
+    for N in (800, 1600, 3200):
         row = {}
         for math in ('exact', 'split'):
             model.ffn_math = math
@@ -43,9 +43,9 @@ def main():
             row[math + '_err_vs_fp64'] = err_fp64(model, sd, N)
         print('ffn', N, json.dumps(row), flush=True)
     from interdiff_amd import _lib
-    for rep in range(3):
-        for math in ('split', 'split_slice_major', 'split_plain_ids'):
-            model.ffn_math = 'split'
+    for rep in range(2):
+        for math in ('exact', 'split', 'split_slice_major', 'split_plain_ids'):
+            model.ffn_math = 'exact' if math == 'exact' else 'split'
             model.w.tune[_lib.TUNE['misc']] = {'split_slice_major': 2, 'split_plain_ids': 3}.get(math, 0)
             if rep == 0:
                 print('burst', math, time_ffn(model, dev, 1600), time_ffn(model, dev, 800), flush=True)

@@ -136,6 +136,11 @@ typedef struct {
     int64_t sa_in_pack_h2;     /* std only: 0, or sa_in_w as two f16 planes in the split-f16 QKV kernel's stream order (5 slices x 8 K steps
                                   [10 tiles][2 planes][64 lanes][8 halves], rows past 768 zero; mdm.py pack_linear160_h2; csrc/ffn_h2.h
                                   ln_linear_h2_kernel).  The kernel scales every input row by a power of two, so only the weights' range matters */
+    int64_t qc_h2;             /* QaN only: 0, or Qc as two f16 planes in the split-f16 row block's fragment order [4 K quarters][2 K steps][3 taps][2 planes][4 kq][NQ][8 halves]
+                                  (mdm.py qan_fragments_h2; csrc/denoiser.hip rowblock_kernel<.., H2>) */
+    int64_t rb_h2_ok;          /* decoder layers: 1 when the packer has proved that the LayerNorm outputs this layer's row block contracts (LN_prev, norm1) stay inside
+                                  the f16 range (16 max|gamma| + max|beta| < 65504; mdm.py ln_h2_range_ok) -- with tune[IDF_TUNE_FFN_MATH] == 1 the row block then runs
+                                  its three contractions as split-f16 products; 0 = always exact fp32 */
 } idf_mdm_layer;
 
 typedef struct {
@@ -159,10 +164,11 @@ typedef struct {
      * the other two to rounding (7e-7 of the output scale), not bit for bit: a caller that steps ONE batch as several calls on row subsets (the
      * sampler's half-batch chains) sets 1 or 2 from the rows of the whole batch so that every call takes the same kernel
      * (interdiff_amd/mdm.py: MDM._pick_ffn_tile does this before every forward / forward_step / encode / ffn call).
-     * tune[IDF_TUNE_FFN_MATH] selects the arithmetic of the feed-forward block AND of the QKV projection (layers whose sa_in_pack_h2 is set): 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/ffn.h),
+     * tune[IDF_TUNE_FFN_MATH] selects the arithmetic of the feed-forward block, of the QKV projection (layers whose sa_in_pack_h2 is set) AND of the row block's three contractions (layers whose rb_h2_ok -- and, QaN, qc_h2 -- is set): 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, csrc/ffn.h),
      * 1 = split-f16 (every fp32 operand as two f16 planes, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate: fp32-grade
      * results at 1/43 of the matrix-pipe time, csrc/ffn_h2.h) for every layer whose ffn_pack_h2 is set, exact fp32 for the others.  Its
-     * 16-, 32- and 64-row tiles are bit-identical, so with 1 the row tile is a pure performance choice. */
+     * 16-, 32- and 64-row tiles are bit-identical, so with 1 the row tile is a pure performance choice.  2 = like 1 for the feed-forward block and the QKV
+     * projection, exact fp32 in the row block (A/B runs). */
     int32_t tune[8];
 } idf_mdm_weights;
 

@@ -27,7 +27,7 @@
 // row tile by tune[IDF_TUNE_FFN] (0: by this launch's rows)
 static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, const float *ar, const int32_t *tune, const float *x2, int M, float *parts) {
     int rows = idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]);
-    if (tune[IDF_TUNE_FFN_MATH] == 1 && ly.ffn_pack_h2 != 0) {
+    if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.ffn_pack_h2 != 0) {
         if (rows == 0) rows = idf_ffn::ffn_tile_for_rows(M);
         return idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows, tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : 0));      // (MISC = 2 / 3: slice-major affine ids / plain ids, A/B only: ffn_h2.h)
     }
@@ -113,6 +113,29 @@ __device__ __forceinline__ void ln_row16_lds(Row16 &r, const float *w, const flo
     }
 }
 
+// the two f16 planes of a token row (ffn_h2.h split4_pk: no flush rule, packed instructions) next to its fp32 image: lane l16 owns the 4-float chunks {l16, 16 + l16, 32 + l16, 48 + l16}
+__device__ __forceinline__ void row16_store_planes(const Row16 &r, _Float16 *hi_row, _Float16 *lo_row, int l16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2 h, l;
+        idf_ffn_h2::split4_pk(r.c[i], h, l);
+        *reinterpret_cast<uint2 *>(hi_row + (i * 16 + l16) * 4) = h;
+        *reinterpret_cast<uint2 *>(lo_row + (i * 16 + l16) * 4) = l;
+    }
+}
+// one K = 32 step of a split-f16 product on NA tiles: main += ah.bh, corr += ah.bl' + al'.bh   (result = main + corr 2^-11)
+template <int NA>
+__device__ __forceinline__ void mma_h2(f32x4 (&am)[NA], f32x4 (&ac)[NA], const idf_ffn_h2::h8 (&ah)[NA], const idf_ffn_h2::h8 (&al)[NA],
+                                       const float4 (&bh)[NA], const float4 (&bl)[NA]) {
+    using idf_ffn_h2::h8;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) IDF_H2_MFMA(am[i], ah[i], __builtin_bit_cast(h8, bh[i]));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) IDF_H2_MFMA(ac[i], ah[i], __builtin_bit_cast(h8, bl[i]));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) IDF_H2_MFMA(ac[i], al[i], __builtin_bit_cast(h8, bh[i]));
+}
+
 // ------------------------------------------------------------------------------------
 // Row block shared by QaN layers and standard layers, 16 tokens of one clip per workgroup:
 //   [QAN]  x = LN_prev(u_in rows t-1 .. t+16);  logits[t][n][j] = <Qc[n][j], x[t+j-1]>  (MFMA, K split over waves)
@@ -131,10 +154,21 @@ constexpr int TR = 16;
 //   G   (per sample, mem_fold_kernel):        [4][4][3 column tiles][64][4], column = 16 ct + li of the 40 (head, slot) pairs (+8 zero)
 //   VWT (per sample, mem_fold_kernel):        [4 waves = output column quarter][3 k-groups][4 tiles][64][4]
 constexpr int G_FRAG = 4 * 4 * 3 * 64 * 4;     // 12288 floats per (layer, clip)
+// split-f16 forms (rowblock_kernel<.., H2>): 16-byte plane fragments = the v_mfma_f32_16x16x32_f16 operand of a lane (8 halves, k = 8 kq .. 8 kq + 7 of a K = 32 step)
+//   Qc  (mdm.py qan_fragments_h2):            [4 waves = K quarter][2 K steps][3 taps][2 planes][4 kq][NQ][8 halves]
+//   G   (mem_fold_h2_kernel):                 [4 waves = K quarter][2 K steps][3 column tiles][2 planes][64 lanes][8 halves], values divided by 2^e
+//   VWT (mem_fold_h2_kernel):                 [4 waves = output column quarter][2 K steps (probability columns 0..63, zero from 40)][4 tiles][2 planes][64][8 halves]
+constexpr int G_H2 = 4 * 2 * 3 * 2 * 64 * 4;   // 12288 floats
+constexpr int VW_H2 = 4 * 2 * 4 * 2 * 64 * 4;  // 16384 floats
 constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
 constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
-template <bool QAN, bool CROSS = true, int NP = 1>
+// H2 (decoder layers, tune[IDF_TUNE_FFN_MATH] == 1 and the packer's range proof): the three contractions on the f16 matrix pipe with every fp32
+// operand as two f16 planes (ffn_h2.h: v = hi + lo' 2^-11, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate).  48 fp32 MFMAs of 32 cycles per
+// wave and contraction -- 1 536 of the ~2 000 cycles each of those three phases took -- become 18 / 18 / 24 of 16.  Qc / G / VWT then point at the
+// plane fragments (mdm.py qan_fragments_h2; mem_fold_h2_kernel) and h2_scale[b][2] holds the powers of two that G[b] / VW[b] were divided by.
+// Token rows need no scaling: they are LayerNorm outputs, bounded by 16 max|gamma| + max|beta| (the packer checks that against the f16 range).
+template <bool QAN, bool CROSS = true, int NP = 1, bool H2 = false>
 __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
                                                        const float *__restrict__ wk, const float *__restrict__ ln1_w,
@@ -145,8 +179,14 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        int out_frame_major /* encoder output: row = t*B + b */,
                                                        size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */,
                                                        const float *__restrict__ sa_resid /* !QAN, nullable: u1 = sum(u_in slabs) + sa_resid row + sa_bias */,
-                                                       const float *__restrict__ sa_bias) {
+                                                       const float *__restrict__ sa_bias, const float *__restrict__ h2_scale = nullptr) {
+    static_assert(!H2 || CROSS, "the split-f16 form exists for the decoder's row blocks");
+    using idf_ffn_h2::h8;
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
+    constexpr int HS = D + 8, PHS = 64 + 8;       // row strides (halves) of the token-row planes / probability planes: 16-byte pieces of 16 rows hit 64 different banks
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[H2 ? 2 * (TR + 2) * HS : 8];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores
+    __shared__ __attribute__((aligned(16))) _Float16 ppl[H2 ? 2 * TR * PHS : 8];            // [hi | lo'][TR][PHS]: probabilities, columns >= HM stay zero
+    _Float16 *const xh = xpl, *const xl = xpl + (H2 ? (TR + 2) * HS : 0), *const ph = ppl, *const pl = ppl + (H2 ? TR * PHS : 0);
     __shared__ __attribute__((aligned(1024))) float prm[8 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias + self-attention output bias (DMA targets)
     __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + TR * PS];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
@@ -154,16 +194,24 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
     float *Ps = part + 4 * 3 * 256;               // [TR][PS]
 
-    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, sa_resid, sa_bias, gridDim.x, gridDim.y);
+    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, sa_resid, sa_bias, h2_scale, gridDim.x, gridDim.y);
     const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
     const int rown = wave * 4 + kq;
-    const float *Gb = CROSS ? G + (size_t)b * G_FRAG : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
-    const float *VWTb = CROSS ? VWT + (size_t)b * D * HMP : nullptr;
+    const float *Gb = CROSS ? G + (size_t)b * (H2 ? G_H2 : G_FRAG) : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
+    const float *VWTb = CROSS ? VWT + (size_t)b * (H2 ? VW_H2 : D * HMP) : nullptr;
     IDF_RB_STAMP(0);
+    if constexpr (H2) {
+        // EXCLUSIVE CU, like the other kernels that issue the f16 MFMA (ffn_h2.h "exclusive CU": next to such a kernel, workgroups of OTHER kernels on the same CU
+        // have been seen to compute wrong values -- again with this kernel before it took its CU: the staggered-chains bit-identity test at B = 32).  The whole
+        // register file (one wave per SIMD x 512 registers) and, by the dynamic LDS the launcher adds, all 160 KiB of LDS: nothing else can be resident here.
+        asm volatile("" ::: "v255", "a255");
+        // probability planes: the columns past HM are never written again
+        for (int i = threadIdx.x; i < 2 * TR * PHS / 8; i += 256) reinterpret_cast<float4 *>(ppl)[i] = zero4();
+    }
 
     // ---- Operand fetch, organised for memory-level parallelism: everything is requested with clamped (always valid) addresses and
     // no lane-divergent guard around a load, in three batches that each have whole phases of work to hide behind --
@@ -184,8 +232,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             if ((i & 3) == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
     }
     Row16 ra, rb;
-    float4 q[4][3], gv[4][3], vw[HMP / 16][4];
-    float wk_n = 0.f, g0v[3];                     // g0 of (head = wave, memory slots q, q+4, q+8 with q = lane & 3)
+    float4 q[4][3], gv[4][3], vw[HMP / 16][4];      // fp32 fragments; H2: the same registers hold 16-byte plane fragments -- q[2 s + pl][j], gv[2 s + pl][ct], vw2[s][c][pl]
+    float4 vw2[2][4][2];
+    float wk_n = 0.f, g0v[3], gsc = 1.f, vsc = 1.f;                     // g0 of (head = wave, memory slots q, q+4, q+8 with q = lane & 3)
     const int ta = QAN ? t0 - 1 + rown : t0 + rown, tb = t0 + 15 + kq;
     const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && kq < 2 && tb < T;
     Row16Raw<NP> raw_a, raw_b;
@@ -195,6 +244,10 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     if constexpr (CROSS) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
+    }
+    if constexpr (H2) {
+        gsc = h2_scale[2 * b];
+        vsc = h2_scale[2 * b + 1];
     }
     if constexpr (QAN) {
         if (wave == 0 && kq < 2) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, li, u_pstride);     // halo rows t0+15, t0+16: two lane groups of wave 0 (exec-masked loads)
@@ -212,22 +265,33 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             for (int j = 0; j < 3; ++j) q[ss][j] = zero4();
         if (li < NQ) {                                   // compact fragment order: only the NQ valid query columns are stored and fetched
 #pragma unroll
-            for (int ss = 0; ss < 4; ++ss)
+            for (int ss = 0; ss < 4; ++ss)               // (H2: ss = 2 s + plane of [wave][K step s][tap][plane][kq][NQ][8 halves] -- the same twelve 16-byte loads)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) q[ss][j] = ld4(Qc + (((wave * 4 + ss) * 3 + j) * (4 * NQ) + kq * NQ + li) * 4);
+                for (int j = 0; j < 3; ++j)
+                    q[ss][j] = H2 ? ld4(Qc + (((((wave * 2 + (ss >> 1)) * 3 + j) * 2 + (ss & 1)) * 4 + kq) * NQ + li) * 4)
+                                  : ld4(Qc + (((wave * 4 + ss) * 3 + j) * (4 * NQ) + kq * NQ + li) * 4);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     auto fetch_g = [&]() {
         if constexpr (CROSS) {
 #pragma unroll
-            for (int ss = 0; ss < 4; ++ss)
+            for (int ss = 0; ss < 4; ++ss)               // (H2: ss = 2 s + plane of [wave][K step s][column tile][plane][lane][8 halves])
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) gv[ss][ct] = ld4(Gb + (((wave * 4 + ss) * 3 + ct) * 64 + lane) * 4);
+                for (int ct = 0; ct < 3; ++ct)
+                    gv[ss][ct] = H2 ? ld4(Gb + (((((wave * 2 + (ss >> 1)) * 3 + ct) * 2 + (ss & 1)) * 64) + lane) * 4)
+                                    : ld4(Gb + (((wave * 4 + ss) * 3 + ct) * 64 + lane) * 4);
         }
     };
     auto fetch_vw = [&]() {
-        if constexpr (CROSS) {
+        if constexpr (H2) {                              // [wave = output column quarter][K step s][column tile c][plane][lane][8 halves]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int pl2 = 0; pl2 < 2; ++pl2) vw2[s2][c][pl2] = ld4(VWTb + (((((wave * 2 + s2) * 4 + c) * 2 + pl2) * 64) + lane) * 4);
+        } else if constexpr (CROSS) {
 #pragma unroll
             for (int sidx = 0; sidx < HMP / 16; ++sidx)
 #pragma unroll
@@ -258,18 +322,41 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         if (!vb) row16_zero(rb);
         row16_store(ra, xs + rown * RS, li);
         if (wave == 0 && kq < 2) row16_store(rb, xs + (16 + kq) * RS, li);
+        if constexpr (H2) {
+            row16_store_planes(ra, xh + rown * HS, xl + rown * HS, li);
+            if (wave == 0 && kq < 2) row16_store_planes(rb, xh + (16 + kq) * HS, xl + (16 + kq) * HS, li);
+        }
         fetch_g();
         __syncthreads();
         IDF_RB_STAMP(1);                                 // rows loaded (+ slab sum), LN_prev
         // logits: three 16x16 tiles (j = 0,1,2), each wave contracts a 64-wide slice of K
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (H2) {
+            f32x4 acc_c[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-            const int koff = 16 * (wave * 4 + ss) + 4 * kq;
-            float4 a[3];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int koff = 64 * wave + 32 * s2 + 8 * kq;
+                h8 ah[3], al[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) a[j] = ld4(xs + (li + j) * RS + koff);
-            mma_rounds<3>(acc, a, q[ss]);
+                for (int j = 0; j < 3; ++j) {
+                    ah[j] = *reinterpret_cast<const h8 *>(xh + (li + j) * HS + koff);
+                    al[j] = *reinterpret_cast<const h8 *>(xl + (li + j) * HS + koff);
+                }
+                mma_h2<3>(acc, acc_c, ah, al, q[2 * s2], q[2 * s2 + 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] += acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
+        } else {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const int koff = 16 * (wave * 4 + ss) + 4 * kq;
+                float4 a[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[j] = ld4(xs + (li + j) * RS + koff);
+                mma_rounds<3>(acc, a, q[ss]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -313,6 +400,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
             }
             ln_row16_lds(xc, P_ln1_w, P_ln1_b, li);
+            if constexpr (H2) row16_store_planes(xc, xh + rown * HS, xl + rown * HS, li);      // (the logits' reads of these planes ended at the barrier above)
             if constexpr (CROSS) row16_store(xc, x1s + rown * RS, li);
             else if (t0 + rown < T) row16_store(xc, x2_out + (out_frame_major ? (size_t)(t0 + rown) * gridDim.y + b : rowbase + t0 + rown) * D, li);
         }
@@ -334,6 +422,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         fetch_g();
         fetch_vw();
         ln_row16_lds(ra, P_ln1_w, P_ln1_b, li);
+        if constexpr (H2) row16_store_planes(ra, xh + rown * HS, xl + rown * HS, li);
         if constexpr (CROSS) row16_store(ra, x1s + rown * RS, li);
         else if (t < T) row16_store(ra, x2_out + (out_frame_major ? (size_t)t * gridDim.y + b : rowbase + t) * D, li);
     }
@@ -342,11 +431,26 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     IDF_RB_STAMP(4);                                     // stencil + LN1
     {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (H2) {
+            f32x4 acc_c[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-            const float4 av = ld4(x1s + li * RS + 16 * (wave * 4 + ss) + 4 * kq);
-            float4 a[3] = {av, av, av};
-            mma_rounds<3>(acc, a, gv[ss]);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int koff = 64 * wave + 32 * s2 + 8 * kq;
+                const h8 a_h = *reinterpret_cast<const h8 *>(xh + li * HS + koff), a_l = *reinterpret_cast<const h8 *>(xl + li * HS + koff);
+                const h8 ah[3] = {a_h, a_h, a_h}, al[3] = {a_l, a_l, a_l};
+                mma_h2<3>(acc, acc_c, ah, al, gv[2 * s2], gv[2 * s2 + 1]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ct][r] = (acc[ct][r] + acc_c[ct][r] * idf_ffn_h2::LO_UNSCALE) * gsc;      // G[b] was divided by gsc (a power of two)
+        } else {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const float4 av = ld4(x1s + li * RS + 16 * (wave * 4 + ss) + 4 * kq);
+                float4 a[3] = {av, av, av};
+                mma_rounds<3>(acc, a, gv[ss]);
+            }
         }
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
@@ -383,8 +487,17 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (qd + 4 * i < MEM) Ps[tq * PS + wave * MEM + qd + 4 * i] = sc[i] * inv;
-        if (wave == 0 && qd < (HMP - HM + 3) / 4) {
+            if (qd + 4 * i < MEM) {
+                if constexpr (H2) {
+                    _Float16 hv, lv;
+                    idf_ffn_h2::split1_nf(sc[i] * inv, hv, lv);
+                    ph[tq * PHS + wave * MEM + qd + 4 * i] = hv;
+                    pl[tq * PHS + wave * MEM + qd + 4 * i] = lv;
+                } else {
+                    Ps[tq * PS + wave * MEM + qd + 4 * i] = sc[i] * inv;
+                }
+            }
+        if (!H2 && wave == 0 && qd < (HMP - HM + 3) / 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (HM + qd * 4 + i < HMP) Ps[tq * PS + HM + qd * 4 + i] = 0.f;
@@ -394,11 +507,26 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     IDF_RB_STAMP(6);                                     // head softmax
     {   // u2 = x1 + P.VW + b_out : wave w owns output columns [64w, 64w+64)
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (H2) {
+            f32x4 acc_c[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < HMP / 16; ++s) {
-            const float4 pv = ld4(Ps + li * PS + 16 * s + 4 * kq);
-            float4 a[4] = {pv, pv, pv, pv};
-            mma_rounds<4>(acc, a, vw[s]);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const h8 p_h = *reinterpret_cast<const h8 *>(ph + li * PHS + 32 * s2 + 8 * kq), p_l = *reinterpret_cast<const h8 *>(pl + li * PHS + 32 * s2 + 8 * kq);
+                const h8 ah[4] = {p_h, p_h, p_h, p_h}, al[4] = {p_l, p_l, p_l, p_l};
+                const float4 bh[4] = {vw2[s2][0][0], vw2[s2][1][0], vw2[s2][2][0], vw2[s2][3][0]}, bl[4] = {vw2[s2][0][1], vw2[s2][1][1], vw2[s2][2][1], vw2[s2][3][1]};
+                mma_h2<4>(acc, acc_c, ah, al, bh, bl);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[c][r] = (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc;       // VW[b] was divided by vsc
+        } else {
+#pragma unroll
+            for (int s = 0; s < HMP / 16; ++s) {
+                const float4 pv = ld4(Ps + li * PS + 16 * s + 4 * kq);
+                float4 a[4] = {pv, pv, pv, pv};
+                mma_rounds<4>(acc, a, vw[s]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -650,6 +778,16 @@ __global__ __launch_bounds__(256) void mem_kv_kernel(const float *__restrict__ a
     kv[((size_t)l * R + r) * 512 + c] = s + arena[w.layer[l].ca_kv_b + c];
 }
 
+// fragment order of the fp32 forms (see G_FRAG): the reader's lane is kq * 16 + li
+__device__ __forceinline__ int g_slot(int col, int k) {            // score column col (0..47), feature k (0..255)
+    const int ks = k >> 4, kq = (k >> 2) & 3, e = k & 3, ct = col >> 4, li = col & 15;
+    return ((ks * 3 + ct) * 64 + kq * 16 + li) * 4 + e;
+}
+__device__ __forceinline__ int vw_slot(int o, int col) {           // output feature o (0..255), probability column col (0..47)
+    const int wave = o >> 6, c = (o >> 4) & 3, li = o & 15, sidx = col >> 4, kq = (col >> 2) & 3, e = col & 3;
+    return (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + kq * 16 + li) * 4 + e;
+}
+
 // G[l][b][h*MEM+m][i] = 1/8 sum_d Wq[h*64+d][i] K[m,b][h*64+d];  g0 = 1/8 sum_d bq[h*64+d] K[..]
 // VWT[l][b][o][h*MEM+m] = sum_d V[m,b][h*64+d] Wo[o][h*64+d]   (columns 40..47 zero)
 // grid (HM, B, L), 256 threads (thread = i / o)
@@ -668,15 +806,6 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
         sg += Wq[(size_t)(h * HD + d) * D + i] * kd[d];
         sv += vd[d] * Wo[(size_t)i * D + h * HD + d];
     }
-    // fragment order (see G_FRAG): the reader's lane is kq * 16 + li
-    auto g_slot = [](int col, int k) {             // score column col (0..47), feature k (0..255)
-        const int ks = k >> 4, kq = (k >> 2) & 3, e = k & 3, ct = col >> 4, li = col & 15;
-        return ((ks * 3 + ct) * 64 + kq * 16 + li) * 4 + e;
-    };
-    auto vw_slot = [](int o, int col) {            // output feature o (0..255), probability column col (0..47)
-        const int wave = o >> 6, c = (o >> 4) & 3, li = o & 15, sidx = col >> 4, kq = (col >> 2) & 3, e = col & 3;
-        return (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + kq * 16 + li) * 4 + e;
-    };
     float *Gf = G + ((size_t)l * B + b) * G_FRAG, *Vf = VWT + ((size_t)l * B + b) * D * HMP;
     Gf[g_slot(hm, i)] = sg * 0.125f;
     Vf[vw_slot(i, hm)] = sv;
@@ -688,6 +817,65 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
         float s = 0.f;
         for (int d = 0; d < HD; ++d) s += bq[h * HD + d] * kd[d];
         g0[((size_t)l * B + b) * HM + hm] = s * 0.125f;
+    }
+}
+
+// The folded memory as split-f16 plane fragments (rowblock_kernel<.., H2>; layouts at G_H2).  Its values are data (encoder output folded with
+// weights), so each (layer, clip) matrix is divided by a power of two that puts its largest magnitude in [2^13, 2^14) -- exact, the f16 pair then keeps
+// 22 bits of every element down to 2^-27 of the largest -- and the row block multiplies the fp32 result back (sc[l][b] = {2^eG, 2^eV}).
+// grid (B, L), 256 threads; once per sample.
+__global__ __launch_bounds__(256) void mem_fold_h2_kernel(const float *__restrict__ G, const float *__restrict__ VWT, int B,
+                                                          float *__restrict__ Gh2, float *__restrict__ VWh2, float *__restrict__ sc) {
+    const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+    const float *Gf = G + ((size_t)l * B + b) * G_FRAG, *Vf = VWT + ((size_t)l * B + b) * D * HMP;
+    __shared__ float red[2][256];
+    float ag = 0.f, av = 0.f;
+    for (int i = tid; i < G_FRAG; i += 256) ag = fmaxf(ag, fabsf(Gf[i]));
+    for (int i = tid; i < D * HMP; i += 256) av = fmaxf(av, fabsf(Vf[i]));
+    red[0][tid] = ag;
+    red[1][tid] = av;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            red[0][tid] = fmaxf(red[0][tid], red[0][tid + st]);
+            red[1][tid] = fmaxf(red[1][tid], red[1][tid + st]);
+        }
+        __syncthreads();
+    }
+    // amax 2^-e in [2^13, 2^14); a matrix of zeros (or non-finite values, which then stay what they are) is left alone
+    const int eg = (red[0][0] > 0.f && red[0][0] < INFINITY) ? ilogbf(red[0][0]) - 13 : 0, ev = (red[1][0] > 0.f && red[1][0] < INFINITY) ? ilogbf(red[1][0]) - 13 : 0;
+    const float dg = ldexpf(1.0f, -eg), dv = ldexpf(1.0f, -ev);
+    float *Go = Gh2 + ((size_t)l * B + b) * G_H2, *Vo = VWh2 + ((size_t)l * B + b) * VW_H2;
+    for (int it = tid; it < 4 * 2 * 3 * 64; it += 256) {
+        const int lane = it & 63, ct = (it >> 6) % 3, s2 = (it / 192) & 1, wv = it / 384, kq = lane >> 4, li = lane & 15;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Gf[g_slot(16 * ct + li, 64 * wv + 32 * s2 + 8 * kq + e)] * dg;
+        uint2 h0, l0, h1, l1;
+        idf_ffn_h2::split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+        idf_ffn_h2::split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+        uint4 *dst = reinterpret_cast<uint4 *>(Go) + (((wv * 2 + s2) * 3 + ct) * 2) * 64 + lane;
+        dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    for (int it = tid; it < 4 * 2 * 4 * 64; it += 256) {
+        const int lane = it & 63, c = (it >> 6) & 3, s2 = (it >> 8) & 1, wv = it >> 9, kq = lane >> 4, li = lane & 15;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = 32 * s2 + 8 * kq + e;
+            v[e] = col < HMP ? Vf[vw_slot(64 * wv + 16 * c + li, min(col, HMP - 1))] * dv : 0.f;
+        }
+        uint2 h0, l0, h1, l1;
+        idf_ffn_h2::split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+        idf_ffn_h2::split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+        uint4 *dst = reinterpret_cast<uint4 *>(Vo) + (((wv * 2 + s2) * 4 + c) * 2) * 64 + lane;
+        dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    if (tid == 0) {
+        sc[((size_t)l * B + b) * 2] = ldexpf(1.0f, eg);
+        sc[((size_t)l * B + b) * 2 + 1] = ldexpf(1.0f, ev);
     }
 }
 
@@ -813,8 +1001,22 @@ extern "C" int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, c
     return IDF_OK;
 }
 
+// memctx: G | VWT | g0 (fp32 forms) | G planes | VWT planes | scales (split-f16 forms, always folded: the arithmetic is chosen per forward)
+struct MemCtx {
+    const float *G, *VWT, *g0, *Gh2, *VWh2, *sc;
+};
+static inline MemCtx memctx_carve(const float *m, int B) {
+    MemCtx c;
+    c.G = m;
+    c.VWT = c.G + (size_t)L * B * G_FRAG;
+    c.g0 = c.VWT + (size_t)L * B * D * HMP;
+    c.Gh2 = c.g0 + (size_t)L * B * HM;
+    c.VWh2 = c.Gh2 + (size_t)L * B * G_H2;
+    c.sc = c.VWh2 + (size_t)L * B * VW_H2;
+    return c;
+}
 extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) {
-    return (size_t)L * B * G_FRAG + (size_t)L * B * D * HMP + (size_t)L * B * HM;
+    return (size_t)L * B * (G_FRAG + D * HMP + HM + G_H2 + VW_H2 + 2);
 }
 
 extern "C" size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T) {
@@ -830,10 +1032,12 @@ extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const floa
     if (ws_bytes < (size_t)L * MEM * B * 512 * sizeof(float)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     float *kv = reinterpret_cast<float *>(ws);
-    float *G = memctx, *VWT = memctx + (size_t)L * B * G_FRAG, *g0 = VWT + (size_t)L * B * D * HMP;
+    const MemCtx mc = memctx_carve(memctx, B);
+    float *G = const_cast<float *>(mc.G), *VWT = const_cast<float *>(mc.VWT), *g0 = const_cast<float *>(mc.g0);
     idf_prof_mark(IDF_K_MEM_PREP, s);
     hipLaunchKernelGGL(mem_kv_kernel, dim3(2, MEM * B, L), dim3(256), 0, s, w->arena, *w, cond, MEM * B, kv);
     hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VWT);
+    hipLaunchKernelGGL(mem_fold_h2_kernel, dim3(B, L), dim3(256), 0, s, G, VWT, B, const_cast<float *>(mc.Gh2), const_cast<float *>(mc.VWh2), const_cast<float *>(mc.sc));
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
@@ -892,7 +1096,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             if (const int rc = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0,
-                                       (w->tune[IDF_TUNE_FFN_MATH] == 1 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr); rc != IDF_OK) return rc;
+                                       (w->tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr); rc != IDF_OK) return rc;
             hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s,
                                k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
             hipLaunchKernelGGL((rowblock_kernel<false, false, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
@@ -913,6 +1117,20 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
 }
 
 namespace {
+// dynamic LDS that tops a split-f16 row block's static LDS up to the CU's whole 160 KiB (exclusive CU, see the kernel); per (kernel, device) opt-in
+template <typename KernelT>
+int rb_h2_fill_lds(KernelT kernel, std::atomic<uint64_t> &done, std::atomic<int> &dyn_bytes) {
+    int dyn = dyn_bytes.load(std::memory_order_acquire);
+    if (dyn < 0) {
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kernel)) != hipSuccess) return -1;
+        dyn = 160 * 1024 - (int)at.sharedSizeBytes;
+        if (dyn < 0) return -1;
+        dyn_bytes.store(dyn, std::memory_order_release);
+    }
+    return idf_opt_in_lds(reinterpret_cast<const void *>(kernel), dyn, done) == IDF_OK ? dyn : -1;
+}
+
 // the sampler-step operands of interdiff_mdm_forward_step (null x: plain forward, x0 written out)
 struct StepPost {
     float *x;
@@ -931,7 +1149,8 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const float *ar = w->arena;
     const int N = B * T, C = w->C;
     Ws k = carve(ws, N);
-    const float *G = memctx, *VWT = memctx + (size_t)L * B * G_FRAG, *g0 = VWT + (size_t)L * B * D * HMP;
+    const MemCtx mc = memctx_carve(memctx, B);
+    const float *G = mc.G, *VWT = mc.VWT, *g0 = mc.g0;
     const int32_t *tune = w->tune;
 
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
@@ -963,9 +1182,20 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];
         const float *Gl = G + (size_t)l * B * G_FRAG, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
+        // split-f16 row block: tune[IDF_TUNE_FFN_MATH] == 1 (2 = split-f16 feed-forward and QKV only), for layers whose LayerNorm outputs the packer proved to stay in the f16 range
+        const bool rb_h2 = tune[IDF_TUNE_FFN_MATH] == 1 && ly.rb_h2_ok != 0 && (!ly.is_qan || (ly.qc_h2 != 0 && u_np == NSL));
+        const float *Gh = mc.Gh2 + (size_t)l * B * G_H2, *VWh = mc.VWh2 + (size_t)l * B * VW_H2, *scl = mc.sc + (size_t)l * B * 2;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
-            if (u_np == NSL)
+            if (rb_h2) {
+                static std::atomic<uint64_t> done{0};
+                static std::atomic<int> dynb{-1};
+                const int dyn = rb_h2_fill_lds(rowblock_kernel<true, true, NSL, true>, done, dynb);
+                if (dyn < 0) return IDF_E_LAUNCH;
+                rowblock_kernel<true, true, NSL, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, scl);
+            } else if (u_np == NSL)
                 hipLaunchKernelGGL((rowblock_kernel<true, true, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr);
@@ -979,7 +1209,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
-            const float *qkv_h2 = (tune[IDF_TUNE_FFN_MATH] == 1 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr;
+            const float *qkv_h2 = (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr;
             int rcq;
             if (post.x && l == 0) rcq = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B, qkv_h2);
             else rcq = run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0, qkv_h2);
@@ -991,6 +1221,15 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
                 hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256),
                                    attn_lds_bytes(T, ATTN_RT), s, k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
+                if (rb_h2) {
+                    static std::atomic<uint64_t> done{0};
+                    static std::atomic<int> dynb{-1};
+                    const int dyn = rb_h2_fill_lds(rowblock_kernel<false, true, H, true>, done, dynb);
+                    if (dyn < 0) return IDF_E_LAUNCH;
+                    rowblock_kernel<false, true, H, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, scl);
+                } else
                 hipLaunchKernelGGL((rowblock_kernel<false, true, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b);

@@ -92,9 +92,28 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     lo = __builtin_bit_cast(uint2, (h4{b0, b1, b2, b3}));
 }
 
+// The same split WITHOUT the hi plane's flush rule, on packed instructions (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32: 3 VALU instructions per
+// element instead of 8).  gfx950's f16 MFMA honours subnormal inputs (tools/mfma_f16_subnormal_probe.hip: 2^-24 x 2^10 comes out exact), so a subnormal
+// hi is as good as a flushed one.  Every IN-KERNEL split of activations uses this form (x2 rows and hidden activations of the feed-forward kernel, the
+// QKV kernel's scaled rows, the row block's A operands in csrc/denoiser.hip); the pre-packed WEIGHT planes keep the rule (mdm.py split_f16 -- either is exact
+// to 2^-22, the two only differ below 2^-14).  tests/ffn_emulator.py restates both.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4_pk(const float4 v, uint2 &hi, uint2 &lo) {
+    const f2 a = {v.x, v.y}, b = {v.z, v.w};
+    const h2v ha = __builtin_convertvector(a, h2v), hb = __builtin_convertvector(b, h2v);
+    const f2 ra = (a - __builtin_convertvector(ha, f2)) * LO_SCALE, rb = (b - __builtin_convertvector(hb, f2)) * LO_SCALE;
+    const h2v la = __builtin_convertvector(ra, h2v), lb = __builtin_convertvector(rb, h2v);
+    hi = uint2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    lo = uint2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+__device__ __forceinline__ void split1_nf(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+
 // gelu_fast (common.h) on a PAIR of values: packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) cost a wave what the
 // plain ones cost, so the polynomial runs at half the issue slots; rcp / exp stay per element.  Same operations in the same order as gelu_fast.
-typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 gelu_fast2(f2 x) {
     const f2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
     const f2 z = ax * 0.70710678118654752440f;
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         const int r = wave + NW * j;
         const float4 v = *reinterpret_cast<const float4 *>(Xs + r * 256 + lane * 4);
         uint2 hi, lo;
-        split4(v, hi, lo);
+        split4_pk(v, hi, lo);
         float *dst = Xs + r * 256 + ((((lane >> 1) ^ (r & 15)) << 2)) + ((lane & 1) << 1);
         *reinterpret_cast<uint2 *>(dst) = hi;
         *reinterpret_cast<uint2 *>(dst + 128) = lo;
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
                 const f2 g01 = gelu_fast2(m01 + c01 * LO_UNSCALE + b01), g23 = gelu_fast2(m23 + c23 * LO_UNSCALE + b23);
                 const float4 v = make_float4(g01.x, g01.y, g23.x, g23.y);
                 uint2 hi, lo;
-                split4(v, hi, lo);
+                split4_pk(v, hi, lo);
                 float *dst = Xs + (16 * t + n) * 256 + ((chunk ^ n) << 2) + ((g & 1) << 1);
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 128) = lo;
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
             const float dn = __builtin_bit_cast(float, (uint32_t)((127 - e) << 23)), up = __builtin_bit_cast(float, (uint32_t)((127 + e) << 23));
             x.x *= dn; x.y *= dn; x.z *= dn; x.w *= dn;
             uint2 hi, lo;
-            split4(x, hi, lo);
+            split4_pk(x, hi, lo);
             float *dst = Xs + row * 256 + ((((lane >> 1) ^ (row & 15)) << 2)) + ((lane & 1) << 1);
             *reinterpret_cast<uint2 *>(dst) = hi;
             *reinterpret_cast<uint2 *>(dst + 128) = lo;

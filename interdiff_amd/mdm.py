@@ -25,6 +25,7 @@ D, FF, HEADS, NQ, MEM, LAYERS = 256, 1024, 4, 10, 10, 8
 QAN_LAYERS = (1, 2, 3, 4, 5, 6)
 ROTARY_DEFAULT = True
 FFN_MATH_DEFAULT = 'split'
+ROWBLOCK_MATH_DEFAULT = 'split'
 
 
 def positional_table(max_len=5000, d=D):
@@ -68,6 +69,33 @@ def qan_fragments(qc):
         for kq in range(4):
             out[kg, :, kq] = qc[:, :, 16 * kg + 4 * kq:16 * kg + 4 * kq + 4].transpose(1, 0, 2)
     return out
+
+
+def qan_fragments_h2(qc):
+    """Qc [NQ, 3, D] -> the split-f16 row block's B-operand fragments (csrc/denoiser.hip G_H2 note): [4 waves = K quarter][2 K steps][3 taps]
+    [2 planes][4 kq][NQ][8 halves], lane (kq, li < NQ) holds plane(Qc[li, tap, 64 w + 32 s + 8 kq : +8]) -- the v_mfma_f32_16x16x32_f16 operand
+    of that lane.  Returned as float32 words (two halves each), the same 7680 words as ``qan_fragments``."""
+    qc = np.asarray(qc, np.float32)
+    nq, _, d = qc.shape
+    hi, lo = split_f16(qc)
+    out = np.empty((d // 64, 2, 3, 2, 4, nq, 8), np.float16)
+    for w in range(d // 64):
+        for s in range(2):
+            for kq in range(4):
+                k0 = 64 * w + 32 * s + 8 * kq
+                out[w, s, :, 0, kq] = hi[:, :, k0:k0 + 8].transpose(1, 0, 2)
+                out[w, s, :, 1, kq] = lo[:, :, k0:k0 + 8].transpose(1, 0, 2)
+    return np.ascontiguousarray(out).view(np.float32).reshape(-1)
+
+
+def ln_h2_range_ok(*gamma_beta_pairs):
+    """A LayerNorm output is bounded by sqrt(D - 1) max|gamma| + max|beta| (|normalised element| <= sqrt(D - 1) < 16): True when every
+    given (gamma, beta) keeps its rows below the f16 limit with the margin of H2_LIMIT -- what the split-f16 row block asks of its A operands."""
+    for gam, bet in gamma_beta_pairs:
+        gam, bet = np.asarray(gam, np.float64), np.asarray(bet, np.float64)
+        if not (np.isfinite(gam).all() and np.isfinite(bet).all() and 16.0 * np.abs(gam).max() + np.abs(bet).max() < H2_LIMIT):
+            return False
+    return True
 
 
 def _np(t):
@@ -118,13 +146,15 @@ H2_SLICE_FLOATS = (H2_KS1 * (FFN_SLICE_H // 16) * 2 * 1024 + H2_KS2 * (D // 16) 
 H2_LIMIT = 60000.0          # |value| every operand of the split-f16 kernel must provably stay below (f16 max 65504)
 
 
-def split_f16(a):
+def split_f16(a, flush=True):
     """fp32 array -> (hi, lo') float16 planes with a = hi + lo' / 2048 up to 2^-23 |a| (csrc/ffn_h2.h split1, same roundings):
-    hi = f16(a), 0 where |a| < 2^-14 (no subnormal in the hi plane); lo' = f16((a - hi) * 2^11) (the residual is exact in fp32)."""
+    hi = f16(a), 0 where |a| < 2^-14 (no subnormal in the hi plane: how the WEIGHT planes are packed); lo' = f16((a - hi) * 2^11) (the residual
+    is exact in fp32).  ``flush=False``: the kernels' in-flight split of activations (split4_pk: hi may be subnormal, which gfx950's f16 MFMA honours)."""
     a = np.asarray(a, np.float32)
     with np.errstate(over='ignore'):
         hi = a.astype(np.float16)
-    hi[np.abs(a) < np.float32(2.0 ** -14)] = 0
+    if flush:
+        hi[np.abs(a) < np.float32(2.0 ** -14)] = 0
     lo = ((a - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
     return hi, lo
 
@@ -266,9 +296,15 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
         p, ly = 'decoder.layers.%d.' % l, w.layer[l]
         ly.is_qan = 1 if (p + 'queries') in sd else 0
         if ly.is_qan:
-            ly.qc = ar.add(qan_fragments(qan_constants(g(p + 'queries'), rotary)))
+            qcn = qan_constants(g(p + 'queries'), rotary)
+            ly.qc = ar.add(qan_fragments(qcn))
+            ly.qc_h2 = ar.add(qan_fragments_h2(qcn)) if np.abs(qcn).max() < H2_LIMIT else 0
             ly.wk = ar.add(g(p + 'wk').reshape(-1))
+            # split-f16 row block: its A operands are LN_prev (the previous layer's norm3; none in front of layer 0) and this layer's norm1 outputs
+            pp = 'decoder.layers.%d.' % (l - 1)
+            ly.rb_h2_ok = 1 if (l > 0 and ln_h2_range_ok((g(pp + 'norm3.weight'), g(pp + 'norm3.bias')), (g(p + 'norm1.weight'), g(p + 'norm1.bias')))) else 0
         else:
+            ly.rb_h2_ok = 1 if ln_h2_range_ok((g(p + 'norm1.weight'), g(p + 'norm1.bias'))) else 0
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
             ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
             ly.sa_in_pack_h2 = ar.add(pack_linear160_h2(g(p + 'self_attn.in_proj_weight'))) if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT else 0
@@ -362,6 +398,11 @@ class MDM:
         self.ffn_math = os.environ.get('INTERDIFF_FFN_MATH', FFN_MATH_DEFAULT)
         if self.ffn_math not in ('split', 'exact'):
             raise ValueError("ffn_math must be 'split' or 'exact'")
+        # with ffn_math = 'split': the row block's three contractions as split-f16 products too ('split', layers whose LayerNorm range proof holds) or on
+        # the fp32 MFMA ('exact'; INTERDIFF_ROWBLOCK_MATH).  Ignored under ffn_math = 'exact'.
+        self.rowblock_math = os.environ.get('INTERDIFF_ROWBLOCK_MATH', ROWBLOCK_MATH_DEFAULT)
+        if self.rowblock_math not in ('split', 'exact'):
+            raise ValueError("rowblock_math must be 'split' or 'exact'")
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -506,7 +547,7 @@ class MDM:
 
     def ffn_graph_key(self, rows):
         """What a captured launch sequence bakes in about the feed-forward block (the sampler's graph cache key, diffusion.py)."""
-        return (self.ffn_class_for_rows(rows), self.ffn_math, self.ffn_rows)
+        return (self.ffn_class_for_rows(rows), self.ffn_math, self.ffn_rows, getattr(self, 'rowblock_math', 'exact'))
 
     def _pick_ffn_tile(self, rows, own_rows=None):
         """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to
@@ -522,7 +563,7 @@ class MDM:
             if tile != 32 and own_rows is not None and own_rows != rows:
                 tile = 16 if own_rows <= self.FFN16_MAX_ROWS else 64
         self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(tile, 1)
-        self.w.tune[_lib.TUNE['ffn_math']] = 1 if getattr(self, 'ffn_math', 'exact') == 'split' else 0
+        self.w.tune[_lib.TUNE['ffn_math']] = (1 if getattr(self, 'rowblock_math', 'exact') == 'split' else 2) if getattr(self, 'ffn_math', 'exact') == 'split' else 0
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).

@@ -370,7 +370,7 @@ def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
     for P in range(S - 1):
         issue_step(P)
     for r in range(bm):
-        hi, lo = split_f16(rows[r])
+        hi, lo = split_f16(rows[r], flush=False)
         for l in range(64):
             write_plane_piece(r, l >> 1, l & 1, hi[4 * l:4 * l + 4], lo[4 * l:4 * l + 4])
 
@@ -420,7 +420,7 @@ def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
                 hid = _gelu(pre).astype(np.float32)
                 for nn in range(16):
                     for gg in range(4):
-                        hi, lo = split_f16(hid[4 * gg:4 * gg + 4, nn])
+                        hi, lo = split_f16(hid[4 * gg:4 * gg + 4, nn], flush=False)
                         write_plane_piece(16 * t + nn, 2 * h + (gg >> 1), gg & 1, hi, lo)
     for tid in range(bm * 4):
         r, pl, ch = tid >> 2, (tid >> 1) & 1, 26 + (tid & 1)
@@ -517,7 +517,7 @@ def emulate_ln_linear_h2(slabs, lnw, lnb, pack_words, bias, N, late):
                 amax = np.abs(row).max()
                 e = int(np.frexp(amax)[1]) if amax > 0 else 0
                 scale[r] = 2.0 ** e
-                hi, lo = split_f16(row * np.float32(2.0 ** -e))
+                hi, lo = split_f16(row * np.float32(2.0 ** -e), flush=False)
                 assert np.abs(hi.astype(np.float32)).max() < 1.0
                 for l in range(64):
                     a = r * 1024 + (((l >> 1) ^ (r & 15)) << 4) + 8 * (l & 1)

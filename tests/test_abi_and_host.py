@@ -343,6 +343,40 @@ def test_split_f16_qkv_pack_and_kernel_addressing_by_emulation():
     assert (np.abs(got0 - ref0).max(axis=1) / np.abs(ref0).max(axis=1)).max() < 3e-7
 
 
+def test_split_f16_row_block_query_fragments_and_range_proof():
+    """The split-f16 row block (csrc/denoiser.hip rowblock_kernel<.., H2>) reads the learned queries as 16-byte plane fragments: wave w (K quarter),
+    K step s, tap j, lane (kq, li < NQ) loads word offset ((((2 w + s) 3 + j) 2 + plane) 4 + kq) NQ + li of mdm.py qan_fragments_h2 and contracts its 8
+    halves with k = 64 w + 32 s + 8 kq .. + 7 of the token row.  Restated here: the three-product sum over those fragments equals the fp32
+    contraction to 2^-21, and the LayerNorm range proof accepts ordinary weights and refuses ones that could leave the f16 range."""
+    import numpy as np
+    from interdiff_amd.mdm import qan_fragments_h2, split_f16, ln_h2_range_ok, NQ
+    rs = np.random.RandomState(5)
+    qc = (rs.standard_normal((NQ, 3, 256)) * 0.05).astype(np.float32)
+    qc[0, 0, :4] = [1e-6, -3e-5, 6.2e-5, 0.0]                           # below the hi plane's flush threshold
+    frag = qan_fragments_h2(qc)
+    assert frag.dtype == np.float32 and frag.size == 16 * 3 * 4 * NQ * 4
+    halves = frag.view(np.float16).reshape(-1, 8)                        # 16-byte units
+    x = rs.standard_normal((18, 256)).astype(np.float32)
+    xh, xl = split_f16(x)
+    got = np.zeros((16, 3, NQ), np.float64)
+    for w in range(4):
+        for s in range(2):
+            for kq in range(4):
+                k0 = 64 * w + 32 * s + 8 * kq
+                for j in range(3):
+                    for li in range(NQ):
+                        u = ((((2 * w + s) * 3 + j) * 2 + 0) * 4 + kq) * NQ + li
+                        bh, bl = halves[u].astype(np.float64), halves[u + 4 * NQ].astype(np.float64)        # the lo' plane sits 4 kq x NQ units behind
+                        ah, al = xh[j:j + 16, k0:k0 + 8].astype(np.float64), xl[j:j + 16, k0:k0 + 8].astype(np.float64)
+                        got[:, j, li] += ah @ bh + (ah @ bl + al @ bh) / 2048.0
+    ref = np.einsum('tjk,njk->tjn', np.stack([x[j:j + 16].astype(np.float64) for j in range(3)], 1), qc.astype(np.float64))
+    assert np.abs(got - ref).max() <= 2.0 ** -21 * np.abs(ref).max() + 1e-9
+    one, zero = np.ones(256, np.float32), np.zeros(256, np.float32)
+    assert ln_h2_range_ok((one, zero), (3 * one, one))
+    assert not ln_h2_range_ok((one, zero), (4000 * one, zero))           # 16 x 4000 > 60000
+    assert not ln_h2_range_ok((one * np.float32(np.nan), zero))
+
+
 def test_scan_order_is_a_consistent_relabelling():
     """Host side of the exact block culling (interdiff_amd/geometry.py MeshTopology): vorder is a permutation, faces_scan / marker
     positions are the same mesh relabelled, and 16 consecutive scan positions of the rest pose are spatially compact."""
@@ -401,7 +435,10 @@ def test_feed_forward_tile_is_picked_from_the_batch_rows():
     assert [m.w.tune[i] for i in range(8) if i != k] == [0] * 7          # nothing else is touched (ffn_math: 'exact' without the attribute)
     m.ffn_math = 'split'
     MDM._pick_ffn_tile(m, 100)
-    assert m.w.tune[_lib.TUNE['ffn_math']] == 1
+    assert m.w.tune[_lib.TUNE['ffn_math']] == 2                        # split-f16 feed-forward + QKV, exact row block (no rowblock_math attribute)
+    m.rowblock_math = 'split'
+    MDM._pick_ffn_tile(m, 100)
+    assert m.w.tune[_lib.TUNE['ffn_math']] == 1                        # split-f16 everywhere
     src = open(os.path.join(ROOT, 'interdiff_amd', 'csrc', 'ffn.h')).read()
     assert 'constexpr int FFN16_MAX_ROWS = %d, FFN64_MIN_ROWS = %d;' % (MDM.FFN16_MAX_ROWS, MDM.FFN64_MIN_ROWS) in src
 

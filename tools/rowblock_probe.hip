@@ -18,7 +18,7 @@ void idf_prof_mark_slow(int, hipStream_t) {}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char **argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 100;
+    const int B = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 100, h2 = argc > 3 ? atoi(argv[3]) : 0;     // h2 = 1: the split-f16 row block
     // a weights struct whose every offset points into one big random arena (layout irrelevant for timing)
     const size_t arena_floats = (size_t)40 << 20;
     std::vector<float> h(arena_floats);
@@ -38,10 +38,12 @@ int main(int argc, char **argv) {
         ly.is_qan = (l >= 1);                 // the last launch is a QaN row block: its stamps are the ones read back
         ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256); ly.sa_out_frag = take(256 * 256);
         ly.qc = take(16 * 3 * 40 * 4); ly.wk = take(64);
+        if (h2) { ly.qc_h2 = take(16 * 3 * 40 * 4); ly.rb_h2_ok = 1; }
         ly.ca_out_b = take(256);
         ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
         for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }
     }
+    if (h2) w.tune[IDF_TUNE_FFN_MATH] = 1;        // (no split-f16 FFN / QKV streams are set: those stay exact)
     if (off > arena_floats) { printf("arena too small\n"); return 1; }
     float *memctx, *x, *x0;
     int64_t *ts;
@@ -63,7 +65,7 @@ int main(int argc, char **argv) {
     double acc[9] = {0}, tot = 0;
     for (int wgi = 0; wgi < nwg; ++wgi)
         for (int i = 1; i < 9; ++i) acc[i] += (double)(st[(size_t)wgi * 16 + i] - st[(size_t)wgi * 16 + i - 1]);
-    printf("QaN row block (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", B, T, nwg);
+    printf("QaN row block%s (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", h2 ? ", split-f16 contractions" : "", B, T, nwg);
     for (int i = 1; i < 9; ++i) { printf("  %-46s %8.0f\n", names[i], acc[i] / nwg); tot += acc[i] / nwg; }
     printf("  total %.0f\n", tot);
     double a9 = 0, a10 = 0, spread = 0;

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     };
     // the DMA'd vectors must have landed for every wave before anyone reads them: each wave drains its own queue (its rows come
     // with it -- they are needed now anyway), then one barrier
+    // (H2 owns the whole register file, so the G / VW fragments could be requested here as well: measured, slower -- the CU's address path takes ~16 cycles per
+    //  sixteen-byte wave load whoever waits for it, a wave cannot start waiting for its rows before it has issued everything, and the first phase grew from
+    //  7.5 k to 9.0 k cycles, the kernel from 15.6 k to 16.6 k: the three batches stay.  This kernel moves ~330 KB per workgroup through that path: 5.2 k of its cycles.)
     IDF_RB_STAMP(9);                                     // every request of the first batch issued
     if constexpr (QAN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // everything older than the 12 Qc fragment loads has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

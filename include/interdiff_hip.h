@@ -183,7 +183,11 @@ int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float 
  *   G   [L][B][40][256]  (scores = x . G^T + g0, 40 = heads*MEM, pre-scaled by 1/sqrt(64))
  *   VWT [L][B][256][48]  (out = P . VW + out_bias, stored output-column-major, 40 padded to 48)
  *   g0  [L][B][40]
- * cond [MEM,B,256] (reference layout).  `memctx` must hold interdiff_mdm_memctx_floats(B). */
+ * and, behind them, the same G / VW as split-f16 plane fragments for the row block's f16-MFMA form (csrc/denoiser.hip G_H2 / VW_H2: each (layer,
+ * clip) matrix divided by the power of two that puts its largest magnitude in [2^13, 2^14), two f16 planes, fragment order) with the two powers
+ * of two per (layer, clip).  Both forms are always folded; which one a forward reads follows tune[IDF_TUNE_FFN_MATH].  The layout is private to
+ * the library: `memctx` is an opaque buffer of interdiff_mdm_memctx_floats(B) floats.
+ * cond [MEM,B,256] (reference layout). */
 /* The feed-forward block of one layer as a standalone op (what bench.py times for its roofline block; the denoiser launches the
  * same kernel): x2 [M,256] -> parts [IDF_FFN_SLICES][M][256] whose sum over the slabs is x2 + linear2(gelu(linear1(x2)))
  * (torch.nn.TransformerDecoderLayer._ff_block + residual; sublayers.py:331-341).  encoder != 0 selects enc_layer[layer].

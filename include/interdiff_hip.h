@@ -170,6 +170,9 @@ typedef struct {
      * 16-, 32- and 64-row tiles are bit-identical, so with 1 the row tile is a pure performance choice.  2 = like 1 for the feed-forward block and the QKV
      * projection, exact fp32 in the row block (A/B runs). */
     int32_t tune[8];
+    /* split-f16 plane fragments of the two token GEMMs at the ends of a step (csrc/tail_h2.h; mdm.py pack_tail_h2), 0 = not packed (token width != 144
+     * or a value outside the f16 range): out_w as [9 output tiles][8 K steps][2 planes][64 lanes][8 halves], in_w as [16][5][2][64][8] (K = 144 padded to 160) */
+    int64_t out_w_h2, in_w_h2;
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
@@ -280,6 +283,19 @@ int interdiff_sampler_advance(int64_t *state, int64_t *ts, int32_t B, void *stre
 int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
                                const float *gt, const uint8_t *mask, const float *table, int64_t *state,
                                void *ws, size_t ws_bytes, void *stream);
+/* interdiff_mdm_forward_step with flags that chain consecutive plain steps of ONE chain on ONE workspace (nothing may touch x, ts or the workspace between
+ * the two calls): IDF_STEP_EMBED_NEXT -- this call's last launch also computes the NEXT step's embedding from the token rows it has just updated
+ * (csrc/tail_h2.h: LN3 -> heads -> update -> embedding by one workgroup per 16 token rows); IDF_STEP_EMBED_READY -- the previous call was made with
+ * IDF_STEP_EMBED_NEXT: this call starts at its QKV projection.  Results are bit-identical to unflagged calls.  Honoured only when
+ * interdiff_mdm_step_chaining(w) is 1 (split arithmetic selected in tune[IDF_TUNE_FFN_MATH], token width 144, out_w_h2 / in_w_h2 packed); otherwise the
+ * flags are ignored and every call runs its own embedding (same results).  Reference seam: one iteration of p_sample_loop_progressive
+ * (gaussian_diffusion.py:640-681) -- the reference runs ~350 launches per iteration. */
+#define IDF_STEP_EMBED_READY 1
+#define IDF_STEP_EMBED_NEXT 2
+int interdiff_mdm_forward_step_ex(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
+                                  const float *gt, const uint8_t *mask, const float *table, int64_t *state, void *ws,
+                                  size_t ws_bytes, int32_t flags, void *stream);
+int interdiff_mdm_step_chaining(const idf_mdm_weights *w);
 
 /* ------------------------------------------------------------------------------------
  * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,

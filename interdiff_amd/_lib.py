@@ -9,12 +9,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
 MDM_LAYERS = 8
 FFN_SLICES = 5              # IDF_FFN_SLICES: partial output slabs of the fused feed-forward kernel
+STEP_EMBED_READY, STEP_EMBED_NEXT = 1, 2          # flags of interdiff_mdm_forward_step_ex (IDF_STEP_*)
 TUNE = dict(embed=0, qkv=1, outproj=2, ffn=3, ffn_math=4, heads=5, contact=6, misc=7)      # indices into MdmWeights.tune (IDF_TUNE_*)
 
 
@@ -37,7 +38,7 @@ class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
                 ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
-                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8)]
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64)]
 
 
 class PnMlp(C.Structure):
@@ -99,6 +100,8 @@ _SIGS = {
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),
     'interdiff_mdm_forward': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
     'interdiff_mdm_forward_step': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    'interdiff_mdm_forward_step_ex': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, i32, vp]),
+    'interdiff_mdm_step_chaining': (C.c_int, [C.POINTER(MdmWeights)]),
     'interdiff_inpaint': (C.c_int, [vp, vp, vp, i64, vp]),
     'interdiff_posterior_step': (C.c_int, [vp, vp, vp, i64, f32, f32, f32, u64, u64, vp]),
     'interdiff_randn': (C.c_int, [vp, i64, u64, u64, vp]),

@@ -22,6 +22,7 @@
 #include "gemm.h"
 #include "ffn.h"
 #include "ffn_h2.h"
+#include "tail_h2.h"
 
 // the feed-forward block of one layer: arithmetic by tune[IDF_TUNE_FFN_MATH] (and whether the packer set the layer's split-f16 stream),
 // row tile by tune[IDF_TUNE_FFN] (0: by this launch's rows)
@@ -113,16 +114,7 @@ __device__ __forceinline__ void ln_row16_lds(Row16 &r, const float *w, const flo
     }
 }
 
-// the two f16 planes of a token row (ffn_h2.h split4_pk: no flush rule, packed instructions) next to its fp32 image: lane l16 owns the 4-float chunks {l16, 16 + l16, 32 + l16, 48 + l16}
-__device__ __forceinline__ void row16_store_planes(const Row16 &r, _Float16 *hi_row, _Float16 *lo_row, int l16) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint2 h, l;
-        idf_ffn_h2::split4_pk(r.c[i], h, l);
-        *reinterpret_cast<uint2 *>(hi_row + (i * 16 + l16) * 4) = h;
-        *reinterpret_cast<uint2 *>(lo_row + (i * 16 + l16) * 4) = l;
-    }
-}
+using idf_ffn_h2::row16_store_planes;
 // one K = 32 step of a split-f16 product on NA tiles: main += ah.bh, corr += ah.bl' + al'.bh   (result = main + corr 2^-11)
 template <int NA>
 __device__ __forceinline__ void mma_h2(f32x4 (&am)[NA], f32x4 (&ac)[NA], const idf_ffn_h2::h8 (&ah)[NA], const idf_ffn_h2::h8 (&al)[NA],
@@ -1144,7 +1136,7 @@ struct StepPost {
 };
 
 int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
-                     void *ws, size_t ws_bytes, void *stream, const StepPost &post) {
+                     void *ws, size_t ws_bytes, void *stream, const StepPost &post, int32_t flags = 0) {
     if (!w || !memctx || !x || !ts || (!x0 && !post.x) || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
     if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_workspace_bytes(B, T)) return IDF_E_NOMEM;
@@ -1156,6 +1148,19 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const float *G = mc.G, *VWT = mc.VWT, *g0 = mc.g0;
     const int32_t *tune = w->tune;
 
+    // The two ends of the step as split-f16 "step tail" launches (tail_h2.h): with the split arithmetic, the SMPL token width and the packer's plane
+    // fragments.  flags (interdiff_mdm_forward_step_ex) then chain consecutive plain steps: IDF_STEP_EMBED_READY = the previous call's tail has already
+    // written this step's embedding into the workspace, IDF_STEP_EMBED_NEXT = this call's tail writes the next step's.  Ignored otherwise.
+    const bool tail_h2 = tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && C == idf_tail_h2::CW && w->layer[L - 1].rb_h2_ok != 0;
+    idf_tail_h2::TailArgs ta{};
+    if (tail_h2) {
+        ta.win = ar + w->in_w_h2; ta.in_b = ar + w->in_b; ta.temb = ar + w->temb_table; ta.pe = ar + w->pe; ta.ts = ts; ta.n_steps = w->n_steps;
+        ta.u0 = k.uA; ta.M = N; ta.T = T; ta.x_tok = x;
+        if (!(post.x && (flags & IDF_STEP_EMBED_READY))) {
+            idf_prof_mark(IDF_K_EMBED, s);
+            if (const int rc = idf_tail_h2::launch_tail(s, 0, ta); rc != IDF_OK) return rc;
+        }
+    } else
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
         Args g{};
         // token width C: any (BASELINE config #1, the HO-GCN skeleton tokens of model/diffusion_skeleton.py:236-253, has C = 106); W_in is packed
@@ -1258,6 +1263,17 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
         lnp_w = ar + ly.ln_w[2];
         lnp_b = ar + ly.ln_b[2];
     }
+    if (tail_h2) {
+        ta.u_in = u_in; ta.pstride = pstride; ta.ln_w = lnp_w; ta.ln_b = lnp_b; ta.wout = ar + w->out_w_h2; ta.out_b = ar + w->out_b; ta.x0 = x0;
+        idf_prof_mark(IDF_K_GEMM_HEADS, s);
+        int mode = 1;
+        if (post.x) {
+            ta.post.N = C; ta.post.M = N; ta.post.T = T;
+            ta.post.post_x = post.x; ta.post.post_gt = post.gt; ta.post.post_mask = post.mask; ta.post.post_table = post.table; ta.post.post_state = post.state;
+            mode = (flags & IDF_STEP_EMBED_NEXT) ? 3 : 2;
+        }
+        if (const int rc = idf_tail_h2::launch_tail(s, mode, ta); rc != IDF_OK) return rc;
+    } else
     {   // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
         Args g{};
         g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + w->out_w; g.bias = ar + w->out_b; g.C = x0;
@@ -1294,4 +1310,21 @@ extern "C" int interdiff_mdm_forward_step(const idf_mdm_weights *w, const float 
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 3) return IDF_E_INVAL;
     if (!w || w->layer[0].is_qan) return IDF_E_INVAL;         // the step bookkeeping rides on layer 0's QKV kernel
     return mdm_forward_impl(w, memctx, x, ts, B, T, nullptr, ws, ws_bytes, stream, StepPost{x, gt, mask, table, state, ts});
+}
+
+// The same with flags that chain CONSECUTIVE plain steps on one workspace (include/interdiff_hip.h IDF_STEP_*): a step's last launch then also computes
+// the next step's embedding from the token rows it has just updated (tail_h2.h), and the next call starts at its QKV projection.
+extern "C" int interdiff_mdm_forward_step_ex(const idf_mdm_weights *w, const float *memctx, float *x, int64_t *ts, int32_t B, int32_t T,
+                                             const float *gt, const uint8_t *mask, const float *table, int64_t *state, void *ws,
+                                             size_t ws_bytes, int32_t flags, void *stream) {
+    if (!x || !ts || !table || !state || (mask && !gt) || T <= 0 || (flags & ~(IDF_STEP_EMBED_READY | IDF_STEP_EMBED_NEXT))) return IDF_E_INVAL;
+    if (!(T & 3) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 15 || (reinterpret_cast<uintptr_t>(mask) & 3))) return IDF_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gt)) & 3) return IDF_E_INVAL;
+    if (!w || w->layer[0].is_qan) return IDF_E_INVAL;
+    return mdm_forward_impl(w, memctx, x, ts, B, T, nullptr, ws, ws_bytes, stream, StepPost{x, gt, mask, table, state, ts}, flags);
+}
+
+// 1 when interdiff_mdm_forward_step_ex honours its flags for this handle (split arithmetic selected, token width 144, plane fragments packed); 0: they are ignored
+extern "C" int interdiff_mdm_step_chaining(const idf_mdm_weights *w) {
+    return w && w->tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && w->C == idf_tail_h2::CW && w->layer[L - 1].rb_h2_ok != 0 ? 1 : 0;
 }

@@ -112,6 +112,18 @@ __device__ __forceinline__ void split1_nf(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)((v - (float)hi) * LO_SCALE);
 }
 
+// the two f16 planes of a token row (split4_pk) for a kernel that keeps rows one per 16-lane group (common.h Row16): lane l16 owns the 4-float chunks
+// {l16, 16 + l16, 32 + l16, 48 + l16}; hi_row / lo_row point at the row's first half in each plane
+__device__ __forceinline__ void row16_store_planes(const Row16 &r, _Float16 *hi_row, _Float16 *lo_row, int l16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2 h, l;
+        split4_pk(r.c[i], h, l);
+        *reinterpret_cast<uint2 *>(hi_row + (i * 16 + l16) * 4) = h;
+        *reinterpret_cast<uint2 *>(lo_row + (i * 16 + l16) * 4) = l;
+    }
+}
+
 // gelu_fast (common.h) on a PAIR of values: packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) cost a wave what the
 // plain ones cost, so the polynomial runs at half the issue slots; rcp / exp stay per element.  Same operations in the same order as gelu_fast.
 __device__ __forceinline__ f2 gelu_fast2(f2 x) {

@@ -186,7 +186,8 @@ __device__ __forceinline__ void post_prefetch(const Args &g, PostOperands<TM, TN
 }
 template <int TM, int TN, bool ragged>
 __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[TM][TN], const float (&bvs)[TN], const PostOperands<TM, TN> &po,
-                                              int rbase0, int col0) {
+                                              int rbase0, int col0, float *lds_tile = nullptr, int lds_stride = 0) {
+    // lds_tile (tail_h2.h, TM = TN = 1): the updated values also go to an LDS tile -- lds_tile[r * lds_stride] = row r of the lane's four -- for the next step's embedding
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -199,6 +200,9 @@ __device__ __forceinline__ void epilogue_post(const Args &g, const f32x4 (&acc)[
             const float4 gv = po.gv[i][j];
             pv.x = m.x ? gv.x : pv.x; pv.y = m.y ? gv.y : pv.y; pv.z = m.z ? gv.z : pv.z; pv.w = m.w ? gv.w : pv.w;
             const float4 out = posterior4(po.c1, po.c2, po.sigma, pv, po.xv[i][j], po.e[i][j]);
+            if (lds_tile) {
+                lds_tile[0] = out.x; lds_tile[lds_stride] = out.y; lds_tile[2 * lds_stride] = out.z; lds_tile[3 * lds_stride] = out.w;
+            }
             if constexpr (!ragged) {
                 const int b = rbase / g.T, t = rbase - b * g.T;
                 idf_store16_wt(g.post_x + ((size_t)b * g.N + col) * g.T + t, out);      // the next step's embedding reads x from other XCDs

@@ -81,6 +81,7 @@ class GaussianDiffusion:
         self._t_cache = {}
         self._tables = {}
         self.fuse_plain_step = True          # plain steps of the graph route: posterior update inside the denoiser's last GEMM
+        self.chain_plain_steps = os.environ.get('INTERDIFF_CHAIN_STEPS', '1') != '0'      # ... and, inside a captured run of plain steps, the next step's embedding in the same launch (csrc/tail_h2.h)
         self.split_chains = True             # ... and, for batches that do not fill the chip, as two independent half-batch chains
         self.split_min_rows = None           # ... when the batch has more token rows than this (None: the denoiser's one_chain_max_rows(), see _graph_loop)
         self.stagger_steps = STAGGER_STEPS   # ... which step through the WHOLE loop on their own streams, this many steps apart, when the hook can be called per half batch
@@ -160,8 +161,13 @@ class GaussianDiffusion:
             if getattr(model, 'supports_forward_step', False):
                 # ... and the fused step's own instantiations (last GEMM with the update in its epilogue, QKV kernel with the sampler
                 # bookkeeping): their FIRST launch must not happen inside a capture, where a launch error cannot be reported
-                scratch = SimpleNamespace(x=st.x.clone(), ts=st.ts.clone(), state=torch.tensor([1, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev))
+                scratch = SimpleNamespace(x=st.x.clone(), ts=st.ts.clone(), state=torch.tensor([2, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev))
                 model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
+                if getattr(model, 'step_chaining', False):     # ... and the chained forms of the step tail (csrc/tail_h2.h)
+                    scratch.state.copy_(torch.tensor([2, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int64))
+                    scratch.ts.copy_(st.ts)
+                    model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, embed_next=True, **st.kwargs, **rows_kw)
+                    model.forward_step(scratch.x, scratch.ts, table, scratch.state, gt=st.gt, mask=st.mask, embed_ready=True, **st.kwargs, **rows_kw)
             torch.cuda.synchronize(dev)
             if pools_before is not None:              # what this cache entry made the denoiser allocate: released with the entry
                 st.pool_keys = model.shape_buffer_keys() - pools_before
@@ -197,21 +203,29 @@ class GaussianDiffusion:
                 ch.cond.copy_(st.cond[:, ch.sl])
                 model.prepare_memory(ch.cond, into=ch.memctx)
 
+        chain_steps = self.chain_plain_steps and fused and getattr(model, 'step_chaining', False)
+        if st.__dict__.get('chain_steps') != chain_steps:      # captured launches bake it in
+            st.graphs.clear()
+            st.chain_steps = chain_steps
+
         def enqueue_plain(k):
-            """k consecutive plain steps on the current (capturing) stream: every per-step scalar is read from HBM, so they fit any position."""
+            """k consecutive plain steps on the current (capturing) stream: every per-step scalar is read from HBM, so they fit any position.
+            Inside such a run nothing touches x or the workspace between two steps, so step i's last launch also computes step i + 1's embedding
+            (``chain_steps``: MDM.forward_step embed_next / embed_ready, csrc/tail_h2.h -- same bits, one launch and its boundary less per step)."""
+            link = lambda i: dict(embed_ready=i > 0, embed_next=i + 1 < k) if chain_steps else {}
             if split:                       # fork: each chain runs its k steps on its own branch; join at the end
                 cur = torch.cuda.current_stream()
                 for ch in st.chains:
                     ch.stream.wait_stream(cur)
                     with torch.cuda.stream(ch.stream):
-                        for _ in range(k):
-                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows)
+                        for i in range(k):
+                            model.forward_step(ch.x, ch.ts, table, ch.state, gt=ch.gt, mask=ch.mask, memctx=ch.memctx, ws=ch.ws, batch_rows=rows, **link(i))
                 for ch in st.chains:
                     cur.wait_stream(ch.stream)
             else:
-                for _ in range(k):
+                for i in range(k):
                     if fused:               # the update runs in the epilogue of the denoiser's last GEMM (same bits)
-                        model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **st.kwargs, **rows_kw)
+                        model.forward_step(st.x, st.ts, table, st.state, gt=st.gt, mask=st.mask, **link(i), **st.kwargs, **rows_kw)
                     else:
                         model(st.x, st.ts, out=st.x0, **st.kwargs, **rows_kw)
                         posterior(st.x, st.x0, st.gt, st.mask, st)

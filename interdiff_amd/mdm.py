@@ -88,6 +88,28 @@ def qan_fragments_h2(qc):
     return np.ascontiguousarray(out).view(np.float32).reshape(-1)
 
 
+def pack_tail_h2(w_out, w_in):
+    """W_out [144, 256] (bodyFinalLinear ; objFinalLinear) and W_in [256, 144] (bodyEmbedding | objEmbedding) -> the plane fragments of the
+    split-f16 step-tail kernel (csrc/tail_h2.h): for every output tile nt (16 rows of the weight), K step s and plane, lane (li, kq) holds
+    plane(W[16 nt + li][32 s + 8 kq : + 8]) (zero past the matrix) -- [tiles][K steps][2 planes][64 lanes][8 halves], as float32 words.
+    Returns (out_w_h2 [36864 words], in_w_h2 [40960 words]); weights keep the hi plane's flush rule (split_f16)."""
+    def frags(w, ntile, kstep):
+        w = np.asarray(w, np.float32)
+        wp = np.zeros((16 * ntile, 32 * kstep), np.float32)
+        wp[:w.shape[0], :w.shape[1]] = w
+        hi, lo = split_f16(wp)
+        out = np.empty((ntile, kstep, 2, 4, 16, 8), np.float16)              # [...][kq][li][8]: lane = 16 kq + li
+        for s in range(kstep):
+            for kq in range(4):
+                k0 = 32 * s + 8 * kq
+                out[:, s, 0, kq] = hi[:, k0:k0 + 8].reshape(ntile, 16, 8)
+                out[:, s, 1, kq] = lo[:, k0:k0 + 8].reshape(ntile, 16, 8)
+        return np.ascontiguousarray(out).view(np.float32).reshape(-1)
+    w_out, w_in = np.asarray(w_out, np.float32), np.asarray(w_in, np.float32)
+    assert w_out.shape == (144, D) and w_in.shape[0] == D and w_in.shape[1] >= 144
+    return frags(w_out, 9, 8), frags(w_in[:, :144], 16, 5)
+
+
 def ln_h2_range_ok(*gamma_beta_pairs):
     """A LayerNorm output is bounded by sqrt(D - 1) max|gamma| + max|beta| (|normalised element| <= sqrt(D - 1) < 16): True when every
     given (gamma, beta) keeps its rows below the f16 limit with the margin of H2_LIMIT -- what the split-f16 row block asks of its A operands."""
@@ -280,6 +302,11 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
     w.in_b = ar.add(g('bodyEmbedding.bias') + g('objEmbedding.bias'))
     w.out_w = ar.add(np.concatenate([g('bodyFinalLinear.weight'), g('objFinalLinear.weight')], axis=0))
     w.out_b = ar.add(np.concatenate([g('bodyFinalLinear.bias'), g('objFinalLinear.bias')]))
+    w.out_w_h2 = w.in_w_h2 = 0                 # split-f16 plane fragments of the two token GEMMs (csrc/tail_h2.h): SMPL token width, values inside the f16 range
+    wout_full = np.concatenate([g('bodyFinalLinear.weight'), g('objFinalLinear.weight')], axis=0)
+    if w.C == 144 and np.abs(wout_full).max() < H2_LIMIT and np.abs(win).max() < H2_LIMIT:
+        oh2, ih2 = pack_tail_h2(wout_full, win)
+        w.out_w_h2, w.in_w_h2 = ar.add(oh2), ar.add(ih2)
     pe = g('PositionalEmbedding.pe')[:, 0] if 'PositionalEmbedding.pe' in sd else positional_table()
     if n_steps > pe.shape[0] or max_T > pe.shape[0]:
         raise ValueError('positional table too short')
@@ -598,8 +625,17 @@ class MDM:
     def supports_forward_step(self):
         return not self.w.layer[0].is_qan             # the step's sampler bookkeeping rides on layer 0's QKV kernel
 
-    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None, batch_rows=None):
-        """One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
+    @property
+    def step_chaining(self):
+        """True when ``forward_step`` honours ``embed_ready`` / ``embed_next`` (interdiff_mdm_step_chaining: split arithmetic selected, token width
+        144, plane fragments packed); otherwise the flags are ignored (same results, every step runs its own embedding)."""
+        self._pick_ffn_tile(1)                    # (writes the arithmetic selection into the handle)
+        return bool(self.lib.interdiff_mdm_step_chaining(C.byref(self.w)))
+
+    def forward_step(self, x, timesteps, table, state, gt=None, mask=None, y=None, memctx=None, ws=None, batch_rows=None, embed_ready=False, embed_next=False):
+        """``embed_next``: this step's last launch also computes the NEXT plain step's embedding into the workspace (csrc/tail_h2.h); ``embed_ready``: the
+        previous call on this x / workspace was made with ``embed_next`` and nothing touched x, the timesteps or the workspace since (same bits either way).
+        One plain reverse step with the update applied inside the last GEMM (interdiff_mdm_forward_step): ``x`` [B,1,C,T] and
         the sampler state (``timesteps`` int64 [B], ``state`` int64 [8]) are advanced in place (any T; T % 4 == 0 takes the 16-byte form of the update).  ``memctx`` / ``ws``:
         caller-owned folded memory (``prepare_memory(cond, into=)``) and workspace (``workspace_bytes(B, T)`` bytes) instead of the
         model's -- what lets two chains of one sample run side by side; ``batch_rows`` then names the whole batch's B * T (see
@@ -617,10 +653,11 @@ class MDM:
             raise ValueError('memctx was folded for another batch size')
         if ws is None:
             ws = self._workspace(B, T)
-        _lib.check(self.lib.interdiff_mdm_forward_step(C.byref(self.w), _lib.dptr(memctx), _lib.dptr(x, torch.float32),
-                                                       _lib.dptr(timesteps, torch.int64), B, T, _lib.dptr(gt, allow_none=True),
-                                                       _lib.dptr(mask, allow_none=True), _lib.dptr(table), _lib.dptr(state),
-                                                       _lib.dptr(ws), ws.numel(), _lib.stream()), 'mdm_forward_step')
+        flags = (_lib.STEP_EMBED_READY if embed_ready else 0) | (_lib.STEP_EMBED_NEXT if embed_next else 0)
+        _lib.check(self.lib.interdiff_mdm_forward_step_ex(C.byref(self.w), _lib.dptr(memctx), _lib.dptr(x, torch.float32),
+                                                          _lib.dptr(timesteps, torch.int64), B, T, _lib.dptr(gt, allow_none=True),
+                                                          _lib.dptr(mask, allow_none=True), _lib.dptr(table), _lib.dptr(state),
+                                                          _lib.dptr(ws), ws.numel(), flags, _lib.stream()), 'mdm_forward_step')
         return x
 
 

@@ -377,6 +377,36 @@ def test_split_f16_row_block_query_fragments_and_range_proof():
     assert not ln_h2_range_ok((one * np.float32(np.nan), zero))
 
 
+def test_split_f16_step_tail_fragments():
+    """csrc/tail_h2.h reads W_out / W_in as 16-byte plane fragments: output tile nt, K step s, plane, lane (li, kq) at 16-byte unit
+    ((nt KS + s) 2 + plane) 64 + 16 kq + li of mdm.py pack_tail_h2, contracted with k = 32 s + 8 kq .. + 7 of the token row.  Restated: the three-product sum
+    over the fragments equals the fp32 contraction to 2^-21 for both matrices (K = 144 zero-padded to 160 for the embedding)."""
+    import numpy as np
+    from interdiff_amd.mdm import pack_tail_h2, split_f16
+    rs = np.random.RandomState(9)
+    w_out = (rs.standard_normal((144, 256)) * 0.06).astype(np.float32)
+    w_in = (rs.standard_normal((256, 144)) * 0.08).astype(np.float32)
+    oh2, ih2 = pack_tail_h2(w_out, w_in)
+    assert oh2.size == 9 * 8 * 2 * 64 * 4 and ih2.size == 16 * 5 * 2 * 64 * 4
+    for frag, w, ntile, ks, K in ((oh2, w_out, 9, 8, 256), (ih2, w_in, 16, 5, 144)):
+        halves = frag.view(np.float16).reshape(-1, 8)
+        x = rs.standard_normal((16, 32 * ks)).astype(np.float32)
+        x[:, K:] = 0
+        xh, xl = split_f16(x, flush=False)
+        got = np.zeros((16, 16 * ntile), np.float64)
+        for nt in range(ntile):
+            for s in range(ks):
+                for kq in range(4):
+                    k0 = 32 * s + 8 * kq
+                    ah, al = xh[:, k0:k0 + 8].astype(np.float64), xl[:, k0:k0 + 8].astype(np.float64)
+                    for li in range(16):
+                        u = ((nt * ks + s) * 2) * 64 + 16 * kq + li
+                        bh, bl = halves[u].astype(np.float64), halves[u + 64].astype(np.float64)
+                        got[:, 16 * nt + li] += ah @ bh + (ah @ bl + al @ bh) / 2048.0
+        ref = x[:, :K].astype(np.float64) @ w.astype(np.float64).T
+        assert np.abs(got - ref).max() <= 2.0 ** -21 * np.abs(ref).max() + 1e-9
+
+
 def test_scan_order_is_a_consistent_relabelling():
     """Host side of the exact block culling (interdiff_amd/geometry.py MeshTopology): vorder is a permutation, faces_scan / marker
     positions are the same mesh relabelled, and 16 consecutive scan positions of the rest pose are spatially compact."""

@@ -1105,6 +1105,38 @@ def test_forward_step_matches_two_call_form(mdm, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,T', [(16, 100), (3, 20), (3, 35), (2, 13)])
+def test_chained_plain_steps_equal_unchained(mdm, B, T):
+    """interdiff_mdm_forward_step_ex: four consecutive plain steps with every step's last launch also computing the next step's embedding
+    (csrc/tail_h2.h, MODE 3; the next call starts at its QKV projection) against the same four steps each run on its own -- x, the timesteps and the sampler
+    state bit for bit, at the bench shape (rows straddle clips: 16-row tiles at T = 100), a ragged last tile and the per-row update form (T % 4 != 0)."""
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    x, ts0, cond = fx.mdm_inputs(B, T)
+    g = torch.Generator().manual_seed(19)
+    gt, mask = torch.randn(x.shape, generator=g).to(DEV), (torch.rand(x.shape, generator=g) < 0.2).to(DEV).view(torch.uint8)
+    table = create_gaussian_diffusion('cosine', 1000)._table(torch.device(DEV))
+    y = {'cond': cond.to(DEV)}
+    keep = mdm.ffn_math, getattr(mdm, 'rowblock_math', 'split')
+    try:
+        for math in ('split', 'exact'):
+            mdm.ffn_math = math
+            assert mdm.step_chaining == (math == 'split')          # exact arithmetic: the flags are ignored (and must still give the same bits)
+
+            def run(chained):
+                xa = x.to(DEV).clone()
+                tsa = torch.full((B,), 640, dtype=torch.int64, device=DEV)
+                sta = torch.tensor([640, 5, 424242, 0, 0, 0, 4 * 311, 0], dtype=torch.int64, device=DEV)
+                for i in range(4):
+                    mdm.forward_step(xa, tsa, table, sta, gt=gt, mask=mask, y=y, embed_ready=chained and i > 0, embed_next=chained and i < 3)
+                return xa, tsa, sta
+            (xa, tsa, sta), (xb, tsb, stb) = run(False), run(True)
+            assert torch.equal(xa, xb) and torch.equal(tsa, tsb) and torch.equal(sta, stb), (math, float((xa - xb).abs().max()))
+            assert int(tsa[0]) == 636 and torch.isfinite(xa).all()
+    finally:
+        mdm.ffn_math, mdm.rowblock_math = keep
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('T,B,P', [(11, 1, 1), (12, 2, 63), (13, 1, 1000), (11, 2, 2048)])
 def test_correction_edge_sizes(smpl, T, B, P):
     """Correction hook with ragged point counts (a single point, below one wave, not a multiple of the workgroup, the

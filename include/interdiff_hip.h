@@ -141,6 +141,8 @@ typedef struct {
     int64_t rb_h2_ok;          /* decoder layers: 1 when the packer has proved that the LayerNorm outputs this layer's row block contracts (LN_prev, norm1) stay inside
                                   the f16 range (16 max|gamma| + max|beta| < 65504; mdm.py ln_h2_range_ok) -- with tune[IDF_TUNE_FFN_MATH] == 1 the row block then runs
                                   its three contractions as split-f16 products; 0 = always exact fp32 */
+    int64_t sa_out_frag_h2;    /* std only: 0, or sa_out_w as two f16 planes in the split-f16 attention kernel's fragment order [head][16 output column tiles][2 K steps][2 planes]
+                                  [64 lanes][8 halves] (mdm.py sa_out_fragments_h2; csrc/attn_h2.h) */
 } idf_mdm_layer;
 
 typedef struct {

@@ -31,7 +31,7 @@ class MdmLayer(C.Structure):
                 ('ca_q_w', i64), ('ca_q_b', i64), ('ca_kv_w', i64), ('ca_kv_b', i64),
                 ('ca_out_w', i64), ('ca_out_b', i64),
                 ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64), ('ffn_b1p', i64), ('sa_in_pack', i64), ('sa_out_frag', i64),
-                ('ln_w', i64 * 3), ('ln_b', i64 * 3), ('ffn_pack_h2', i64), ('sa_in_pack_h2', i64), ('qc_h2', i64), ('rb_h2_ok', i64)]
+                ('ln_w', i64 * 3), ('ln_b', i64 * 3), ('ffn_pack_h2', i64), ('sa_in_pack_h2', i64), ('qc_h2', i64), ('rb_h2_ok', i64), ('sa_out_frag_h2', i64)]
 
 
 class MdmWeights(C.Structure):

@@ -1,0 +1,260 @@
+// NOT ON THE DEFAULT ROUTE (tune[IDF_TUNE_MISC] = 5 selects it): correct (all parity tests pass with it; a denoiser forward is 3.2e-7 from the fp64 answer
+// with it, 4.6e-7 without) but 1.5 % slower over whole samples than the fp32 kernel it would replace -- 11.1 / 10.0 us against 10.2 / 9.8 in situ
+// (profiles/r04_attn_split_f16_ab.txt): owning the CU costs the overlap of two co-resident workgroups, which was worth more than the matrix time saved.
+//
+// Temporal self-attention of the two standard layers with its head's slice of the out-projection, on the f16 matrix pipe (round 4):
+//
+//     ctx = softmax(Q K^T / 8) V   per (clip, head);   slab[head] = ctx . W_o[:, head]^T        (torch.nn.MultiheadAttention inside TransformerDecoderLayer)
+//
+// Same contract as denoiser.hip self_attn_kernel<OUTPROJ>: qkv [N][768] in, H partial slabs [N][256] out (the row block sums them).  What differs:
+//  * 32 queries per workgroup and ONE workgroup per CU (ceil(T/32) x 4 heads x B = 256 workgroups at T = 100, B = 16: exactly the chip), 512 threads;
+//    the fp32 kernel runs 448 workgroups of 16 queries, two per CU -- a kernel that issues the f16 MFMA must own its CU (ffn_h2.h "exclusive CU"), so the
+//    overlap of two co-resident workgroups is replaced by twice the waves on twice the rows and K / V fetched once per 32 queries instead of per 16;
+//  * the three contractions are split-f16 products (v = hi + lo' 2^-11: three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate).  Q, K and V come out
+//    of the QKV projection with no a-priori range: each of the three tiles is divided by the power of two that puts its largest magnitude in [2^13, 2^14)
+//    (exact; an f16 pair then keeps 22 bits of every element down to 2^-27 of the largest) and the fp32 results are multiplied back -- S by 2^(eq + ek) / 8,
+//    the out-projection by 2^ev (the context is a convex combination of V rows: it inherits V's scale and range).  Probabilities are split as they are.
+//  * W_o arrives as pre-split plane fragments [head][16 column tiles][2 K steps][2 planes][64 lanes][8 halves] (mdm.py sa_out_fragments_h2).
+// LDS (dynamic, sized by T; T <= 208): K planes [TP][72] x 2 | V^T planes [64][TPP + 8] x 2 | S fp32 [32][TP + 4] | Q planes [32][72] x 2; the probability
+// planes [32][TPP + 8] x 2 overwrite K once S is complete, the context planes overwrite Q.  TP = T up to 16, TPP = T up to 32 (K steps over the keys).
+#pragma once
+#include <float.h>
+#include "common.h"
+#include "ffn_h2.h"
+
+namespace idf_attn_h2 {
+
+using idf_ffn_h2::h8;
+constexpr int D = IDF_MDM_D, H = IDF_MDM_HEADS, HD = D / H, QT = 32, NTH = 512, NWV = NTH / 64;
+constexpr int KHS = HD + 8;                              // row stride (halves) of the Q / K / context planes
+constexpr int MAX_T = 208, NIT = (MAX_T * 16 + NTH - 1) / NTH;      // float4 sweeps of a K / V tile per thread: 7
+constexpr int WO_H2_FLOATS = H * 16 * 2 * 2 * 64 * 4;      // 32768
+
+// halves of the region that holds the K planes and later the probability planes
+__host__ __device__ inline int k_region_halves(int TP, int TPP) { return 2 * TP * KHS > 2 * QT * (TPP + 8) ? 2 * TP * KHS : 2 * QT * (TPP + 8); }
+inline size_t lds_bytes(int T) {
+    const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31;
+    return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * HD * (TPP + 8) * 2 + (size_t)QT * (TP + 4) * 4 + (size_t)2 * QT * KHS * 2 + 64;
+}
+
+// power of two that brings amax into [2^13, 2^14): returns the multiplier 2^-e and, through `up`, 2^e (1 for an all-zero or non-finite tile)
+__device__ __forceinline__ float pow2_scale(float amax, float &up) {
+    int e = (amax > 0.f && amax < INFINITY) ? (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 127 - 13 : 0;
+    e = max(-100, min(100, e));                          // (a tile below 2^-87 is as good as zero; keeps both powers of two finite)
+    up = __builtin_bit_cast(float, (uint32_t)((127 + e) << 23));
+    return __builtin_bit_cast(float, (uint32_t)((127 - e) << 23));
+}
+
+__global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restrict__ qkv, int T, const float *__restrict__ wo_h2,
+                                                           float *__restrict__ slabs, size_t pstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    asm volatile("" ::: "v255");                         // exclusive CU: 2 waves per SIMD x 256 registers (+ the launcher's 160 KiB of LDS)
+    __shared__ float red[3][NWV];
+    idf_args_now(qkv, T, wo_h2, slabs, pstride, gridDim.x);
+    const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31, VTS = TPP + 8, SS = TP + 4;
+    _Float16 *kh = reinterpret_cast<_Float16 *>(smraw), *kl = kh + TP * KHS;                 // K planes [TP][KHS]
+    _Float16 *vth = kh + k_region_halves(TP, TPP), *vtl = vth + HD * VTS;                    // V^T planes [64][VTS]
+    float *Ss = reinterpret_cast<float *>(vtl + HD * VTS);                                   // S [32][SS]
+    _Float16 *qh = reinterpret_cast<_Float16 *>(Ss + QT * SS), *ql = qh + QT * KHS;          // Q planes [32][KHS], later the context planes
+    _Float16 *ph = kh, *pl = kh + QT * VTS;                                                  // probability planes [32][VTS] over K (the region is sized for the larger of the two)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int nwg = gridDim.x, id = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);      // XCD-affine: the query tiles of a (clip, head) share its K / V in one L2
+    const int nqt = (T + QT - 1) / QT, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT;
+    const size_t rowbase = (size_t)b * T;
+
+    // ---- operand fetch: everything requested at once with clamped addresses (no guard around a load)
+    const int qr = tid >> 4, c4 = (tid & 15) * 4;        // thread (row, 4-float chunk) of a [rows][64] tile
+    const float4 qv = *reinterpret_cast<const float4 *>(qkv + (rowbase + min(q0 + qr, T - 1)) * (3 * D) + h * HD + c4);
+    float4 kreg[NIT], vreg[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int j = min(qr + 32 * u, T - 1);
+        const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
+        kreg[u] = *reinterpret_cast<const float4 *>(src + D);
+        vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
+    }
+    float4 wo[2][2][2];                                  // out-projection fragments of this wave's two column tiles: [tile][K step][plane]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wo[c][s][p] = *reinterpret_cast<const float4 *>(wo_h2 + (size_t)(((((h * 16 + 2 * wave + c) * 2 + s) * 2 + p) * 64) + lane) * 4);
+
+    // ---- the three tile scales
+    auto amax4 = [](const float4 v) { return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))); };
+    float aq = q0 + qr < T ? amax4(qv) : 0.f, ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int u = 0; u < NIT; ++u)
+        if (qr + 32 * u < T) {
+            ak = fmaxf(ak, amax4(kreg[u]));
+            av = fmaxf(av, amax4(vreg[u]));
+        }
+    aq = wave_max(aq); ak = wave_max(ak); av = wave_max(av);
+    if (lane == 0) { red[0][wave] = aq; red[1][wave] = ak; red[2][wave] = av; }
+    __syncthreads();
+    aq = ak = av = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { aq = fmaxf(aq, red[0][w]); ak = fmaxf(ak, red[1][w]); av = fmaxf(av, red[2][w]); }
+    float uq, uk, uv;
+    const float dq = pow2_scale(aq, uq), dk = pow2_scale(ak, uk), dv = pow2_scale(av, uv);
+
+    // ---- planes: Q and K row-major [row][dim], V transposed [dim][key] (it is the B operand of P V: a lane's 8 halves run along the keys)
+    {
+        uint2 hi, lo;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        idf_ffn_h2::split4_pk(q0 + qr < T ? make_float4(qv.x * dq, qv.y * dq, qv.z * dq, qv.w * dq) : z, hi, lo);
+        *reinterpret_cast<uint2 *>(qh + qr * KHS + c4) = hi;
+        *reinterpret_cast<uint2 *>(ql + qr * KHS + c4) = lo;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = qr + 32 * u;
+            if (32 * u < TPP) {                          // (workgroup-uniform)
+                const bool live = j < T;
+                if (j < TP) {
+                    idf_ffn_h2::split4_pk(live ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
+                    *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
+                    *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
+                }
+                const float vv[4] = {vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, c;
+                    idf_ffn_h2::split1_nf(live ? vv[e] : 0.f, a, c);
+                    vth[(c4 + e) * VTS + j] = a;         // keys T .. TPP - 1 are zero: they meet zero probabilities
+                    vtl[(c4 + e) * VTS + j] = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T / 8: wave w owns key tiles w, w + 8, ... for both query tiles
+    const float sscale = uq * uk * 0.125f;
+    for (int ct = wave; ct < TP / 16; ct += NWV) {
+        f32x4 am[2], ac[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) am[rt] = ac[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ko = 32 * s + 8 * kq;
+            const h8 bh = *reinterpret_cast<const h8 *>(kh + (ct * 16 + li) * KHS + ko), bl = *reinterpret_cast<const h8 *>(kl + (ct * 16 + li) * KHS + ko);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const h8 ah = *reinterpret_cast<const h8 *>(qh + (rt * 16 + li) * KHS + ko), al = *reinterpret_cast<const h8 *>(ql + (rt * 16 + li) * KHS + ko);
+                IDF_H2_MFMA(am[rt], ah, bh);
+                IDF_H2_MFMA(ac[rt], ah, bl);
+                IDF_H2_MFMA(ac[rt], al, bh);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = (am[rt][r] + ac[rt][r] * idf_ffn_h2::LO_UNSCALE) * sscale;
+    }
+    __syncthreads();
+
+    // ---- row softmax: one 16-lane group per query row (32 groups = 32 rows); lane l16 owns columns l16, 16 + l16, ...; probabilities leave as planes over K
+    {
+        constexpr int NC = ((MAX_T + 31) & ~31) / 16;    // 14 columns per lane cover TPP of the longest clip
+        const int row = wave * 4 + kq;
+        const float *srow = Ss + row * SS;
+        float v[NC], mx = -FLT_MAX;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = 16 * c + li;
+            v[c] = srow[min(j, TP - 1)];
+            v[c] = j < T ? v[c] : -FLT_MAX;
+            mx = fmaxf(mx, v[c]);
+        }
+        mx = row16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            v[c] = 16 * c + li < T ? __expf(v[c] - mx) : 0.f;
+            sum += v[c];
+        }
+        const float inv = __builtin_amdgcn_rcpf(row16_sum(sum));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = 16 * c + li;
+            if (j < TPP) {                               // columns T .. TPP - 1 are written as zeros: they are part of the last K step
+                _Float16 a, cc;
+                idf_ffn_h2::split1_nf(v[c] * inv, a, cc);
+                ph[row * VTS + j] = a;
+                pl[row * VTS + j] = cc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- ctx' = P (V 2^-ev): eight 16 x 16 tiles, one per wave (query tile w >> 2, head-dim tile w & 3); left scaled, split, parked over Q
+    {
+        const int rt = wave >> 2, dt = wave & 3;
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = am;
+        for (int s = 0; s < TPP / 32; ++s) {
+            const int ko = 32 * s + 8 * kq;
+            const h8 ah = *reinterpret_cast<const h8 *>(ph + (rt * 16 + li) * VTS + ko), al = *reinterpret_cast<const h8 *>(pl + (rt * 16 + li) * VTS + ko);
+            const h8 bh = *reinterpret_cast<const h8 *>(vth + (dt * 16 + li) * VTS + ko), bl = *reinterpret_cast<const h8 *>(vtl + (dt * 16 + li) * VTS + ko);
+            IDF_H2_MFMA(am, ah, bh);
+            IDF_H2_MFMA(ac, ah, bl);
+            IDF_H2_MFMA(ac, al, bh);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16 a, c;
+            idf_ffn_h2::split1_nf(am[r] + ac[r] * idf_ffn_h2::LO_UNSCALE, a, c);
+            qh[(rt * 16 + kq * 4 + r) * KHS + dt * 16 + li] = a;      // (every wave finished reading the Q planes two barriers ago)
+            ql[(rt * 16 + kq * 4 + r) * KHS + dt * 16 + li] = c;
+        }
+    }
+    __syncthreads();
+
+    // ---- out-projection partial of this head: [32 x 64] . [64 x 256]; wave w owns output column tiles 2w, 2w + 1 for both query tiles
+    {
+        f32x4 om[2][2], oc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) om[rt][c] = oc[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ko = 32 * s + 8 * kq;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const h8 ah = *reinterpret_cast<const h8 *>(qh + (rt * 16 + li) * KHS + ko), al = *reinterpret_cast<const h8 *>(ql + (rt * 16 + li) * KHS + ko);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    IDF_H2_MFMA(om[rt][c], ah, __builtin_bit_cast(h8, wo[c][s][0]));
+                    IDF_H2_MFMA(oc[rt][c], ah, __builtin_bit_cast(h8, wo[c][s][1]));
+                    IDF_H2_MFMA(oc[rt][c], al, __builtin_bit_cast(h8, wo[c][s][0]));
+                }
+            }
+        }
+        float *slab = slabs + (size_t)h * pstride;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = q0 + rt * 16 + kq * 4 + r;
+                if (t < T) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        idf_store4_wt(slab + (rowbase + t) * D + (2 * wave + c) * 16 + li, (om[rt][c][r] + oc[rt][c][r] * idf_ffn_h2::LO_UNSCALE) * uv);
+                }
+            }
+    }
+}
+
+inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride) {
+    static std::atomic<uint64_t> done{0};
+    constexpr int LDS_REQUEST = 160 * 1024 - 256;        // the whole CU's LDS minus the kernel's static words (exclusive CU)
+    if (T > MAX_T || (int)lds_bytes(T) > LDS_REQUEST) return IDF_E_INVAL;
+    if (idf_opt_in_lds(reinterpret_cast<const void *>(&self_attn_h2_kernel), LDS_REQUEST, done) != IDF_OK) return IDF_E_LAUNCH;
+    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)LDS_REQUEST, s, qkv, T, wo_h2, slabs, pstride);
+    return IDF_OK;
+}
+
+}  // namespace idf_attn_h2

@@ -23,6 +23,7 @@
 #include "ffn.h"
 #include "ffn_h2.h"
 #include "tail_h2.h"
+#include "attn_h2.h"
 
 // the feed-forward block of one layer: arithmetic by tune[IDF_TUNE_FFN_MATH] (and whether the packer set the layer's split-f16 stream),
 // row tile by tune[IDF_TUNE_FFN] (0: by this launch's rows)
@@ -1226,6 +1227,9 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             if (tune[IDF_TUNE_GEMM_OUTPROJ] == 0) {
                 // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's
                 // slab buffer (its previous contents were consumed by the QKV kernel), summed with xn + bo by the row block
+                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] == 5) {      // NOT the default: the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) measured 1.5 % slower over whole samples than the fp32 kernel with two workgroups per CU (profiles/r04_attn_split_f16_ab.txt); MISC = 5 selects it
+                    if (const int rc = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride); rc != IDF_OK) return rc;
+                } else
                 hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256),
                                    attn_lds_bytes(T, ATTN_RT), s, k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);

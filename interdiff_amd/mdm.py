@@ -264,6 +264,22 @@ def sa_out_fragments(w):
     return np.ascontiguousarray(f.transpose(3, 0, 4, 1, 5, 2, 6)).ravel()      # [head][wave][kgroup][tile][kq][li][e]
 
 
+def sa_out_fragments_h2(w):
+    """out_proj.weight [256 out, 256 in] -> the split-f16 attention kernel's out-projection fragments (csrc/attn_h2.h): [head][16 output column tiles]
+    [2 K steps][2 planes][64 lanes][8 halves]; lane (li, kq) of (head, tile ct, step s) holds plane(w[16 ct + li][64 head + 32 s + 8 kq : + 8]).  As float32 words."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (D, D)
+    hi, lo = split_f16(w)
+    out = np.empty((HEADS, 16, 2, 2, 4, 16, 8), np.float16)              # [...][kq][li][8]
+    for h in range(HEADS):
+        for s in range(2):
+            for kq in range(4):
+                k0 = 64 * h + 32 * s + 8 * kq
+                out[h, :, s, 0, kq] = hi[:, k0:k0 + 8].reshape(16, 16, 8)
+                out[h, :, s, 1, kq] = lo[:, k0:k0 + 8].reshape(16, 16, 8)
+    return np.ascontiguousarray(out).view(np.float32).reshape(-1)
+
+
 def pad_ffn_bias(b1):
     """linear1.bias [1024] -> [5 * 208] zero-padded + one spare KiB (the kernel fetches a slice's bias with one 1-KiB DMA)."""
     out = np.zeros(FFN_SLICE_H * _lib.FFN_SLICES + 256, np.float32)
@@ -338,6 +354,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
             ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))
+            ly.sa_out_frag_h2 = ar.add(sa_out_fragments_h2(g(p + 'self_attn.out_proj.weight'))) if np.abs(g(p + 'self_attn.out_proj.weight')).max() < H2_LIMIT else 0
             ly.sa_out_b = ar.add(g(p + 'self_attn.out_proj.bias'))
         cw, cb = g(p + 'multihead_attn.in_proj_weight'), g(p + 'multihead_attn.in_proj_bias')
         ly.ca_q_w, ly.ca_q_b = ar.add(cw[:D]), ar.add(cb[:D])

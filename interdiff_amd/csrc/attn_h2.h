@@ -22,6 +22,11 @@
 #include "common.h"
 #include "ffn_h2.h"
 
+// phase stamps exist only in tools/rowblock_probe.hip (which defines the macro before including this file)
+#ifndef IDF_AH2_STAMP
+#define IDF_AH2_STAMP(i) do { } while (0)
+#endif
+
 namespace idf_attn_h2 {
 
 using idf_ffn_h2::h8;
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     const int nqt = (T + QT - 1) / QT, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT;
     const size_t rowbase = (size_t)b * T;
 
+    IDF_AH2_STAMP(0);
     // ---- operand fetch: everything requested at once with clamped addresses (no guard around a load)
     const int qr = tid >> 4, c4 = (tid & 15) * 4;        // thread (row, 4-float chunk) of a [rows][64] tile
     const float4 qv = *reinterpret_cast<const float4 *>(qkv + (rowbase + min(q0 + qr, T - 1)) * (3 * D) + h * HD + c4);
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
             ak = fmaxf(ak, amax4(kreg[u]));
             av = fmaxf(av, amax4(vreg[u]));
         }
+    IDF_AH2_STAMP(1);                                    // operands landed (the amax code above consumed them)
     aq = wave_max(aq); ak = wave_max(ak); av = wave_max(av);
     if (lane == 0) { red[0][wave] = aq; red[1][wave] = ak; red[2][wave] = av; }
     __syncthreads();
@@ -101,35 +108,48 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     float uq, uk, uv;
     const float dq = pow2_scale(aq, uq), dk = pow2_scale(ak, uk), dv = pow2_scale(av, uv);
 
-    // ---- planes: Q and K row-major [row][dim], V transposed [dim][key] (it is the B operand of P V: a lane's 8 halves run along the keys)
+    // ---- planes: Q and K row-major [row][dim], V transposed [dim][key] (it is the B operand of P V: a lane's 8 halves run along the keys).
+    // The transposition goes through LDS as fp32 (staged in the K region, which K's planes take afterwards): a first version wrote V^T straight from the registers
+    // with 56 two-byte stores per thread into four banks -- 6 k of the launch's 18.6 k cycles (tools/rowblock_probe.hip).
     {
-        uint2 hi, lo;
+        constexpr int VFS = HD + 4;                      // row stride (floats) of the staged V tile: [TP][VFS] floats <= the K region for every T
+        float *Vf = reinterpret_cast<float *>(kh);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = qr + 32 * u;
+            if (32 * u < TP && j < TP)                   // (first condition workgroup-uniform)
+                *reinterpret_cast<float4 *>(Vf + j * VFS + c4) = j < T ? make_float4(vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv) : z;
+        }
+        __syncthreads();
+        for (int g = tid; g < HD * (TPP / 8); g += NTH) {            // (dim, octet of keys): lanes run along the dims, so the strided reads hit 64 different banks
+            const int d = g & (HD - 1), j0 = (g / HD) * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = j0 + e < TP ? Vf[(j0 + e) * VFS + d] : 0.f;       // keys TP .. TPP - 1 are zero: they meet zero probabilities
+            uint2 h0, l0, h1, l1;
+            idf_ffn_h2::split4_pk(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+            idf_ffn_h2::split4_pk(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+            *reinterpret_cast<uint4 *>(vth + d * VTS + j0) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4 *>(vtl + d * VTS + j0) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+        __syncthreads();                                 // the staged tile is consumed: its region becomes the K planes
+        uint2 hi, lo;
         idf_ffn_h2::split4_pk(q0 + qr < T ? make_float4(qv.x * dq, qv.y * dq, qv.z * dq, qv.w * dq) : z, hi, lo);
         *reinterpret_cast<uint2 *>(qh + qr * KHS + c4) = hi;
         *reinterpret_cast<uint2 *>(ql + qr * KHS + c4) = lo;
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             const int j = qr + 32 * u;
-            if (32 * u < TPP) {                          // (workgroup-uniform)
-                const bool live = j < T;
-                if (j < TP) {
-                    idf_ffn_h2::split4_pk(live ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
-                    *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
-                    *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
-                }
-                const float vv[4] = {vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 a, c;
-                    idf_ffn_h2::split1_nf(live ? vv[e] : 0.f, a, c);
-                    vth[(c4 + e) * VTS + j] = a;         // keys T .. TPP - 1 are zero: they meet zero probabilities
-                    vtl[(c4 + e) * VTS + j] = c;
-                }
+            if (32 * u < TP && j < TP) {
+                idf_ffn_h2::split4_pk(j < T ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
+                *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
+                *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
             }
         }
     }
     __syncthreads();
+    IDF_AH2_STAMP(2);                                    // scales + planes in LDS
 
     // ---- S = Q K^T / 8: wave w owns key tiles w, w + 8, ... for both query tiles
     const float sscale = uq * uk * 0.125f;
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
             for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = (am[rt][r] + ac[rt][r] * idf_ffn_h2::LO_UNSCALE) * sscale;
     }
     __syncthreads();
+    IDF_AH2_STAMP(3);                                    // S
 
     // ---- row softmax: one 16-lane group per query row (32 groups = 32 rows); lane l16 owns columns l16, 16 + l16, ...; probabilities leave as planes over K
     {
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
         }
     }
     __syncthreads();
+    IDF_AH2_STAMP(4);                                    // softmax + probability planes
 
     // ---- ctx' = P (V 2^-ev): eight 16 x 16 tiles, one per wave (query tile w >> 2, head-dim tile w & 3); left scaled, split, parked over Q
     {
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
         }
     }
     __syncthreads();
+    IDF_AH2_STAMP(5);                                    // P V + context planes
 
     // ---- out-projection partial of this head: [32 x 64] . [64 x 256]; wave w owns output column tiles 2w, 2w + 1 for both query tiles
     {
@@ -246,6 +269,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
                 }
             }
     }
+    IDF_AH2_STAMP(6);                                    // out-projection + stores issued
 }
 
 inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride) {

@@ -8,6 +8,8 @@ __device__ long long g_rb_stamps[8192 * 16];
 #define IDF_RB_STAMP(i) do { if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
 __device__ long long g_at_stamps[8192 * 8];
 #define IDF_AT_STAMP(i) do { if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); } while (0)
+__device__ long long g_ah2_stamps[8192 * 8];
+#define IDF_AH2_STAMP(i) do { if (threadIdx.x == 0) g_ah2_stamps[blockIdx.x * 8 + (i)] = clock64(); } while (0)
 #include "denoiser.hip"
 #include <algorithm>
 #include <cstdio>
@@ -39,11 +41,13 @@ int main(int argc, char **argv) {
         ly.sa_in_w = take(768 * 256); ly.sa_in_b = take(768); ly.sa_out_w = take(256 * 256); ly.sa_out_b = take(256); ly.sa_out_frag = take(256 * 256);
         ly.qc = take(16 * 3 * 40 * 4); ly.wk = take(64);
         if (h2) { ly.qc_h2 = take(16 * 3 * 40 * 4); ly.rb_h2_ok = 1; }
+        if (h2 == 2) ly.sa_out_frag_h2 = take(256 * 256);
         ly.ca_out_b = take(256);
         ly.ff1_b = take(1024); ly.ff2_b = take(256); ly.ffn_pack = take(5 * 106496); ly.ffn_b1p = take(5 * 208 + 256);
         for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }
     }
-    if (h2) w.tune[IDF_TUNE_FFN_MATH] = 1;        // (no split-f16 FFN / QKV streams are set: those stay exact)
+    if (h2) w.tune[IDF_TUNE_FFN_MATH] = 1;
+    if (h2 == 2) w.tune[IDF_TUNE_MISC] = 5;       // the split-f16 attention kernel (csrc/attn_h2.h)        // (no split-f16 FFN / QKV streams are set: those stay exact)
     if (off > arena_floats) { printf("arena too small\n"); return 1; }
     float *memctx, *x, *x0;
     int64_t *ts;
@@ -89,6 +93,18 @@ int main(int argc, char **argv) {
             for (int i = 1; i < 6; ++i) aa[i] += (double)(sa[(size_t)w * 8 + i] - sa[(size_t)w * 8 + i - 1]);
         printf("self-attention (last launch), %d workgroups; mean cycles per phase:\n", nat);
         for (int i = 1; i < 6; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nat); at += aa[i] / nat; }
+        printf("  total %.0f\n", at);
+    }
+    if (h2 == 2) {
+        const int nw = ((T + 31) / 32) * 4 * B;
+        std::vector<long long> sa((size_t)nw * 8);
+        CK(hipMemcpyFromSymbol(sa.data(), HIP_SYMBOL(g_ah2_stamps), sa.size() * 8));
+        const char *an[7] = {"", "operand fetch", "tile scales + Q / K / V^T planes", "S = Q K^T", "softmax + probability planes", "P V + context planes", "out-projection + stores issued"};
+        double aa[7] = {0}, at = 0;
+        for (int w = 0; w < nw; ++w)
+            for (int i = 1; i < 7; ++i) aa[i] += (double)(sa[(size_t)w * 8 + i] - sa[(size_t)w * 8 + i - 1]);
+        printf("split-f16 self-attention (last launch), %d workgroups; mean cycles per phase:\n", nw);
+        for (int i = 1; i < 7; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nw); at += aa[i] / nw; }
         printf("  total %.0f\n", at);
     }
     return 0;

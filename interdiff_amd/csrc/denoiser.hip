@@ -5,19 +5,21 @@
 // NOT a translation: the reference runs ~40 eager torch kernels per layer over [T,B,D]
 // tensors and re-projects the constant memory every step.  Here
 //   * tokens are clip-major rows (row = b*T + t) of [N,256] fp32 matrices that stay L2-resident,
-//   * EVERY contraction runs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products) --
-//     the six token GEMMs (gemm.h), the temporal self-attention (QK^T and PV), and the whole
-//     "row block" between two FFNs: learned-query local attention, LayerNorms and the cross
-//     attention to the 10-token memory,
+//   * EVERY contraction runs on the matrix pipe.  Exact form: the fp32 MFMA (v_mfma_f32_16x16x4_f32) -- the six token GEMMs (gemm.h), the temporal
+//     self-attention (QK^T and PV), and the whole "row block" between two FFNs: learned-query local attention, LayerNorms and the cross attention to the
+//     10-token memory.  Shipped form (tune[IDF_TUNE_FFN_MATH] = 1, round 4): the feed-forward block, the QKV projection, the row block's contractions and the
+//     two token GEMMs at the ends of a step as split-f16 products on v_mfma_f32_16x16x32_f16 (ffn_h2.h, tail_h2.h: every fp32 operand as two f16 planes, three
+//     MFMAs per product, fp32 accumulate: fp32-grade results); the self-attention stays on the fp32 MFMA (attn_h2.h: its split-f16 form measured slower),
 //   * the learned-query local attention collapses to a [16 x 256] x [256 x 30] contraction with
 //     constant pre-rotated queries Qc (interdiff_amd/mdm.py: qan_constants) + a 3-tap stencil,
 //   * cross-attention to the constant memory is folded per sample into
 //     scores = x.G^T + g0 and out = P.VW (interdiff_mdm_prepare_memory),
 //   * LayerNorm never gets its own launch: the row-block kernel owns whole rows (LN_prev on load,
-//     LN1, LN2 in place) and the QKV / heads GEMMs normalise on load.
-//   * the feed-forward block is ONE launch (ffn.h): linear1 -> gelu -> linear2 per (32-row tile, hidden slice), the hidden
+//     LN1, LN2 in place) and the QKV / heads kernels normalise on load.
+//   * the feed-forward block is ONE launch (ffn.h / ffn_h2.h): linear1 -> gelu -> linear2 per (32-row tile, hidden slice), the hidden
 //     activations never leave the CU; it leaves IDF_FFN_SLICES partial slabs that the next reader sums on load.
-// Per step: 1 embed GEMM + 2 x 5 (standard layers) + 6 x 2 (QaN layers) + 1 heads GEMM = 24 launches.
+// Per step: embedding + 2 x 4 (standard layers: QKV, self-attention + out-projection, row block, FFN) + 6 x 2 (QaN layers: row block, FFN) + heads = 22 launches;
+// 21 inside a captured run of plain steps, where a step's last launch also computes the next step's embedding (tail_h2.h).
 #include "common.h"
 #include "gemm.h"
 #include "ffn.h"

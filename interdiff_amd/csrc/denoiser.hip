@@ -33,7 +33,7 @@ static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, c
     int rows = idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]);
     if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.ffn_pack_h2 != 0) {
         if (rows == 0) rows = idf_ffn::ffn_tile_for_rows(M);
-        return idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows, tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : 0));      // (MISC = 2 / 3: slice-major affine ids / plain ids, A/B only: ffn_h2.h)
+        return idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows, tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : (tune[IDF_TUNE_MISC] == 6 ? 3 : 0)));      // (MISC = 2 / 3 / 6: slice-major affine ids / plain ids / three ring slots, A/B only: ffn_h2.h)
     }
     idf_ffn::launch_ffn(s, x2, M, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows);
     return IDF_OK;

@@ -71,7 +71,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {          // n is a constant 
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     }
 }
 
@@ -141,8 +145,19 @@ __device__ __forceinline__ f2 gelu_fast2(f2 x) {
 
 #define IDF_H2_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0)
 
-// TT = token tiles of 16 rows per workgroup (1, 2, 4 -> BM = 16, 32, 64); S = ring slots (3; 2 for TT = 4, where the planes take 64 KiB).
-// LDS: BM KiB of planes + S x 32 KiB ring + 1 KiB bias = 113 / 129 / 129 KiB.
+// Sixteen consecutive floats at a wave-uniform address into SGPRs through the scalar cache, waited for inside the block.  As inline asm on purpose: a plain load
+// here would be a vector (flat) load whose compiler-inserted wait is `vmcnt(0)` -- the pass cannot see the LDS-DMA stream that is in flight around it.
+typedef float f4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void idf_sload16(const float *p, f4s &a, f4s &b, f4s &c, f4s &d) {
+    p = idf_uniform_ptr(p);
+    asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+                 : "s"(p)
+                 : "memory");
+}
+
+// TT = token tiles of 16 rows per workgroup (1, 2, 4 -> BM = 16, 32, 64); S = ring slots (4; 2 for TT = 4, where the planes take 64 KiB).
+// LDS: BM KiB of planes + S x 32 KiB ring = 144 / 160 / 128 KiB (the launcher asks for all 160 either way: exclusive CU).
 // MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue, 3 = phase stamps of thread 0 behind the slabs, 4 = no slab stores
 // (tools/ffn_h2_probe.hip only; `if constexpr` keeps every trace of them out of MODE 0).
 template <int TT, int S, int MODE = 0>
@@ -150,13 +165,13 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
                                                      const float *__restrict__ b1p, const float *__restrict__ b2,
                                                      float *__restrict__ parts, int order) {
     constexpr int BM = 16 * TT;
-    static_assert((TT == 1 || TT == 2 || TT == 4) && (S == 2 || S == 3), "geometry");
-    static_assert(BM * 1024 + S * SLOT + 1024 <= 160 * 1024, "LDS");
+    static_assert((TT == 1 || TT == 2 || TT == 4) && (S == 2 || S == 3 || S == 4), "geometry");
+    static_assert(BM * 1024 + S * SLOT <= 160 * 1024, "LDS");
     static_assert(TT == 4 ? BM * CSS * 4 <= BM * 1024 + S * SLOT : BM * CSS * 4 <= 2 * SLOT, "output staging");
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     asm volatile("" ::: "v255");                       // the whole register file: see EXCLUSIVE CU below
     float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
-    float *ring = smem + BM * 256, *Bs = ring + S * (SLOT / 4);    // Bs: the slice's linear1 bias (208 floats)
+    float *ring = smem + BM * 256;                  // (the slice's linear1 bias comes through the scalar cache: with four ring slots the planes and the ring are the whole 160 KiB)
     idf_args_now(x2, M, pack, b1p, b2, parts, order, gridDim.x);
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
@@ -199,21 +214,23 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
             else if (8 * j < nins && lt2) idf_dma16_s(stream, vsrc + so + 8192u * j, sdst + dof + 8192u * j);
         }
     };
-    // wait until this wave's DMAs of step P have landed: the steps P + 1 .. P + S - 2 issued behind them may keep flying
+    // wait until this wave's DMAs of step P have landed: the steps P + 1 .. P + S - 2 issued behind them may keep flying (S = 3: one step, S = 4: two)
     auto wait_step = [&](int P) {
-        bool some = false;
+        int flying = 0, ragged = 0;                   // this wave's instructions of the younger steps P + 1 .. P + S - 2 (constants after unrolling)
 #pragma unroll
-        for (int Q = P + 1; Q <= P + S - 2; ++Q) some = some || Q < NPAIR;
-        if constexpr (MODE == 2) some = some && P + 1 < S - 1;
-        if (!some) { wait_vmcnt(0); return; }
-        const int nins = step_ins(P + 1);             // S == 3 here: exactly one younger step
-        if (nins % 8 == 0) wait_vmcnt(nins / 8);
-        else if (lt2) wait_vmcnt(nins / 8 + 1);
-        else wait_vmcnt(nins / 8);
+        for (int Q = P + 1; Q <= P + S - 2; ++Q) {
+            bool live = Q < NPAIR;
+            if constexpr (MODE == 2) live = live && Q < S - 1;
+            if (live) {
+                flying += step_ins(Q) / 8;
+                ragged += step_ins(Q) % 8 != 0 ? 1 : 0;
+            }
+        }
+        if (lt2) wait_vmcnt(flying + ragged);
+        else wait_vmcnt(flying);
     };
 
     // ---- prologue: bias slice, x2 rows (fp32, row r at r KiB, linear), the first S - 1 steps
-    if (wave == 0) idf_dma16_s(idf_uniform_ptr(b1p + sl * HS), lane16, idf_lds_addr(Bs));
     const uint32_t xs_lds = idf_lds_addr(Xs);
 #pragma unroll
     for (int j = 0; j < BM / NW; ++j) {
@@ -222,7 +239,15 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     }
 #pragma unroll
     for (int P = 0; P < S - 1; ++P) issue_step(P);
-    {   // the x2 rows (and the bias) are older than this wave's share of the steps just issued
+    // linear1 bias of this wave's one or two hidden tiles (phase 1 tile map below: 2 w, 2 w + 1 for waves 0..4, else 5 + w): sixteen floats each, through the scalar cache,
+    // behind the DMA issue (the wave is about to wait for its rows anyway); b1p carries 256 spare floats, so the second tile's address is valid for every wave
+    f4s bias_s[2][4];
+    {
+        const int hb = wave < 5 ? 2 * wave : 5 + wave;
+        idf_sload16(b1p + sl * HS + hb * 16, bias_s[0][0], bias_s[0][1], bias_s[0][2], bias_s[0][3]);
+        idf_sload16(b1p + sl * HS + (hb + 1) * 16, bias_s[1][0], bias_s[1][1], bias_s[1][2], bias_s[1][3]);
+    }
+    {   // the x2 rows are older than this wave's share of the steps just issued
         int younger = 0;
 #pragma unroll
         for (int P = 0; P < S - 1; ++P) younger += step_ins(P) / 8;         // + 1 for waves 0, 1 per ragged step
@@ -337,7 +362,8 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         if (a == 0 || two1) {
-            const float4 bv = *reinterpret_cast<const float4 *>(Bs + (h0 + a) * 16 + 4 * g);
+            const f4s bsel = g == 0 ? bias_s[a][0] : (g == 1 ? bias_s[a][1] : (g == 2 ? bias_s[a][2] : bias_s[a][3]));      // lane group g takes hidden units 4 g .. 4 g + 3 of the tile
+            const float4 bv = make_float4(bsel[0], bsel[1], bsel[2], bsel[3]);
             const int chunk = 2 * (h0 + a) + (g >> 1);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
@@ -432,10 +458,14 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 // it asks for the whole 160 KiB of LDS and for 256 VGPRs per wave (2 waves per SIMD x 256 = the register file), so that no other
 // workgroup can be resident next to it -- 0 differences in the same probe.  It costs nothing: the grid is one workgroup per CU by design.
 constexpr int LDS_REQUEST = 160 * 1024;
+#ifndef IDF_FFN_H2_SLOTS
+#define IDF_FFN_H2_SLOTS 4
+#endif
+constexpr int FFN_H2_SLOTS = IDF_FFN_H2_SLOTS;            // ring slots of the 16- and 32-row kernels: 4 = planes + ring fill the CU's LDS exactly (3: rounds 4a; -D for A/B)
 template <int TT, int S>
 inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int order) {
     constexpr int BM = 16 * TT;
-    static_assert(BM * 1024 + S * SLOT + 1024 <= LDS_REQUEST, "LDS");
+    static_assert(BM * 1024 + S * SLOT <= LDS_REQUEST, "LDS");
     static std::atomic<uint64_t> done{0};
     const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS_REQUEST, done);
     if (rc != IDF_OK) return rc;
@@ -443,10 +473,16 @@ inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack
     return IDF_OK;
 }
 // rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits
+// order 3 (A/B only): XCD-affine M-tile-major ids like order 0, with the THREE-slot ring of the round's first builds
 inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int rows, int order) {
-    if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts, order);
+    if (order == 3) {
+        if (rows == 16) return launch_h2_tt<1, 3>(s, x2, M, pack, b1p, b2, parts, 0);
+        if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts, 0);
+        return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts, 0);
+    }
+    if (rows == 16) return launch_h2_tt<1, FFN_H2_SLOTS>(s, x2, M, pack, b1p, b2, parts, order);
     if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts, order);
-    return launch_h2_tt<2, 3>(s, x2, M, pack, b1p, b2, parts, order);
+    return launch_h2_tt<2, FFN_H2_SLOTS>(s, x2, M, pack, b1p, b2, parts, order);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

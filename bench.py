@@ -47,7 +47,7 @@ FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0                               # MI355X_MICROARCH.md: f16 / bf16 MFMA, dense
-DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r04b'       # the build the roofline block (and profiles/traffic.json) speaks about
+DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r04c'       # the build the roofline block (and profiles/traffic.json) speaks about
 ROCPROF_STATS = 'profiles/r04_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r04.sh)
 
 

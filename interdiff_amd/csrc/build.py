@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, 'libinterdiff_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-Wno-inline-asm']        # the asm LDS-DMA names m0 as a clobber on purpose (csrc/common.h idf_dma16_*)
+FLAGS += os.environ.get('IDF_EXTRA_HIPCC_FLAGS', '').split()      # A/B builds (e.g. -DIDF_WT_MODE=2); empty for the product
 
 
 def sources():

@@ -70,15 +70,25 @@ __device__ __forceinline__ void idf_dma16_v(const float *gptr, uint32_t lds_base
 // the flush off the kernel boundary (MI355X_MICROARCH.md: a boundary costs + bytes-left-dirty / 6 TB/s) and overlaps it with the
 // rest of the launch.  Invisible to the compiler's vmcnt bookkeeping like every asm memory op: only for data this kernel never
 // reads back.
+#ifndef IDF_WT_MODE
+#define IDF_WT_MODE 0             // 0: system-scope write-through (shipped); 1: agent scope (sc1); 2: plain stores -- A/B builds only (tools/wt_mode_ab.sh)
+#endif
+#if IDF_WT_MODE == 0
+#define IDF_WT_BITS " sc0 sc1"
+#elif IDF_WT_MODE == 1
+#define IDF_WT_BITS " sc1"
+#else
+#define IDF_WT_BITS ""
+#endif
 __device__ __forceinline__ void idf_store4_wt(float *p, const float v) {
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dword %0, %1, off" IDF_WT_BITS ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void idf_store16_wt(float *p, const float4 v) {
     const f32x4 t = {v.x, v.y, v.z, v.w};
     // s_nop: a store of more than 64 bits reads its data registers AFTER issue -- a VALU write to them needs wait states in
     // between.  The compiler's hazard recognizer pads its own stores; it cannot see into this asm (tools/lnlin_probe.hip caught
     // the next loop iteration's index landing in .x of ~0.1 % of the stores).
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" IDF_WT_BITS "\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
 // Kernel arguments live in the kernarg segment and reach SGPRs by s_load; the compiler sinks each s_load (+ s_waitcnt) next to its

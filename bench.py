@@ -47,8 +47,41 @@ FLOP_PER_TOKEN = 11978752 + 2048 * T
 FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 of one layer: what ONE launch of the fused kernel computes
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0                               # MI355X_MICROARCH.md: f16 / bf16 MFMA, dense
-DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r04c'       # the build the roofline block (and profiles/traffic.json) speaks about
-ROCPROF_STATS = 'profiles/r04_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r04.sh)
+MALL_STREAM_TBPS = 12 * 256 * 2.4e9 / 1e12                  # Infinity-Cache-resident private streams: 12 B/clk/CU measured (tools/dma_ceiling.hip, profiles/r02_dma_ceiling.txt) = 7.4 TB/s
+DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r05'        # the build the roofline block (and profiles/traffic.json) speaks about
+ROCPROF_STATS = 'profiles/r05_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r05.sh)
+
+
+def ffn_issued_f16_flop(rows, tile):
+    """f16 FLOP the split-f16 feed-forward kernel ISSUES for one launch over `rows` token rows with `tile`-row workgroups (csrc/ffn_h2.h): per workgroup
+    (13 hidden tiles x 8 K steps + 16 output tiles x 7 K steps) x tile/16 token tiles x 3 products, each one v_mfma_f32_16x16x32_f16 = 16 384 FLOP;
+    ceil(rows / tile) x 5 slices workgroups.  324 000 MFMAs at 1600 rows = SQ_VALU_MFMA_BUSY_CYCLES / 16 of the PMC pass (profiles/)."""
+    wgs = -(-rows // tile) * 5
+    return wgs * (13 * 8 + 16 * 7) * (tile // 16) * 3 * 16384
+
+
+def EXECUTED_FLOP_PER_TOKEN(T):
+    """What the kernels really contract per token and step: the cross-attention to the constant memory is folded per sample (x.G^T, P.VW instead of the q / out
+    projections), so ~16 % less than SURVEY.md's count of the reference's own GEMMs."""
+    ffn = 8 * 2 * 2 * 256 * 1024
+    qkv, attn, outp = 2 * 2 * 256 * 768, 2 * 2 * 2 * T * 256, 2 * 2 * 256 * 256
+    qan, cross = 6 * 2 * 256 * 30, 8 * (2 * 256 * 40 + 2 * 40 * 256)
+    ends = 2 * 2 * 144 * 256
+    return ffn + qkv + attn + outp + qan + cross + ends
+
+
+def STEP_WEIGHT_BYTES(B):
+    """Bytes of weights and per-sample constants one step reads (each at least once): feed-forward plane streams, QKV planes, out-projection fragments,
+    learned queries, step-tail fragments, and the folded memory G / VW of every (layer, clip) as plane fragments + g0."""
+    ffn, qkv, outp = 8 * 5 * 442368, 2 * 5 * 163840, 2 * 262144
+    qc, tail = 6 * 30720, (36864 + 40960) * 4
+    mem = 8 * B * ((12288 + 16384) * 4 + 160)
+    return ffn + qkv + outp + qc + tail + mem
+
+
+def STEP_ACTIVATION_BYTES(rows):
+    """Kernel-to-kernel hand-overs of one chained plain step, each written once and read once: 19 x [rows,256] fp32 + the two QKV matrices [rows,768]."""
+    return 2 * (19 * rows * 256 * 4 + 2 * rows * 768 * 4)
 
 
 def tt(d, dev=None):
@@ -545,57 +578,109 @@ def main():
         split = getattr(model, 'ffn_math', 'exact') == 'split'
         dom = 'ffn_fused'
         us = dom_us
-        flops = FFN_FLOP_PER_TOKEN * B_PER_GPU * T
-        ach = flops / (us * 1e-6) / 1e12
+        rows = B_PER_GPU * T
+        flops = FFN_FLOP_PER_TOKEN * rows                     # algorithmic fp32 FLOP of one launch (1 048 576 per token)
         traffic, traffic_src = None, None
         recorded = None                                      # RECORDED, not measured by this run: the committed rocprofv3 summary of this same command
+        tj = {}
         try:
             tf = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 if tj.get('kernel_id') == DOMINANT_KERNEL_ID:      # a PMC figure is only valid for the kernel build it was taken on
                     traffic, traffic_src = tj.get(dom), tj.get('_how')
-                    r_ = tj.get('rocprofv3_in_situ_us')
-                    if r_:
-                        recorded = dict(us_per_launch=r_, frac=flops / (r_ * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, recorded_not_measured=True, source=ROCPROF_STATS)
+                else:
+                    tj = {}
         except Exception as e:                               # a stale or reformatted profile must never take the measurement down
-            traffic_src = 'profiles/traffic.json unreadable: %r' % (e,)
-        stream_bytes = 5 * 442368 if split else 5 * 425984   # packed weight stream of one layer (what every XCD pulls through its L2 once per launch)
-        line['roofline'] = dict(
-            bound='mfma', kernel=dom, kernel_id=DOMINANT_KERNEL_ID, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
-            traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
-            rocprofv3_in_situ=recorded,
-            peak_note='achieved = ALGORITHMIC fp32 FLOP of the block (2 x 2*M*256*1024) / measured duration; peak = the fp32-input MFMA peak, the roof an fp32 '
-                      'contraction has on this chip (no TF32 path).  The shipped kernel does the arithmetic as 3 f16 MFMAs per product (fp32-grade, csrc/ffn_h2.h), '
-                      'so its matrix pipe is nearly idle (see issued_f16_mfma) and what it waits for is its weight stream (see weight_stream): frac measures how close the '
-                      'BLOCK is to the fp32 roof, not how busy the pipe is' if split else None,
-            issued_f16_mfma=dict(achieved=3 * ach, peak=PEAK_F16_MFMA_TFLOPS, unit='TFLOP/s', frac=3 * ach / PEAK_F16_MFMA_TFLOPS,
-                                 note='what the kernel really issues: three v_mfma_f32_16x16x32_f16 per 32 k of every output tile') if split else None,
-            weight_stream=dict(bytes_per_workgroup=stream_bytes // 5, bytes_per_layer=stream_bytes, gb_per_s_per_cu=(stream_bytes // 5) / (us * 1e-6) / 1e9,
-                               note='every workgroup streams its slice of the packed weights (LDS-DMA, ring of 32-KiB slots) once per launch: the kernel\'s critical resource once the MFMAs cost 1/43'),
-            exact_fp32_kernel=dict(us_per_launch=exact_us, achieved=flops / (exact_us * 1e-6) / 1e12, frac=flops / (exact_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   denoiser_forward_us=exact_fwd_us, kernel='idf_ffn::ffn_fused_kernel (v_mfma_f32_16x16x4_f32; csrc/ffn.h), selectable with MDM.ffn_math = "exact" / INTERDIFF_FFN_MATH=exact',
-                                   note='same measurement recipe, same process') if exact_us else None,
-            one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=flops / (burst_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                 note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic; secondary'),
-            two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                note='NOT the route of this shape since the split-f16 kernel (one chain up to 1632 rows, MDM.one_chain_max_rows); kept for comparison: '
-                                     'the two-chain form runs the same layer as two concurrent launches at M=%d, timed as two such chains of back-to-back '
-                                     'launches (same FLOP per pair as one launch at M=%d)' % (B_PER_GPU * T // 2, B_PER_GPU * T)),
-            small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best,
-                                         frac=flops * 800 / (B_PER_GPU * T) / (small_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                         note='the 16-row tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU)'),
-            large_batch_64_row_tile=dict(rows=3200, us_per_launch=big_us, us_per_launch_best=big_best,
-                                         frac=flops * 3200 / (B_PER_GPU * T) / (big_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                         note='the 64-row tile BASELINE config #3 (32 clips of 100 frames) takes'),
-            traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
-            note='one launch = linear1 + gelu + linear2 of a layer at M=%d; 8 of the 22 launches of a denoiser forward; duration = mean of three bursts of '
-                 '192 launches replayed from a hipGraph that walk through the eight layers\' weight streams and alternate activation buffers like a '
-                 'denoiser step (every weight stream from the Infinity Cache), HIP events on the launch stream; the rocprofv3 in-situ average of the same '
-                 'command is committed under profiles/ (rocprofv3_in_situ, recorded)' % (B_PER_GPU * T))
+            traffic_src, tj = 'profiles/traffic.json unreadable: %r' % (e,), {}
+        if split:
+            # The shipped kernel issues v_mfma_f32_16x16x32_f16 (three per product): its matrix roof is the f16 dense peak, and what it is priced with is the
+            # f16 FLOP it ISSUES (zero-padded hidden units / K steps included: they occupy the pipe like the rest) -- not the fp32-equivalent work, which
+            # would be priced against a pipe this kernel no longer uses.
+            issued = ffn_issued_f16_flop(rows, 32)
+            ach = issued / (us * 1e-6) / 1e12
+            peak = PEAK_F16_MFMA_TFLOPS
+            frac_of = lambda rows_, tile_, us_: ffn_issued_f16_flop(rows_, tile_) / (us_ * 1e-6) / 1e12 / PEAK_F16_MFMA_TFLOPS
+            r_ = tj.get('rocprofv3_in_situ_us')
+            if r_:
+                recorded = dict(us_per_launch=r_, achieved=issued / (r_ * 1e-6) / 1e12, frac=issued / (r_ * 1e-6) / 1e12 / peak, recorded_not_measured=True, source=ROCPROF_STATS)
+            stream_bytes = 5 * 442368                        # packed weight stream of one layer (what every XCD pulls through its L2 once per launch)
+            eq = flops / (us * 1e-6) / 1e12
+            line['roofline'] = dict(
+                bound='mfma', kernel=dom, kernel_id=DOMINANT_KERNEL_ID, achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
+                traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, issued_f16_flop_per_launch=issued, issued_f16_mfma_per_launch=issued // 16384,
+                algorithmic_flop_per_launch=flops, rocprofv3_in_situ=recorded,
+                peak_note='the kernel issues v_mfma_f32_16x16x32_f16 -- three per fp32-grade product (csrc/ffn_h2.h) -- so achieved = f16 FLOP ISSUED per launch (324 000 MFMAs x 16 384 at '
+                          'M = 1600, zero padding included) / measured duration and peak = the f16 dense MFMA peak (MI355X_MICROARCH.md).  frac is also the share of the launch during which '
+                          'the matrix pipes issue (an MFMA of this shape holds its SIMD 16 cycles: 324 000 x 16 / 1024 SIMDs = 5.06 k cycles = 2.1 us)',
+                mfma_busy_share=dict(analytic=ach / peak, recorded_pmc=tj.get('mfma_busy_share'), target_of_round_5=0.25,
+                                     note='SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x launch cycles); analytic = issued MFMAs x 16 cycles over the same denominator'),
+                binding_resource=dict(what='the LDS-DMA weight stream (every workgroup pulls its slice\'s 432 KiB from its XCD\'s L2 at the ~50 B/clk a CU reaches) plus fixed phases outside the K loops '
+                                           '(row fetch + split, GELU + split, staging, the 8-MB slab store burst): DESIGN.md 4.2 phase stamps',
+                                      weight_stream_bytes_per_workgroup=stream_bytes // 5, weight_stream_bytes_per_layer=stream_bytes,
+                                      weight_stream_gb_per_s_per_cu=(stream_bytes // 5) / (us * 1e-6) / 1e9,
+                                      l2_fed_dma_ceiling_gb_per_s_per_cu=50 * 2.4, note='ceiling: tools/dma_ceiling.hip (profiles/r02_dma_ceiling.txt), ~50 B/clk/CU at 2.4 GHz'),
+                fp32_equivalent=dict(achieved_tflops=eq, f32_mfma_peak_tflops=PEAK_F32_MFMA_TFLOPS, split_f16_roof_tflops=PEAK_F16_MFMA_TFLOPS / 3,
+                                     frac_of_split_f16_roof=eq / (PEAK_F16_MFMA_TFLOPS / 3),
+                                     note='the block\'s ALGORITHMIC fp32 FLOP (2 x 2*M*256*1024) / duration, priced against the roof an fp32-grade product has on the f16 pipe '
+                                          '(f16 dense peak / 3 products).  The fp32-input MFMA peak is listed for orientation only: the arithmetic left that pipe, so a ratio to it is not a roofline fraction'),
+                exact_fp32_kernel=dict(us_per_launch=exact_us, bound='mfma', achieved=flops / (exact_us * 1e-6) / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                                       frac=flops / (exact_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, denoiser_forward_us=exact_fwd_us,
+                                       kernel='idf_ffn::ffn_fused_kernel (v_mfma_f32_16x16x4_f32; csrc/ffn.h), selectable with MDM.ffn_math = "exact" / INTERDIFF_FFN_MATH=exact',
+                                       note='same measurement recipe, same process; this kernel DOES issue the fp32-input MFMA, so its roof is that peak') if exact_us else None,
+                one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=frac_of(rows, 32, burst_us),
+                                     note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic; secondary'),
+                two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=2 * ffn_issued_f16_flop(rows // 2, 32) / (pair_us * 1e-6) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                    note='NOT the route of this shape (one chain up to one round of workgroups, MDM.one_chain_max_rows); kept for comparison: '
+                                         'the same layer as two concurrent launches at M=%d on two graph branches' % (rows // 2)),
+                small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best, frac=frac_of(800, 16, small_us),
+                                             note='the 16-row tile batches of <= 800 token rows take (8 clips of 100 frames = BASELINE config #4\'s share of a GPU)'),
+                large_batch_64_row_tile=dict(rows=3200, us_per_launch=big_us, us_per_launch_best=big_best, frac=frac_of(3200, 64, big_us),
+                                             note='the 64-row tile BASELINE config #3 (32 clips of 100 frames) takes'),
+                traffic_source=traffic_src or 'null: profiles/traffic.json holds no rocprofv3 FETCH_SIZE/WRITE_SIZE passes for this kernel build',
+                traffic_vs_algorithmic=dict(algorithmic_bytes=5493824, note='x2 1.64 MB + packed weight planes 2.21 MB + output 1.64 MB; the design writes the output as five partial slabs (8.19 MB) '
+                                                                          'and every XCD pulls the weight stream into its own L2 once (8 x 2.2 MB)') if traffic else None,
+                note='one launch = linear1 + gelu + linear2 of a layer at M=%d; 8 of the 21 launches of a chained plain step; duration = mean of three bursts of '
+                     '192 launches replayed from a hipGraph that walk through the eight layers\' weight streams and alternate activation buffers like a '
+                     'denoiser step (every weight stream from the Infinity Cache), HIP events on the launch stream; the rocprofv3 in-situ average of the same '
+                     'command is committed under profiles/ (rocprofv3_in_situ, recorded)' % rows)
+        else:
+            ach = flops / (us * 1e-6) / 1e12
+            line['roofline'] = dict(bound='mfma', kernel=dom, kernel_id='idf_ffn::ffn_fused_kernel (exact fp32 MFMA selected)', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, us_per_launch=us, us_per_launch_best=dom_best, algorithmic_flop_per_launch=flops,
+                                    note='exact-fp32 arithmetic selected (INTERDIFF_FFN_MATH=exact): v_mfma_f32_16x16x4_f32, priced against the fp32-input MFMA peak')
+        # the whole step against the chip: what the matrix pipes and the memory system would need for one step's algorithmic work, next to what a step takes
+        step_us = 1e6 * wall / STEPS
+        alg_flop = FLOP_PER_TOKEN * rows
+        exe_flop = EXECUTED_FLOP_PER_TOKEN(T) * rows
+        matrix_roof = PEAK_F16_MFMA_TFLOPS / 3 if split else PEAK_F32_MFMA_TFLOPS
+        w_bytes = STEP_WEIGHT_BYTES(B_PER_GPU)
+        a_bytes = STEP_ACTIVATION_BYTES(rows)
+        mem_us = (w_bytes + a_bytes) / MALL_STREAM_TBPS / 1e6
+        mat_us = alg_flop / matrix_roof / 1e6
+        line['step_roofline'] = dict(
+            us_per_step=step_us, algorithmic_flop_per_step=alg_flop, executed_flop_per_step=exe_flop,
+            matrix_roof=dict(tflops=matrix_roof, us=mat_us, frac_of_step=mat_us / step_us,
+                             note='algorithmic FLOP of one step (SURVEY.md 8(d): 11 978 752 + 2048 T per token) / the fp32-grade roof of the f16 pipe (f16 dense peak / 3 products)' if split else
+                                  'algorithmic FLOP of one step / the fp32-input MFMA peak'),
+            memory_roof=dict(weight_and_constant_bytes=w_bytes, activation_handover_bytes=a_bytes, stream_tb_per_s=MALL_STREAM_TBPS, us=mem_us, frac_of_step=mem_us / step_us,
+                             note='bytes every step must move at least once: the packed weights + per-sample folded memory (read once per step, Infinity-Cache resident) and every '
+                                  'kernel-to-kernel hand-over written once and read once ([M,256] fp32 rows; QKV 3x); rate = the Infinity-Cache stream rate measured for private streams '
+                                  '(tools/dma_ceiling.hip: 12 B/clk/CU x 256 CUs x 2.4 GHz)'),
+            frac=max(mat_us, mem_us) / step_us,
+            gap_note='a step takes %.1fx its binding roof: 21 strictly dependent launches (~1.7 us boundary each), each a fetch -> compute -> store latency chain on <= 250 workgroups, plus the '
+                     'amortised hook (11 corrected steps per 1000); DESIGN.md 4' % (step_us / max(mat_us, mem_us)))
+        line['arithmetic_by_layer'] = model.arithmetic_report() if hasattr(model, 'arithmetic_report') else None
+        try:
+            txt, bad = _lib.exclusive_cu_report()
+            line['exclusive_cu'] = dict(kernels_not_exclusive=bad, table=txt.strip().split('\n'),
+                                        note='every kernel that issues the f16 MFMA must own its CU (verified at launch: occupancy query == 1, LDS == 160 KiB, >= 256 registers); a kernel that fails runs as its fp32 counterpart')
+        except Exception as e:
+            line['exclusive_cu'] = dict(error=repr(e))
         fl = FLOP_PER_TOKEN * B_PER_GPU * T
         line['denoiser_forward'] = dict(us=fwd_us, achieved_tflops=fl / (fwd_us * 1e-6) / 1e12,
-                                        frac_of_f32_mfma_peak=fl / (fwd_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, launches=22,
+                                        frac_of_matrix_roof=fl / (fwd_us * 1e-6) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3 if split else PEAK_F32_MFMA_TFLOPS),
+                                        matrix_roof_tflops=(PEAK_F16_MFMA_TFLOPS / 3 if split else PEAK_F32_MFMA_TFLOPS), launches=22,
                                         how='MDM.forward (22 launches, B=%d T=%d) replayed from a hipGraph, HIP events on its stream' % (B_PER_GPU, T))
         line['kernels_us_event_to_event'] = {k: round(v['us_avg'], 2) for k, v in prof.items()}    # includes the launch gap + event records
     line['conditioning_ms_per_sample'] = enc_ms        # MDM._get_embeddings, outside the timed region (once per 1000 steps)

@@ -175,6 +175,9 @@ typedef struct {
     /* split-f16 plane fragments of the two token GEMMs at the ends of a step (csrc/tail_h2.h; mdm.py pack_tail_h2), 0 = not packed (token width != 144
      * or a value outside the f16 range): out_w as [9 output tiles][8 K steps][2 planes][64 lanes][8 halves], in_w as [16][5][2][64][8] (K = 144 padded to 160) */
     int64_t out_w_h2, in_w_h2;
+    /* 1 when the packer has proved that the heads GEMM's A operand -- LayerNorm norm3 of the LAST decoder layer -- stays inside the f16 range
+     * (mdm.py ln_h2_range_ok on its gamma / beta); 0: the step tail keeps the fp32 token GEMMs (and interdiff_mdm_forward_step_ex ignores its flags) */
+    int64_t tail_h2_ok;
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
@@ -298,6 +301,12 @@ int interdiff_mdm_forward_step_ex(const idf_mdm_weights *w, const float *memctx,
                                   const float *gt, const uint8_t *mask, const float *table, int64_t *state, void *ws,
                                   size_t ws_bytes, int32_t flags, void *stream);
 int interdiff_mdm_step_chaining(const idf_mdm_weights *w);
+/* Every kernel of the library that issues the f16 MFMA claims its CU for itself (all 160 KiB of LDS, the whole register file: DESIGN.md "exclusive CU");
+ * since round 5 each launcher VERIFIES that on the device it launches on -- occupancy query == 1, static + dynamic LDS == 160 KiB, >= 256 registers
+ * allocated -- and a kernel that does not pass runs as its fp32-MFMA counterpart instead (same results to rounding; the choice is per device and
+ * process-stable, so every route of one process computes the same bits).  This entry forces the check for every such kernel on the current device,
+ * writes one text line per kernel into buf (<= cap bytes, NUL-terminated) and returns how many do NOT pass (0 on MI355X), or a negative IDF_E_*. */
+int interdiff_exclusive_cu_report(char *buf, int32_t cap);
 
 /* ------------------------------------------------------------------------------------
  * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,

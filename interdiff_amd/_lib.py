@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -38,7 +38,7 @@ class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
                 ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
-                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64)]
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64), ('tail_h2_ok', i64)]
 
 
 class PnMlp(C.Structure):
@@ -125,6 +125,7 @@ _SIGS = {
     'interdiff_optimize_finish': (C.c_int, [C.POINTER(OptCtx), C.POINTER(OptState), vp, vp, vp, vp, vp]),
     'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
     'interdiff_debug_lds_sentinel': (C.c_int, [vp, i32, i32, vp]),
+    'interdiff_exclusive_cu_report': (C.c_int, [C.c_char_p, i32]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -157,6 +158,16 @@ def load():
         raise HipLibraryMissing('stale %s: abi %d != %d, rebuild' % (LIB_PATH, lib.interdiff_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def exclusive_cu_report():
+    """(text table, number of f16-MFMA kernels that do NOT get their CU to themselves on the current device) -- include/interdiff_hip.h
+    interdiff_exclusive_cu_report; kernels that fail run as their fp32-MFMA counterparts."""
+    buf = C.create_string_buffer(8192)
+    bad = load().interdiff_exclusive_cu_report(buf, len(buf))
+    if bad < 0:
+        check(bad, 'exclusive_cu_report')
+    return buf.value.decode(), bad
 
 
 def exported_symbols():

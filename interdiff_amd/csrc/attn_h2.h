@@ -273,11 +273,11 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
 }
 
 inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride) {
-    static std::atomic<uint64_t> done{0};
-    constexpr int LDS_REQUEST = 160 * 1024 - 256;        // the whole CU's LDS minus the kernel's static words (exclusive CU)
-    if (T > MAX_T || (int)lds_bytes(T) > LDS_REQUEST) return IDF_E_INVAL;
-    if (idf_opt_in_lds(reinterpret_cast<const void *>(&self_attn_h2_kernel), LDS_REQUEST, done) != IDF_OK) return IDF_E_LAUNCH;
-    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)LDS_REQUEST, s, qkv, T, wo_h2, slabs, pstride);
+    static idf_excl_cache excl;
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
+    if (dyn < 0) return IDF_NOT_EXCLUSIVE;
+    if (T > MAX_T || (int)lds_bytes(T) > dyn) return IDF_E_INVAL;
+    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, wo_h2, slabs, pstride);
     return IDF_OK;
 }
 

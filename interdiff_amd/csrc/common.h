@@ -34,6 +34,57 @@ static inline int idf_opt_in_lds(const void *fn, int bytes, std::atomic<uint64_t
     return IDF_OK;
 }
 
+// ---- EXCLUSIVE CU, verified (round 5) ------------------------------------------------------------------------------------------
+// Every kernel of this library that issues the f16 MFMA claims its CU for itself (ffn_h2.h "EXCLUSIVE CU": next to such a kernel, waves of OTHER kernels on
+// the same CU have been seen to compute wrong values): all 160 KiB of LDS (static + the dynamic bytes its launcher adds) and the whole register file
+// (asm clobbers v255 / a255).  That used to be a property nobody checked.  idf_exclusive_cu() asks the runtime, once per (kernel, device):
+//   * hipOccupancyMaxActiveBlocksPerMultiprocessor(kernel, threads, dyn) == 1            -- no second workgroup of the same kernel,
+//   * static + dynamic LDS == 160 KiB                                                     -- no LDS-using workgroup of any other kernel,
+//   * the compiler really allocated >= 256 registers per lane (hipFuncAttributes.numRegs) -- with threads / 256 waves per SIMD no LDS-free wave fits either
+// and returns the dynamic LDS to launch with, or -1: the caller then takes its fp32-MFMA kernel instead (csrc/denoiser.hip) -- a configuration where
+// the claim does not hold (LDS partitioning, a compiler that stops honouring the clobber) degrades to the exact arithmetic, never to an unprotected launch
+// and never to IDF_E_LAUNCH.  Every verdict is kept in a table that interdiff_exclusive_cu_report() prints (tests, bench.py).
+struct idf_excl_entry {
+    const char *name;
+    int threads, num_regs, static_lds, dyn_lds, blocks_per_cu, ok, dev;
+};
+int idf_excl_report(char *buf, int cap);                // prof.hip: the table as text, returns the number of non-exclusive rows
+void idf_excl_record(const idf_excl_entry &e);          // prof.hip (one table per process, mutex inside; not on any hot path: once per kernel and device)
+struct idf_excl_cache {
+    std::atomic<uint64_t> yes{0}, no{0};
+    std::atomic<int> dyn{-1};
+};
+constexpr int IDF_CU_LDS_BYTES = 160 * 1024;
+constexpr int IDF_NOT_EXCLUSIVE = 1;                    // internal (positive) return of the split-f16 launchers: "take the fp32 kernel"
+static inline int idf_exclusive_cu(const void *fn, const char *name, int threads, idf_excl_cache &c) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (c.yes.load(std::memory_order_acquire) & bit) return c.dyn.load(std::memory_order_acquire);
+    if (c.no.load(std::memory_order_acquire) & bit) return -1;
+    idf_excl_entry e{name, threads, -1, -1, -1, -1, 0, dev};
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, fn) == hipSuccess) {
+        e.num_regs = at.numRegs;
+        e.static_lds = (int)at.sharedSizeBytes;
+        e.dyn_lds = IDF_CU_LDS_BYTES - e.static_lds;
+        if (e.dyn_lds >= 0 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.dyn_lds) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&e.blocks_per_cu, fn, threads, (size_t)e.dyn_lds) == hipSuccess)
+            e.ok = e.blocks_per_cu == 1 && e.num_regs >= 256 ? 1 : 0;
+    }
+    (void)hipGetLastError();                             // a refused attribute must not surface as the next launch's error
+    idf_excl_record(e);
+    if (e.ok) {
+        c.dyn.store(e.dyn_lds, std::memory_order_release);
+        c.yes.fetch_or(bit, std::memory_order_release);
+        return e.dyn_lds;
+    }
+    c.no.fetch_or(bit, std::memory_order_release);
+    fprintf(stderr, "interdiff_hip: %s does not get its CU to itself on device %d (regs %d, LDS %d + %d, %d workgroups per CU): the fp32-MFMA kernel runs instead\n",
+            name, dev, e.num_regs, e.static_lds, e.dyn_lds, e.blocks_per_cu);
+    return -1;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- LDS-DMA (global -> LDS without a VGPR round trip) as INLINE ASM ----------------------------------------------------------

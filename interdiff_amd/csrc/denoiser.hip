@@ -32,8 +32,8 @@
 static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, const float *ar, const int32_t *tune, const float *x2, int M, float *parts) {
     int rows = idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]);
     if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.ffn_pack_h2 != 0) {
-        if (rows == 0) rows = idf_ffn::ffn_tile_for_rows(M);
-        return idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows, tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : (tune[IDF_TUNE_MISC] == 6 ? 3 : 0)));      // (MISC = 2 / 3 / 6: slice-major affine ids / plain ids / three ring slots, A/B only: ffn_h2.h)
+        const int rc = idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows ? rows : idf_ffn::ffn_tile_for_rows(M), tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : (tune[IDF_TUNE_MISC] == 6 ? 3 : 0)));      // (MISC = 2 / 3 / 6: slice-major affine ids / plain ids / three ring slots, A/B only: ffn_h2.h)
+        if (rc != IDF_NOT_EXCLUSIVE) return rc;        // (the kernel does not get its CU on this device -- common.h idf_exclusive_cu: the exact kernel below)
     }
     idf_ffn::launch_ffn(s, x2, M, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows);
     return IDF_OK;
@@ -958,9 +958,9 @@ int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, 
             int step_B = 0, const float *pack_h2 = nullptr) {
     if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return IDF_OK; }
     if (pack_h2) {
-        if (np == NSL)
-            return idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
-        return idf_ffn_h2::launch_ln_linear_h2<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+        const int rc = np == NSL ? idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B)
+                                 : idf_ffn_h2::launch_ln_linear_h2<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
+        if (rc != IDF_NOT_EXCLUSIVE) return rc;        // (not exclusive on this device: the fp32 kernel below)
     }
     if (np == NSL)
         idf_ffn::launch_ln_linear<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B);
@@ -1115,18 +1115,15 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
 }
 
 namespace {
-// dynamic LDS that tops a split-f16 row block's static LDS up to the CU's whole 160 KiB (exclusive CU, see the kernel); per (kernel, device) opt-in
-template <typename KernelT>
-int rb_h2_fill_lds(KernelT kernel, std::atomic<uint64_t> &done, std::atomic<int> &dyn_bytes) {
-    int dyn = dyn_bytes.load(std::memory_order_acquire);
-    if (dyn < 0) {
-        hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kernel)) != hipSuccess) return -1;
-        dyn = 160 * 1024 - (int)at.sharedSizeBytes;
-        if (dyn < 0) return -1;
-        dyn_bytes.store(dyn, std::memory_order_release);
-    }
-    return idf_opt_in_lds(reinterpret_cast<const void *>(kernel), dyn, done) == IDF_OK ? dyn : -1;
+// dynamic LDS that tops a split-f16 row block's static LDS up to the CU's whole 160 KiB (exclusive CU, see the kernel), verified per (kernel, device):
+// -1 = the kernel does not get its CU there (common.h idf_exclusive_cu) and the caller launches the fp32 row block
+int rb_h2_qan_dyn() {
+    static idf_excl_cache excl;
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<true, true, NSL, true>), "rowblock_kernel<QaN, split-f16>", 256, excl);
+}
+int rb_h2_std_dyn() {
+    static idf_excl_cache excl;
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<false, true, H, true>), "rowblock_kernel<std, split-f16>", 256, excl);
 }
 
 // the sampler-step operands of interdiff_mdm_forward_step (null x: plain forward, x0 written out)
@@ -1154,7 +1151,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     // The two ends of the step as split-f16 "step tail" launches (tail_h2.h): with the split arithmetic, the SMPL token width and the packer's plane
     // fragments.  flags (interdiff_mdm_forward_step_ex) then chain consecutive plain steps: IDF_STEP_EMBED_READY = the previous call's tail has already
     // written this step's embedding into the workspace, IDF_STEP_EMBED_NEXT = this call's tail writes the next step's.  Ignored otherwise.
-    const bool tail_h2 = tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && C == idf_tail_h2::CW && w->layer[L - 1].rb_h2_ok != 0;
+    const bool tail_h2 = tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && C == idf_tail_h2::CW && w->tail_h2_ok != 0 && idf_tail_h2::tail_exclusive_ok((T & 3) != 0);
     idf_tail_h2::TailArgs ta{};
     if (tail_h2) {
         ta.win = ar + w->in_w_h2; ta.in_b = ar + w->in_b; ta.temb = ar + w->temb_table; ta.pe = ar + w->pe; ta.ts = ts; ta.n_steps = w->n_steps;
@@ -1198,11 +1195,8 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
         const float *Gh = mc.Gh2 + (size_t)l * B * G_H2, *VWh = mc.VWh2 + (size_t)l * B * VW_H2, *scl = mc.sc + (size_t)l * B * 2;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
-            if (rb_h2) {
-                static std::atomic<uint64_t> done{0};
-                static std::atomic<int> dynb{-1};
-                const int dyn = rb_h2_fill_lds(rowblock_kernel<true, true, NSL, true>, done, dynb);
-                if (dyn < 0) return IDF_E_LAUNCH;
+            const int dyn = rb_h2 ? rb_h2_qan_dyn() : -1;
+            if (dyn >= 0) {
                 rowblock_kernel<true, true, NSL, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, scl);
@@ -1229,17 +1223,17 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
             if (tune[IDF_TUNE_GEMM_OUTPROJ] == 0) {
                 // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's
                 // slab buffer (its previous contents were consumed by the QKV kernel), summed with xn + bo by the row block
+                int rc_ah2 = IDF_NOT_EXCLUSIVE;
                 if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] == 5) {      // NOT the default: the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) measured 1.5 % slower over whole samples than the fp32 kernel with two workgroups per CU (profiles/r04_attn_split_f16_ab.txt); MISC = 5 selects it
-                    if (const int rc = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride); rc != IDF_OK) return rc;
-                } else
+                    rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride);
+                    if (rc_ah2 != IDF_OK && rc_ah2 != IDF_NOT_EXCLUSIVE) return rc_ah2;
+                }
+                if (rc_ah2 == IDF_NOT_EXCLUSIVE)
                 hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256),
                                    attn_lds_bytes(T, ATTN_RT), s, k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
-                if (rb_h2) {
-                    static std::atomic<uint64_t> done{0};
-                    static std::atomic<int> dynb{-1};
-                    const int dyn = rb_h2_fill_lds(rowblock_kernel<false, true, H, true>, done, dynb);
-                    if (dyn < 0) return IDF_E_LAUNCH;
+                const int dyn = rb_h2 ? rb_h2_std_dyn() : -1;
+                if (dyn >= 0) {
                     rowblock_kernel<false, true, H, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, scl);
@@ -1332,5 +1326,28 @@ extern "C" int interdiff_mdm_forward_step_ex(const idf_mdm_weights *w, const flo
 
 // 1 when interdiff_mdm_forward_step_ex honours its flags for this handle (split arithmetic selected, token width 144, plane fragments packed); 0: they are ignored
 extern "C" int interdiff_mdm_step_chaining(const idf_mdm_weights *w) {
-    return w && w->tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && w->C == idf_tail_h2::CW && w->layer[L - 1].rb_h2_ok != 0 ? 1 : 0;
+    return w && w->tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && w->C == idf_tail_h2::CW && w->tail_h2_ok != 0 &&
+                   idf_tail_h2::tail_exclusive_ok(false) && idf_tail_h2::tail_exclusive_ok(true) ? 1 : 0;
+}
+
+// Verdicts of the exclusive-CU check (common.h idf_exclusive_cu) for EVERY kernel of the library that issues the f16 MFMA, on the current device: forces
+// the check for each (no launch), writes one text line per kernel into buf (<= cap bytes, NUL-terminated) and returns the number of kernels that do NOT
+// get their CU to themselves (those run as their fp32-MFMA counterparts), or a negative IDF_E_* code.
+extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
+    if (!buf || cap <= 0) return IDF_E_INVAL;
+    {
+        static idf_excl_cache c[7];
+        using namespace idf_ffn_h2;
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<1, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<16 rows>", NT, c[0]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<32 rows>", NT, c[1]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<4, 2, 0>), "ffn_h2_kernel<64 rows>", NT, c[2]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
+    }
+    rb_h2_qan_dyn();
+    rb_h2_std_dyn();
+    idf_tail_h2::tail_exclusive_ok(false);
+    idf_tail_h2::tail_exclusive_ok(true);
+    return idf_excl_report(buf, cap);
 }

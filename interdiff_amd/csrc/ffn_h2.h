@@ -457,6 +457,8 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
 // lds_sentinel_probe.py) saw no foreign LDS write.  The mechanism is not established.  The kernel therefore takes its CU for itself:
 // it asks for the whole 160 KiB of LDS and for 256 VGPRs per wave (2 waves per SIMD x 256 = the register file), so that no other
 // workgroup can be resident next to it -- 0 differences in the same probe.  It costs nothing: the grid is one workgroup per CU by design.
+// Since round 5 the launchers VERIFY the claim (common.h idf_exclusive_cu: occupancy query == 1, LDS == 160 KiB, >= 256 registers allocated) and hand back
+// IDF_NOT_EXCLUSIVE where it does not hold; the caller then runs the fp32 kernel of ffn.h.
 constexpr int LDS_REQUEST = 160 * 1024;
 #ifndef IDF_FFN_H2_SLOTS
 #define IDF_FFN_H2_SLOTS 4
@@ -466,9 +468,9 @@ template <int TT, int S>
 inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int order) {
     constexpr int BM = 16 * TT;
     static_assert(BM * 1024 + S * SLOT <= LDS_REQUEST, "LDS");
-    static std::atomic<uint64_t> done{0};
-    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), LDS_REQUEST, done);
-    if (rc != IDF_OK) return rc;
+    static idf_excl_cache excl;
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), TT == 1 ? "ffn_h2_kernel<16 rows>" : (TT == 2 ? "ffn_h2_kernel<32 rows>" : "ffn_h2_kernel<64 rows>"), NT, excl);
+    if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;            // (the kernel has no static LDS: its dynamic request IS the CU's 160 KiB)
     hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, pack, b1p, b2, parts, order);
     return IDF_OK;
 }
@@ -667,9 +669,9 @@ template <int NP>
 inline int launch_ln_linear_h2(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
                                const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
                                int64_t *step_ts = nullptr, int step_B = 0) {
-    static std::atomic<uint64_t> done{0};
-    const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP>), LDS_REQUEST, done);
-    if (rc != IDF_OK) return rc;
+    static idf_excl_cache excl;
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NT, excl);
+    if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
     const int nsl = (int)idf_cdiv(N, QHS);
     hipLaunchKernelGGL(ln_linear_h2_kernel<NP>, dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, lnw, lnb,
                        M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl);

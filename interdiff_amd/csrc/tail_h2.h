@@ -240,24 +240,18 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
 }
 
 // launch with the dynamic LDS that tops the kernel's static LDS up to the CU's 160 KiB (exclusive CU); per (kernel, device) opt-in
+// (ta == nullptr: only the exclusive-CU verdict of this instantiation, common.h idf_exclusive_cu: dynamic LDS >= 0, or -1)
 template <int MODE, bool RAGGED>
-inline int launch_tail_one(hipStream_t s, const TailArgs &ta) {
-    static std::atomic<uint64_t> done{0};
-    static std::atomic<int> dyn_bytes{-1};
-    int dyn = dyn_bytes.load(std::memory_order_acquire);
-    if (dyn < 0) {
-        hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&step_tail_h2_kernel<MODE, RAGGED>)) != hipSuccess) return IDF_E_LAUNCH;
-        dyn = 160 * 1024 - (int)at.sharedSizeBytes;
-        if (dyn < 0) return IDF_E_LAUNCH;
-        dyn_bytes.store(dyn, std::memory_order_release);
-    }
-    if (idf_opt_in_lds(reinterpret_cast<const void *>(&step_tail_h2_kernel<MODE, RAGGED>), dyn, done) != IDF_OK) return IDF_E_LAUNCH;
-    hipLaunchKernelGGL((step_tail_h2_kernel<MODE, RAGGED>), dim3((unsigned)idf_cdiv(ta.M, TRW)), dim3(NTH), (size_t)dyn, s, ta);
+inline int launch_tail_one(hipStream_t s, const TailArgs *ta) {
+    static idf_excl_cache excl;
+    static const char *const names[4] = {"step_tail_h2_kernel<embed>", "step_tail_h2_kernel<heads>", "step_tail_h2_kernel<heads+update>", "step_tail_h2_kernel<heads+update+embed>"};
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&step_tail_h2_kernel<MODE, RAGGED>), names[MODE], NTH, excl);
+    if (!ta) return dyn;
+    if (dyn < 0) return IDF_NOT_EXCLUSIVE;
+    hipLaunchKernelGGL((step_tail_h2_kernel<MODE, RAGGED>), dim3((unsigned)idf_cdiv(ta->M, TRW)), dim3(NTH), (size_t)dyn, s, *ta);
     return IDF_OK;
 }
-inline int launch_tail(hipStream_t s, int mode, const TailArgs &ta) {
-    const bool ragged = (ta.T & 3) != 0;
+inline int launch_tail_sel(hipStream_t s, int mode, bool ragged, const TailArgs *ta) {
     switch (mode * 2 + (ragged ? 1 : 0)) {
     case 0: return launch_tail_one<0, false>(s, ta);
     case 1: return launch_tail_one<0, true>(s, ta);
@@ -268,6 +262,14 @@ inline int launch_tail(hipStream_t s, int mode, const TailArgs &ta) {
     case 6: return launch_tail_one<3, false>(s, ta);
     default: return launch_tail_one<3, true>(s, ta);
     }
+}
+inline int launch_tail(hipStream_t s, int mode, const TailArgs &ta) { return launch_tail_sel(s, mode, (ta.T & 3) != 0, &ta); }
+// The step tail is usable on this device only if ALL FOUR parts of its raggedness class get their CU (a step's two ends, and the chained / unchained forms of
+// consecutive steps, must take the same arithmetic): decided once, up front, by the forward (csrc/denoiser.hip) and by interdiff_mdm_step_chaining.
+inline bool tail_exclusive_ok(bool ragged) {
+    bool ok = true;
+    for (int mode = 0; mode < 4; ++mode) ok = (launch_tail_sel(nullptr, mode, ragged, nullptr) >= 0) && ok;
+    return ok;
 }
 
 }  // namespace idf_tail_h2

@@ -245,7 +245,9 @@ class GaussianDiffusion:
         # then one captured graph, and the 49 plain steps before it ride in the same graph -- a 50-step segment of the loop is one launch.
         # Same kernels in the same order as the eager hook step: same bits (tests).  Hooks without apply_dev, or with debug outputs
         # switched on, keep the eager path.
-        hook_dev = (denoised_fn is not None and getattr(denoised_fn, 'graph_capturable', False) and getattr(denoised_fn, 'debug', None) is None
+        # (the staggered per-chain form below calls the hook eagerly per half batch: it needs none of this -- no workspace, no warm-up call, no input copies)
+        staggered = split and self.stagger_steps > 0 and B % nch == 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs')
+        hook_dev = (not staggered and denoised_fn is not None and getattr(denoised_fn, 'graph_capturable', False) and getattr(denoised_fn, 'debug', None) is None
                     and getattr(denoised_fn, 'is_active', None) is not None and all(k in y for k in ('inpainted_motion', 'hand_pose', 'beta', 'obj_points'))
                     and os.environ.get('INTERDIFF_EAGER_HOOK') != '1')
         if hook_dev:
@@ -257,8 +259,8 @@ class GaussianDiffusion:
                                      y=dict(inpainted_motion=st.gt if has_mask else torch.empty_like(img),
                                             **{k: torch.empty(y[k].shape, dtype=torch.float32, device=dev) for k in ('hand_pose', 'beta', 'obj_points')}))
                 hooks[denoised_fn._uid] = hk
-                for key in [key for key in st.graphs if isinstance(key, tuple) and key[0] == 'hook' and key[1] == denoised_fn._uid]:
-                    del st.graphs[key]
+                for stale in [gk for gk in st.graphs if isinstance(gk, tuple) and gk[0] == 'hook' and gk[1] == denoised_fn._uid]:
+                    del st.graphs[stale]
             for k in ('hand_pose', 'beta', 'obj_points') + (() if has_mask else ('inpainted_motion',)):      # this sample's hook inputs, in buffers the graphs know
                 hk.y[k].copy_(y[k])
             if hk.fresh:                            # first launches of the hook's kernels must not happen inside a capture
@@ -290,7 +292,7 @@ class GaussianDiffusion:
         st.state.copy_(torch.tensor([t_start, 0, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0, 0, elem0, 0], dtype=torch.int64))
         gate = getattr(denoised_fn, 'is_active', None)
         active = lambda i: denoised_fn is not None and (gate is None or gate(i))
-        if split and self.stagger_steps > 0 and B % nch == 0 and denoised_fn is not None and hasattr(denoised_fn, 'slice_kwargs'):
+        if staggered:
             return self._staggered_chains(model, st, table, model_kwargs, denoised_fn, active, seed, todo, dump_steps, t_start, has_mask, rows, elem0)
         if split:                                   # the other chains' states: the same schedule position, their x starts c chain-sizes in
             for c, ch in enumerate(st.chains[1:], 1):

@@ -17,12 +17,29 @@ import torch
 SMPLH_KEYS = ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'parents', 'faces')
 
 
-def load_lightning_state_dict(path, prefix='model.', map_location='cpu'):
+def _torch_load_weights(path, map_location, trust_pickle):
+    """torch.load restricted to tensors and plain containers (``weights_only=True``); a lightning checkpoint's ``hyper_parameters`` hold an
+    ``argparse.Namespace``, which is allow-listed for this one call (it is data: attribute names -> values).  Anything else a file wants to
+    unpickle is code execution by whoever wrote the file, and is refused unless the caller says the file is trusted."""
+    import argparse
+    try:
+        from torch.serialization import safe_globals
+        with safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:
+        if not trust_pickle:
+            raise ValueError('%s does not load with weights_only=True (%s: %s); pass trust_pickle=True only for a file whose origin you trust -- '
+                             'a pickle runs code' % (path, type(e).__name__, str(e).splitlines()[0] if str(e) else '')) from e
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def load_lightning_state_dict(path, prefix='model.', map_location='cpu', trust_pickle=False):
     """``.ckpt`` (pytorch-lightning) or a plain ``torch.save``d state_dict -> {reference key name: tensor}.  Keys that do not start
     with ``prefix`` (optimizer-side entries of other attributes) are dropped; with ``prefix=''`` everything is kept.  Also returns
     nothing else: hyper-parameters travel on the command line in the reference (``args.dct`` is absent from correction.ckpt's own
-    hparams and comes from the CLI default, eval_smpl_short.py:394)."""
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    hparams and comes from the CLI default, eval_smpl_short.py:394).  The file is read with ``weights_only=True`` (tensors, containers,
+    ``argparse.Namespace``); ``trust_pickle=True`` falls back to a full unpickle for checkpoints that carry other objects."""
+    ck = _torch_load_weights(path, map_location, trust_pickle)
     sd = ck['state_dict'] if isinstance(ck, dict) and 'state_dict' in ck else ck
     if not isinstance(sd, dict) or not sd:
         raise ValueError('%s holds no state_dict' % path)
@@ -42,11 +59,26 @@ def load_state_dict_npz(path):
         return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
-def load_smplh_npz(path, n_betas=10):
+def load_smplh_npz(path, n_betas=10, trust_pickle=False):
     """-> dict(v_template [V,3], shapedirs [V,3,n_betas], posedirs [V,3,9(J-1)], J_regressor [J,V], weights [V,J], parents [J] (root -1),
-    faces [F,3]) as numpy arrays: what ``SMPL_Layer(model)`` takes."""
-    with np.load(path, allow_pickle=True) as z:
-        a = {k: z[k] for k in z.files}
+    faces [F,3]) as numpy arrays: what ``SMPL_Layer(model)`` takes.  Plain arrays are read without pickle.  The official SMPL+H release stores
+    ``J_regressor`` as a pickled scipy sparse matrix: that ONE entry is unpickled, and only with ``trust_pickle=True`` (a pickle runs code);
+    every other entry of the file is still read as a plain array."""
+    with np.load(path, allow_pickle=False) as z:
+        a = {}
+        for k in z.files:
+            try:
+                a[k] = z[k]
+            except ValueError:                     # an object array: needs pickle
+                if k != 'J_regressor':
+                    if k in ('v_template', 'shapedirs', 'posedirs', 'weights', 'parents', 'kintree_table', 'faces', 'f'):
+                        raise ValueError('%s: entry %r is a pickled object; only J_regressor may be (the official release\'s sparse matrix)' % (path, k))
+                    continue                       # entries the layer does not use are skipped, not unpickled
+                if not trust_pickle:
+                    raise ValueError('%s stores J_regressor as a pickled object (the official SMPL+H release does); pass trust_pickle=True only for a '
+                                     'file whose origin you trust -- a pickle runs code' % path)
+                with np.load(path, allow_pickle=True) as zp:
+                    a[k] = zp[k]
     m = {}
     m['v_template'] = np.asarray(a['v_template'], np.float32).reshape(-1, 3)
     V = m['v_template'].shape[0]

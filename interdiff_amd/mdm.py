@@ -323,6 +323,9 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
     if w.C == 144 and np.abs(wout_full).max() < H2_LIMIT and np.abs(win).max() < H2_LIMIT:
         oh2, ih2 = pack_tail_h2(wout_full, win)
         w.out_w_h2, w.in_w_h2 = ar.add(oh2), ar.add(ih2)
+    # the heads GEMM's A operand is LN3 of the LAST layer: its own range proof (the embedding side is row-scaled in the kernel and needs none)
+    pl = 'decoder.layers.%d.' % (LAYERS - 1)
+    w.tail_h2_ok = 1 if ln_h2_range_ok((g(pl + 'norm3.weight'), g(pl + 'norm3.bias'))) else 0
     pe = g('PositionalEmbedding.pe')[:, 0] if 'PositionalEmbedding.pe' in sd else positional_table()
     if n_steps > pe.shape[0] or max_T > pe.shape[0]:
         raise ValueError('positional table too short')
@@ -574,7 +577,11 @@ class MDM:
         no longer slip its small kernels beside it, and up to one round a single chain is ahead (same process, whole samples with correction,
         tools/chains_ab.py: 12 clips 0.2171 vs 0.2252, 16 clips 0.2300 vs 0.2372 ms per step; beyond one round two chains win big: 17 clips 0.2455 vs
         0.3135, 20: 0.2545 vs 0.3310, 24: 0.2875 vs 0.3412, 32: 0.3362 vs 0.3495)."""
-        return 32 * (256 // _lib.FFN_SLICES) if self.ffn_math == 'split' else self.FFN16_MAX_ROWS
+        if self.ffn_math != 'split':
+            return self.FFN16_MAX_ROWS
+        if getattr(self, '_n_cu', None) is None:      # one round of 32-row x 5-slice workgroups on THIS device's CUs (256 on MI355X: 1632 rows)
+            self._n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 256
+        return 32 * (self._n_cu // _lib.FFN_SLICES)
 
 
     @classmethod
@@ -608,6 +615,27 @@ class MDM:
                 tile = 16 if own_rows <= self.FFN16_MAX_ROWS else 64
         self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(tile, 1)
         self.w.tune[_lib.TUNE['ffn_math']] = (1 if getattr(self, 'rowblock_math', 'exact') == 'split' else 2) if getattr(self, 'ffn_math', 'exact') == 'split' else 0
+
+    def arithmetic_report(self):
+        """Which arithmetic every contraction of a denoiser forward takes under the current ``ffn_math`` / ``rowblock_math`` selection, layer by
+        layer -- the same conditions csrc/denoiser.hip applies (a layer whose f16 range proof failed at pack time stays on the exact fp32-MFMA kernel;
+        nothing else reports that).  'split' = split-f16 (two f16 planes per fp32 operand, three f16 MFMAs per product), 'exact' = fp32 MFMA."""
+        split = self.ffn_math == 'split'
+        rb_split = split and self.rowblock_math == 'split'
+        w = self.w
+        layers = []
+        for l in range(LAYERS):
+            ly = w.layer[l]
+            d = dict(layer=l, kind='qan' if ly.is_qan else 'std',
+                     ffn='split' if (split and ly.ffn_pack_h2) else 'exact',
+                     rowblock='split' if (rb_split and ly.rb_h2_ok and (not ly.is_qan or (ly.qc_h2 and l > 0))) else 'exact')
+            if not ly.is_qan:
+                d['qkv'] = 'split' if (split and ly.sa_in_pack_h2) else 'exact'
+                d['self_attention'] = 'exact'
+            layers.append(d)
+        tail = 'split' if (split and w.out_w_h2 and w.in_w_h2 and w.C == 144 and w.tail_h2_ok) else 'exact'
+        return dict(ffn_math=self.ffn_math, rowblock_math=self.rowblock_math, layers=layers, embedding_and_heads=tail,
+                    all_split=all(d['ffn'] == 'split' and d['rowblock'] == 'split' and d.get('qkv', 'split') == 'split' for d in layers) and tail == 'split')
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).

@@ -29,6 +29,8 @@ What each fixture pins (reference file:line in brackets):
                    per-call decisions; generated separately (`make_golden.py full`, ~35 min) [eval_smpl_short.py:84-177]
   full64.npz       the fp64 twin of full.npz (the ORACLE in float64 on the same inputs / noise; `make_golden.py full64`, ~1 h):
                    not a reference output -- the yardstick that says how far fp32 itself is from exact arithmetic on this chain
+  fullwc.npz, fullwc64.npz   the same two runs with the WELL-CONDITIONED synthetic denoiser (tests/fixtures.py mdm_weights_wc: small-gain output heads
+                   around a valid pose), on which north_star's 1e-4 is attainable for the final poses (`make_golden.py fullwc`, `fullwc64`)
   long.npz         eval_smpl_long.get_batch (window algebra of the autoregressive rollout, "next" row N3) on two windows of one
                    clip, from the reference's own source with its two non-executable method chains removed (`make_golden.py long`)
   corr32.npz       eval_smpl_short.denoised_fn, one corrected step (t = 250) at B=32, T=100, P=2048 (`make_golden.py corr32`)
@@ -70,13 +72,13 @@ def ref_diffusion(steps):
         loss_type=gd.LossType.MSE, rescale_timesteps=False, lambda_vel=1.)
 
 
-def ref_mdm():
+def ref_mdm(weights=None):
     m = refshim.load('model.diffusion_smpl')
     args = Namespace(embedding_dim=256, smpl_dim=132, use_pointnet2=1, dropout=0.1, num_heads=4,
                      ff_size=1024, activation='gelu', latent_usage='memory', future_len=25,
                      cond_mask_prob=0)
     net = m.MDM(args).eval()
-    missing, unexpected = net.load_state_dict(fx.mdm_weights(), strict=False)
+    missing, unexpected = net.load_state_dict(weights if weights is not None else fx.mdm_weights(), strict=False)
     assert not unexpected
     assert all(k.startswith(('encoder', 'pcEmb', 'finalLinear', 'bodyFuture', 'objFuture', 'PositionalEmbedding',
                              'embedTimeStep.sequence_pos_encoder')) for k in missing), missing
@@ -158,8 +160,10 @@ def gen_optim():
     save('optim.npz', **res)
 
 
-def gen_full():
-    """BASELINE config #2 end to end on the reference's own code: eval_smpl_short.sample_once_proj (1000-step p_sample_loop with the
+def gen_full(wc=False):
+    """(wc=True: the same run with the WELL-CONDITIONED synthetic denoiser fx.mdm_weights_wc() -> fullwc.npz, dumps fx.FULLWC_DUMPS;
+    `python tests/golden/make_golden.py fullwc`.)
+    BASELINE config #2 end to end on the reference's own code: eval_smpl_short.sample_once_proj (1000-step p_sample_loop with the
     reference MDM and the reference denoised_fn, injected x_T and per-step noise) at B=16, T=100, P=2048, then get_gt and metrics.
     Recorded besides the outputs: the sampler state at fx.FULL_DUMPS and, for each of the 11 correction calls, which clips the hook
     rewrote (``condition``) and the contact counts it handed to ObjProjector.sample (whose argmax picks the reference marker).
@@ -167,7 +171,8 @@ def gen_full():
     import time
     ev = refshim.load('eval_smpl_short')
     gd = refshim.load('diffusion.gaussian_diffusion')
-    net = ref_mdm()
+    net = ref_mdm(fx.mdm_weights_wc() if wc else None)
+    dump_steps = fx.FULLWC_DUMPS if wc else fx.FULL_DUMPS
     L = ref_smpl(fx.smpl_model())
     T, B, P = fx.FULL_SHAPE
     past = fx.PAST
@@ -210,8 +215,8 @@ def gen_full():
     dumps = {}
 
     def loop_spy(model, shape, **kw):
-        out = real_loop(model, shape, dump_steps=fx.FULL_DUMPS, **kw)
-        dumps.update({s: v for s, v in zip(fx.FULL_DUMPS, out)})
+        out = real_loop(model, shape, dump_steps=dump_steps, **kw)
+        dumps.update({s: v for s, v in zip(dump_steps, out)})
         return out[-1]
     diff.p_sample_loop = loop_spy
     pose_full = torch.cat([torch.zeros(T, B, 66), batch['hand_pose']], dim=2)     # only [:, 66:] is read (:146)
@@ -229,13 +234,14 @@ def gen_full():
     met = ev.metrics(obj[past:], jtrs[past:], body[past:], obj_gt[past:], jtr_gt[past:], body_gt[past:], verts[past:], faces,
                      batch['obj_points'])
     from oracle.correction import MARKERS67
-    save('full.npz', obj=np_(obj), body=np_(body), markers=np_(verts[:, :, MARKERS67]), jtr=np_(jtrs),
+    save('fullwc.npz' if wc else 'full.npz', obj=np_(obj), body=np_(body), markers=np_(verts[:, :, MARKERS67]), jtr=np_(jtrs),
          corr_t=np.array(rec['t']), condition=np.stack(rec['condition']), contact=np.stack(rec['contact']),
          **{'dump_%d' % s: np_(v) for s, v in dumps.items()}, **{'m_' + k: np_(v) for k, v in met.items()})
 
 
-def gen_full64():
-    """The fp64 twin of full.npz: the ORACLE's restatement of the same path (sampler + denoiser + hook) run in float64 on the same
+def gen_full64(wc=False):
+    """(wc=True: the twin of fullwc.npz -> fullwc64.npz; `python tests/golden/make_golden.py fullwc64`.)
+    The fp64 twin of full.npz: the ORACLE's restatement of the same path (sampler + denoiser + hook) run in float64 on the same
     inputs and the same injected noise.  It is the yardstick for the end-to-end tolerance: the reference's fp32 run and the HIP
     fp32 run are both compared with it (which side is closer, and how far fp32 itself is from the exact arithmetic after 1000
     steps and 11 discrete decisions).  ~1 h on 8 cores; `python tests/golden/make_golden.py full64`."""
@@ -245,7 +251,8 @@ def gen_full64():
     past = fx.PAST
     batch, noise, stream = fx.full_inputs()
     d = lambda v: v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v
-    sd = {k: d(v) for k, v in fx.mdm_weights().items()}
+    sd = {k: d(v) for k, v in (fx.mdm_weights_wc() if wc else fx.mdm_weights()).items()}
+    dump_steps = fx.FULLWC_DUMPS if wc else fx.FULL_DUMPS
     y = {k: d(v) for k, v in fx.model_kwargs_y(dict(batch, noise=noise), T).items()}
     y.update(smpl={k: d(v) for k, v in fx.smpl_model().items()}, obj_model={k: d(v) for k, v in fx.objproj_weights().items()})
     rec = dict(t=[], condition=[], contact=[])
@@ -261,10 +268,10 @@ def gen_full64():
         print('  fp64 correction at t=%d: %d/%d clips rewritten (%.0f s)' % (int(t[0]), int(terms['condition'].sum()), B, time.time() - t0), flush=True)
         return ocor.denoised_fn(x, t, model_kwargs, past_len=past)
     dumps = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond']), tuple(noise.shape), odf.make_schedule(fx.FULL_STEPS),
-                              noise.double(), lambda i, x: stream.next_like(x).double(), {'y': y}, denoised_fn=hook, dump_steps=fx.FULL_DUMPS)
+                              noise.double(), lambda i, x: stream.next_like(x).double(), {'y': y}, denoised_fn=hook, dump_steps=dump_steps)
     print('fp64 twin sampled in %.0f s' % (time.time() - t0), flush=True)
-    save('full64.npz', corr_t=np.array(rec['t']), condition=np.stack(rec['condition']), contact=np.stack(rec['contact']),
-         **{'dump_%d' % s: np_(v).astype(np.float32) for s, v in zip(fx.FULL_DUMPS, dumps)})
+    save('fullwc64.npz' if wc else 'full64.npz', corr_t=np.array(rec['t']), condition=np.stack(rec['condition']), contact=np.stack(rec['contact']),
+         **{'dump_%d' % s: np_(v).astype(np.float32) for s, v in zip(dump_steps, dumps)})
 
 
 def gen_etl():
@@ -434,6 +441,10 @@ def main():
         return gen_optim()
     if len(sys.argv) > 1 and sys.argv[1] == 'full':
         return gen_full()
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullwc':
+        return gen_full(wc=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullwc64':
+        return gen_full64(wc=True)
     # ---- real correction checkpoint -> plain arrays (must exist before fx.objproj_weights())
     ck = torch.load('/root/reference/interdiff/checkpoints/correction.ckpt', map_location='cpu', weights_only=False)
     save('correction_ckpt.npz', **{k[len('model.'):]: np_(v) for k, v in ck['state_dict'].items()})

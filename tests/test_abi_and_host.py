@@ -490,6 +490,19 @@ def test_io_lightning_checkpoint_reproduces_the_committed_fixture(tmp_path):
     iio.state_dict_to_npz(sd, str(tmp_path / 'sd.npz'))
     back = iio.load_state_dict_npz(str(tmp_path / 'sd.npz'))
     assert all(torch.equal(back[k], sd[k]) for k in sd)
+    # a checkpoint that smuggles an arbitrary object is refused (weights_only=True) unless the caller declares the file trusted
+    class Payload:
+        def __reduce__(self):
+            return (list, ((1, 2),))
+    evil = str(tmp_path / 'evil.ckpt')
+    torch.save({'state_dict': {'model.w': torch.zeros(2)}, 'callbacks': Payload()}, evil)
+    with pytest.raises(ValueError, match='trust_pickle'):
+        iio.load_lightning_state_dict(evil)
+    assert list(iio.load_lightning_state_dict(evil, trust_pickle=True)) == ['w']
+    import argparse
+    ns = str(tmp_path / 'ns.ckpt')                    # what lightning really writes next to the weights: an argparse.Namespace -- allow-listed
+    torch.save({'state_dict': {'model.w': torch.ones(2)}, 'hyper_parameters': {'args': argparse.Namespace(dct=10)}}, ns)
+    assert torch.equal(iio.load_lightning_state_dict(ns)['w'], torch.ones(2))
     real = '/root/reference/interdiff/checkpoints/correction.ckpt'
     if not os.path.exists(real):
         pytest.skip('reference checkpoint not on this box')
@@ -530,6 +543,21 @@ def test_io_smplh_npz_and_dataset_batch_adaptor(tmp_path):
     with pytest.raises(ValueError):
         np.savez(str(tmp_path / 'bad.npz'), **{**{k: np.asarray(m[k]) for k in iio.SMPLH_KEYS}, 'weights': np.asarray(m['weights'])[:, :40]})
         iio.load_smplh_npz(str(tmp_path / 'bad.npz'))
+    # the official release pickles J_regressor (a scipy sparse matrix): that one entry needs trust_pickle=True, nothing else is ever unpickled
+    import scipy.sparse as sp
+    jr_obj = np.empty((), dtype=object)
+    jr_obj[()] = sp.csc_matrix(np.asarray(m['J_regressor']))
+    p3 = str(tmp_path / 'official_sparse.npz')
+    np.savez(p3, v_template=m['v_template'], shapedirs=sd16, posedirs=np.asarray(m['posedirs']).reshape(V * 3, -1), J_regressor=jr_obj,
+             weights=m['weights'], kintree_table=kt, f=np.asarray(m['faces']).astype(np.uint32), extra_object=np.array({'a': 1}, dtype=object))
+    with pytest.raises(ValueError, match='trust_pickle'):
+        iio.load_smplh_npz(p3)
+    c = iio.load_smplh_npz(p3, trust_pickle=True)
+    assert np.array_equal(c['J_regressor'], a['J_regressor'])
+    p4 = str(tmp_path / 'object_weights.npz')
+    np.savez(p4, **{**{k: np.asarray(m[k]) for k in iio.SMPLH_KEYS}, 'weights': np.array({'w': 1}, dtype=object)})
+    with pytest.raises(ValueError, match='pickled object'):
+        iio.load_smplh_npz(p4, trust_pickle=True)
     # dataset batch: T records of collated tensors
     T, B, P = 5, 3, 7
     g = torch.Generator().manual_seed(0)

@@ -114,7 +114,8 @@ int interdiff_point2point_signed(const float *x, int32_t P1, const float *y, int
 #define IDF_MDM_FF     1024
 #define IDF_MDM_HEADS  4
 #define IDF_MDM_NQ     10      /* learned queries per QaN layer                          */
-#define IDF_MDM_MEM    10      /* memory (past) tokens                                   */
+#define IDF_MDM_MEM    10      /* memory (past) tokens: the default (every BASELINE config), compact layout of the folded memory */
+#define IDF_MDM_MEM_MAX 16     /* longest memory (idf_mdm_weights.mem_len): the reference takes --past_len from the CLI (eval_smpl_short.py:376) */
 #define IDF_FFN_SLICES 5       /* hidden-unit slices of the fused FFN = partial output slabs (csrc/ffn.h) */
 
 typedef struct {
@@ -178,6 +179,10 @@ typedef struct {
     /* 1 when the packer has proved that the heads GEMM's A operand -- LayerNorm norm3 of the LAST decoder layer -- stays inside the f16 range
      * (mdm.py ln_h2_range_ok on its gamma / beta); 0: the step tail keeps the fp32 token GEMMs (and interdiff_mdm_forward_step_ex ignores its flags) */
     int64_t tail_h2_ok;
+    /* memory length of the NEXT interdiff_mdm_prepare_memory / forward calls on this handle: rows of cond [mem_len,B,256].  0 = IDF_MDM_MEM (10).  Any 1 ..
+     * IDF_MDM_MEM_MAX is served; 10 takes the compact (fast) layout of the folded memory, other lengths a generic one (one more score-column tile in the row
+     * block).  A memctx folded at one length must be consumed at the same length (its size differs: interdiff_mdm_memctx_floats_for). */
+    int32_t mem_len, reserved0;
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA
@@ -201,14 +206,18 @@ int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, const float 
  * (torch.nn.TransformerDecoderLayer._ff_block + residual; sublayers.py:331-341).  encoder != 0 selects enc_layer[layer].
  * Row tile by w->tune[IDF_TUNE_FFN] (see idf_mdm_weights). */
 int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts, void *stream);
+/* floats of a memctx for B clips at memory length mem_len (1 .. IDF_MDM_MEM_MAX; 0 if out of range); interdiff_mdm_memctx_floats(B) is the mem_len = 10 case */
+size_t interdiff_mdm_memctx_floats_for(int32_t B, int32_t mem_len);
 
 size_t interdiff_mdm_memctx_floats(int32_t B);
 size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T);
 int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B,
                                  float *memctx, void *ws, size_t ws_bytes, void *stream);
 /* x [B,1,C,T], ts int64 [B] -> x0 [B,1,C,T].
- * Size limits (IDF_E_INVAL beyond them): T <= 208 -- the temporal self-attention of the two standard layers parks K and V of one
- * (clip, head) in one CU's LDS (2 x T x 68 floats + the score tile = 149 KiB at T = 208); T <= max_T of the packed positional table;
+ * Size limits (IDF_E_INVAL beyond them): T <= max_T of the packed positional table (mdm.py pack_mdm_weights(max_T=): up to the 5000 rows of the
+ * reference's PositionalEncoding).  Up to T = 208 the temporal self-attention of the two standard layers parks K and V of one (clip, head) in one CU's
+ * LDS (2 x T x 68 floats + the score tile = 149 KiB at T = 208: the fast path, every BASELINE shape); longer clips take a K/V-tiled form of the same
+ * attention (64-key tiles, running row maximum / sum; csrc/denoiser.hip self_attn_tiled_kernel) -- correct, not tuned.  Memory length: idf_mdm_weights.mem_len;
  * C <= 256 (any width: W_in's rows are packed zero-padded to a multiple of 4 floats, mdm.py; BASELINE config #1 has C = 106).  The reference itself is bounded only by PositionalEncoding(max_len=5000) (model/layers.py:11); its
  * datasets use T = 35 (eval_smpl_short.py:376-377) and BASELINE.json T = 100.  B is unbounded (clips are independent). */
 int interdiff_mdm_forward(const idf_mdm_weights *w, const float *memctx, const float *x,
@@ -466,6 +475,10 @@ int interdiff_debug_joint_map_vjp(const float *R, const float *g_out, float *g_i
 /* Diagnostic: n_wg one-wave workgroups each fill 6 KiB of LDS with a pattern and re-read it `spin` times; out[0] counts foreign writes seen,
  * out[4 + 4 k ..] = {workgroup, word, value found, pass} of the first 1000 (tools/lds_sentinel_probe.py; not used by the product path). */
 int interdiff_debug_lds_sentinel(uint32_t *out, int32_t n_wg, int32_t spin, void *stream);
+/* Diagnostic: the "aggressor" of the co-residency probes (DESIGN.md "exclusive CU"; tools/hook_stage_probe.py, tools/coresidency_repro.hip): `grid` workgroups of 256
+ * threads that loop `iters` times over four v_mfma_f32_16x16x32_f16 on register operands and, with_loads != 0, one streaming 16-byte load per lane from
+ * src[n_floats] (>= 4096 floats).  Small LDS / register needs on purpose, so that it shares CUs with kernels on other streams.  Never launched by the product path. */
+int interdiff_debug_f16_aggressor(const float *src, size_t n_floats, float *sink, int32_t iters, int32_t grid, int32_t with_loads, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Live per-kernel timing for bench.py's `roofline` block (not on the product path).

@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')
+LIB_PATH = os.environ.get('INTERDIFF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')      # (the override: A/B builds of the SAME library under build_ab/, tools/ only)
 ABI_VERSION = 14
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -38,7 +38,7 @@ class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
                 ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
-                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64), ('tail_h2_ok', i64)]
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64), ('tail_h2_ok', i64), ('mem_len', i32), ('reserved0', i32)]
 
 
 class PnMlp(C.Structure):
@@ -96,6 +96,7 @@ _SIGS = {
     'interdiff_mdm_encode': (C.c_int, [C.POINTER(MdmWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     'interdiff_mdm_ffn': (C.c_int, [C.POINTER(MdmWeights), i32, i32, vp, i32, vp, vp]),
     'interdiff_mdm_memctx_floats': (sz, [i32]),
+    'interdiff_mdm_memctx_floats_for': (sz, [i32, i32]),
     'interdiff_mdm_workspace_bytes': (sz, [i32, i32]),
     'interdiff_mdm_prepare_memory': (C.c_int, [C.POINTER(MdmWeights), vp, i32, vp, vp, sz, vp]),
     'interdiff_mdm_forward': (C.c_int, [C.POINTER(MdmWeights), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
@@ -126,6 +127,7 @@ _SIGS = {
     'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
     'interdiff_debug_lds_sentinel': (C.c_int, [vp, i32, i32, vp]),
     'interdiff_exclusive_cu_report': (C.c_int, [C.c_char_p, i32]),
+    'interdiff_debug_f16_aggressor': (C.c_int, [vp, sz, vp, i32, i32, i32, vp]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -29,12 +29,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, out_dir=None):
+    """out_dir (or IDF_BUILD_DIR): objects and the library go THERE instead of next to the sources -- variant builds for A/B tools (build_ab/<name>/,
+    loaded through INTERDIFF_HIP_LIB); the product library is always the in-tree one."""
+    out_dir = out_dir or os.environ.get('IDF_BUILD_DIR') or HERE
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, 'libinterdiff_hip.so')
     hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
     hdrs.append(os.path.join(HERE, '..', '..', 'include', 'interdiff_hip.h'))
     objs, jobs = [], []
     for s in sources():
-        src, obj = os.path.join(HERE, s), os.path.join(HERE, s[:-4] + '.o')
+        src, obj = os.path.join(HERE, s), os.path.join(out_dir, s[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
@@ -45,9 +50,9 @@ def build(force=False, verbose=True):
         subprocess.run(cmd, check=True)
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+    return lib
 
 
 if __name__ == '__main__':

@@ -39,6 +39,9 @@ static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, c
     return IDF_OK;
 }
 #include <float.h>
+#ifndef IDF_LDS_STRIDE_SET
+#define IDF_LDS_STRIDE_SET 5          // LDS row strides of the row block's planes and the attention's Q / K / score images -- 5: round 5's (conflict-free fragment reads, see HS / ASK);
+#endif                                // 4: round 4's (one 16-byte slot mod 16 everywhere): A/B builds only (tools/r05_ab.py, IDF_EXTRA_HIPCC_FLAGS=-DIDF_LDS_STRIDE_SET=4)
 
 // phase stamps of the row-block kernel exist only in tools/rowblock_probe.hip (which defines the macro before including this file)
 #ifndef IDF_AT_STAMP
@@ -56,9 +59,28 @@ constexpr int D = IDF_MDM_D;          // 256
 constexpr int H = IDF_MDM_HEADS;      // 4
 constexpr int HD = D / H;             // 64
 constexpr int NQ = IDF_MDM_NQ;        // 10
-constexpr int MEM = IDF_MDM_MEM;      // 10
+constexpr int MEM = IDF_MDM_MEM;      // 10: the memory length of every BASELINE config -- the COMPACT layout of the folded memory below
+constexpr int MEMX = IDF_MDM_MEM_MAX; // 16: longest memory the generic layout takes (eval_smpl_short.py:376 --past_len is a CLI argument)
 constexpr int HM = H * MEM;           // 40
 constexpr int HMP = 48;               // HM padded to a multiple of 16 (k-groups of the P.VW contraction)
+// Layout of the folded memory's (head, slot) score columns, by the template parameter MS of the kernels that touch it:
+//   MS == MEM (compact, the shipped fast path):  column = head * 10 + slot, 40 columns in 3 tiles of 16 (8 zero columns);
+//   MS == MEMX (generic, any memory length 1..16 given at run time):  column = head * 16 + slot, one 16-column tile per head, slots >= mem_len masked.
+// Everything that depends on it -- fragment sizes, column tiles, slots per softmax lane -- comes from here; with MS == MEM every expression below folds to
+// the constants the kernels had before the generic path existed (same instructions, same bits).
+template <int MS>
+struct MemLay {
+    static_assert(MS == MEM || MS == MEMX, "compact or generic");
+    static constexpr bool GEN = MS != MEM;
+    static constexpr int NCT = GEN ? 4 : 3;                 // 16-column tiles of the score matrix
+    static constexpr int HMPX = 16 * NCT;                   // padded score columns = K of the P.VW contraction (fp32 form)
+    static constexpr int NSLOT = GEN ? 4 : 3;               // memory slots per lane of the head softmax (quad q takes slots q, q + 4, ...)
+    static constexpr int G0N = GEN ? 64 : HM;               // g0 floats per (layer, clip), indexed like the columns
+    static constexpr int G_FRAG = 4 * 4 * NCT * 64 * 4;     // fp32 G fragments per (layer, clip)
+    static constexpr int G_H2 = 4 * 2 * NCT * 2 * 64 * 4;   // split-f16 G plane fragments (as floats)
+    static constexpr int VWT_F = D * HMPX;                  // fp32 VW fragments
+    __host__ __device__ static constexpr int col(int h, int m) { return GEN ? h * 16 + m : h * MEM + m; }
+};
 constexpr int L = IDF_MDM_LAYERS;
 constexpr int NSL = IDF_FFN_SLICES;   // partial output slabs of the fused FFN (ffn.h)
 
@@ -148,22 +170,20 @@ constexpr int TR = 16;
 //   Qc  (weights, mdm.py qan_fragments):      [4][4][3 taps][4 kq][NQ][4]: only lanes li < NQ fetch (logit columns >= NQ are never read)
 //   G   (per sample, mem_fold_kernel):        [4][4][3 column tiles][64][4], column = 16 ct + li of the 40 (head, slot) pairs (+8 zero)
 //   VWT (per sample, mem_fold_kernel):        [4 waves = output column quarter][3 k-groups][4 tiles][64][4]
-constexpr int G_FRAG = 4 * 4 * 3 * 64 * 4;     // 12288 floats per (layer, clip)
+//   (sizes per (layer, clip): MemLay<MS>::G_FRAG / G_H2 / VWT_F -- 12288 / 12288 / 12288 floats in the compact layout)
 // split-f16 forms (rowblock_kernel<.., H2>): 16-byte plane fragments = the v_mfma_f32_16x16x32_f16 operand of a lane (8 halves, k = 8 kq .. 8 kq + 7 of a K = 32 step)
 //   Qc  (mdm.py qan_fragments_h2):            [4 waves = K quarter][2 K steps][3 taps][2 planes][4 kq][NQ][8 halves]
 //   G   (mem_fold_h2_kernel):                 [4 waves = K quarter][2 K steps][3 column tiles][2 planes][64 lanes][8 halves], values divided by 2^e
 //   VWT (mem_fold_h2_kernel):                 [4 waves = output column quarter][2 K steps (probability columns 0..63, zero from 40)][4 tiles][2 planes][64][8 halves]
-constexpr int G_H2 = 4 * 2 * 3 * 2 * 64 * 4;   // 12288 floats
 constexpr int VW_H2 = 4 * 2 * 4 * 2 * 64 * 4;  // 16384 floats
 constexpr int RS = D + 4;             // LDS row stride of token rows (floats)
-constexpr int PS = HMP + 4;           // LDS row stride of the probability tile
 
 // H2 (decoder layers, tune[IDF_TUNE_FFN_MATH] == 1 and the packer's range proof): the three contractions on the f16 matrix pipe with every fp32
 // operand as two f16 planes (ffn_h2.h: v = hi + lo' 2^-11, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulate).  48 fp32 MFMAs of 32 cycles per
 // wave and contraction -- 1 536 of the ~2 000 cycles each of those three phases took -- become 18 / 18 / 24 of 16.  Qc / G / VWT then point at the
 // plane fragments (mdm.py qan_fragments_h2; mem_fold_h2_kernel) and h2_scale[b][2] holds the powers of two that G[b] / VW[b] were divided by.
 // Token rows need no scaling: they are LayerNorm outputs, bounded by 16 max|gamma| + max|beta| (the packer checks that against the f16 range).
-template <bool QAN, bool CROSS = true, int NP = 1, bool H2 = false>
+template <bool QAN, bool CROSS = true, int NP = 1, bool H2 = false, int MS = MEM>
 __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
                                                        const float *__restrict__ wk, const float *__restrict__ ln1_w,
@@ -174,30 +194,38 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                                                        int out_frame_major /* encoder output: row = t*B + b */,
                                                        size_t u_pstride /* NP > 1: u_in is NP partial slabs this many floats apart */,
                                                        const float *__restrict__ sa_resid /* !QAN, nullable: u1 = sum(u_in slabs) + sa_resid row + sa_bias */,
-                                                       const float *__restrict__ sa_bias, const float *__restrict__ h2_scale = nullptr) {
+                                                       const float *__restrict__ sa_bias, const float *__restrict__ h2_scale = nullptr,
+                                                       int mem_len = MEM /* MS == MEMX: slots per head actually present (1..16) */) {
     static_assert(!H2 || CROSS, "the split-f16 form exists for the decoder's row blocks");
     using idf_ffn_h2::h8;
+    using ML = MemLay<MS>;
+    constexpr int NCT = ML::NCT, HMPX = ML::HMPX, NSLOT = ML::NSLOT, PSX = HMPX + 4;
+    const int mlen = ML::GEN ? mem_len : MEM;
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
-    constexpr int HS = D + 8, PHS = 64 + 8;       // row strides (halves) of the token-row planes / probability planes: 16-byte pieces of 16 rows hit 64 different banks
+    // Row strides (halves) of the token-row planes / probability planes.  A fragment read is one ds_read_b128 per lane, lane (li, kq) -> row li, 16-byte slot s0 + kq;
+    // the instruction is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS table), i.e. rows {0-3, 12-15} at slot s and
+    // rows {4-11} at slot s + 1 together.  With a row stride of 2 slots mod 16 (32 bytes mod 256) the first set lands on the even slots and the second on the odd ones:
+    // conflict-free.  (Round 4 had a stride of 1 slot -- D + 8 halves, 64 + 8 -- where row 12 at slot s and row 11 at slot s + 1 collide in every group: 2 x the LDS cycles.)
+    constexpr int HS = D + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16), PHS = 64 + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16);
     __shared__ __attribute__((aligned(16))) _Float16 xpl[H2 ? 2 * (TR + 2) * HS : 8];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores
     __shared__ __attribute__((aligned(16))) _Float16 ppl[H2 ? 2 * TR * PHS : 8];            // [hi | lo'][TR][PHS]: probabilities, columns >= HM stay zero
     _Float16 *const xh = xpl, *const xl = xpl + (H2 ? (TR + 2) * HS : 0), *const ph = ppl, *const pl = ppl + (H2 ? TR * PHS : 0);
     __shared__ __attribute__((aligned(1024))) float prm[8 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias + self-attention output bias (DMA targets)
-    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * 3 * 256 + TR * PS];
+    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + 4 * (NCT > 3 ? NCT : 3) * 256 + TR * PSX];
     float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
-    float *part = x1s + TR * RS;                  // [4 waves][3 tiles][16x16] K-split partial tiles
-    float *Ps = part + 4 * 3 * 256;               // [TR][PS]
+    float *part = x1s + TR * RS;                  // [4 waves][3 taps | NCT score tiles][16x16] K-split partial tiles
+    float *Ps = part + 4 * (NCT > 3 ? NCT : 3) * 256;               // [TR][PSX]
 
-    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, sa_resid, sa_bias, h2_scale, gridDim.x, gridDim.y);
+    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, out_frame_major, u_pstride, sa_resid, sa_bias, h2_scale, mem_len, gridDim.x, gridDim.y);
     const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     // row passes (LayerNorms): every 16-lane group owns one token row, four rows per wave, all 16 rows in one sweep
     const int rown = wave * 4 + kq;
-    const float *Gb = CROSS ? G + (size_t)b * (H2 ? G_H2 : G_FRAG) : nullptr, *g0b = CROSS ? g0 + b * HM : nullptr;
-    const float *VWTb = CROSS ? VWT + (size_t)b * (H2 ? VW_H2 : D * HMP) : nullptr;
+    const float *Gb = CROSS ? G + (size_t)b * (H2 ? ML::G_H2 : ML::G_FRAG) : nullptr, *g0b = CROSS ? g0 + b * ML::G0N : nullptr;
+    const float *VWTb = CROSS ? VWT + (size_t)b * (H2 ? VW_H2 : ML::VWT_F) : nullptr;
     IDF_RB_STAMP(0);
     if constexpr (H2) {
         // EXCLUSIVE CU, like the other kernels that issue the f16 MFMA (ffn_h2.h "exclusive CU": next to such a kernel, workgroups of OTHER kernels on the same CU
@@ -227,9 +255,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
             if ((i & 3) == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
     }
     Row16 ra, rb;
-    float4 q[4][3], gv[4][3], vw[HMP / 16][4];      // fp32 fragments; H2: the same registers hold 16-byte plane fragments -- q[2 s + pl][j], gv[2 s + pl][ct], vw2[s][c][pl]
+    float4 q[4][3], gv[4][NCT], vw[NCT][4];      // fp32 fragments; H2: the same registers hold 16-byte plane fragments -- q[2 s + pl][j], gv[2 s + pl][ct], vw2[s][c][pl]
     float4 vw2[2][4][2];
-    float wk_n = 0.f, g0v[3], gsc = 1.f, vsc = 1.f;                     // g0 of (head = wave, memory slots q, q+4, q+8 with q = lane & 3)
+    float wk_n = 0.f, g0v[NSLOT], gsc = 1.f, vsc = 1.f;                     // g0 of (head = wave, memory slots q, q+4, q+8 with q = lane & 3)
     const int ta = QAN ? t0 - 1 + rown : t0 + rown, tb = t0 + 15 + kq;
     const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && kq < 2 && tb < T;
     Row16Raw<NP> raw_a, raw_b;
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
     if constexpr (CROSS) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) g0v[i] = g0b[wave * MEM + min((lane & 3) + 4 * i, MEM - 1)];
+        for (int i = 0; i < NSLOT; ++i) g0v[i] = g0b[ML::col(wave, min((lane & 3) + 4 * i, mlen - 1))];
     }
     if constexpr (H2) {
         gsc = h2_scale[2 * b];
@@ -273,9 +301,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss)               // (H2: ss = 2 s + plane of [wave][K step s][column tile][plane][lane][8 halves])
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-                    gv[ss][ct] = H2 ? ld4(Gb + (((((wave * 2 + (ss >> 1)) * 3 + ct) * 2 + (ss & 1)) * 64) + lane) * 4)
-                                    : ld4(Gb + (((wave * 4 + ss) * 3 + ct) * 64 + lane) * 4);
+                for (int ct = 0; ct < NCT; ++ct)
+                    gv[ss][ct] = H2 ? ld4(Gb + (((((wave * 2 + (ss >> 1)) * NCT + ct) * 2 + (ss & 1)) * 64) + lane) * 4)
+                                    : ld4(Gb + (((wave * 4 + ss) * NCT + ct) * 64 + lane) * 4);
         }
     };
     auto fetch_vw = [&]() {
@@ -288,9 +316,9 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                     for (int pl2 = 0; pl2 < 2; ++pl2) vw2[s2][c][pl2] = ld4(VWTb + (((((wave * 2 + s2) * 4 + c) * 2 + pl2) * 64) + lane) * 4);
         } else if constexpr (CROSS) {
 #pragma unroll
-            for (int sidx = 0; sidx < HMP / 16; ++sidx)
+            for (int sidx = 0; sidx < NCT; ++sidx)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vw[sidx][c] = ld4(VWTb + (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + lane) * 4);
+                for (int c = 0; c < 4; ++c) vw[sidx][c] = ld4(VWTb + (((wave * NCT + sidx) * 4 + c) * 64 + lane) * 4);
         }
     };
     // the DMA'd vectors must have landed for every wave before anyone reads them: each wave drains its own queue (its rows come
@@ -427,78 +455,87 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
     if constexpr (!CROSS) return;                  // encoder layers: no memory to attend to, x1 is the FFN input
     __syncthreads();
     IDF_RB_STAMP(4);                                     // stencil + LN1
-    {   // folded cross-attention scores: three 16x16 tiles over the 40 (head, memory) columns
-        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    {   // folded cross-attention scores: NCT 16x16 tiles over the (head, memory slot) columns (compact layout: three tiles over 40 columns)
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (H2) {
-            f32x4 acc_c[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc_c[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc_c[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int koff = 64 * wave + 32 * s2 + 8 * kq;
                 const h8 a_h = *reinterpret_cast<const h8 *>(xh + li * HS + koff), a_l = *reinterpret_cast<const h8 *>(xl + li * HS + koff);
-                const h8 ah[3] = {a_h, a_h, a_h}, al[3] = {a_l, a_l, a_l};
-                mma_h2<3>(acc, acc_c, ah, al, gv[2 * s2], gv[2 * s2 + 1]);
+                h8 ah[NCT], al[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) { ah[ct] = a_h; al[ct] = a_l; }
+                mma_h2<NCT>(acc, acc_c, ah, al, gv[2 * s2], gv[2 * s2 + 1]);
             }
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ct][r] = (acc[ct][r] + acc_c[ct][r] * idf_ffn_h2::LO_UNSCALE) * gsc;      // G[b] was divided by gsc (a power of two)
         } else {
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss) {
                 const float4 av = ld4(x1s + li * RS + 16 * (wave * 4 + ss) + 4 * kq);
-                float4 a[3] = {av, av, av};
-                mma_rounds<3>(acc, a, gv[ss]);
+                float4 a[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = av;
+                mma_rounds<NCT>(acc, a, gv[ss]);
             }
         }
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(wave * 3 + ct) * 256 + (kq * 4 + r) * 16 + li] = acc[ct][r];
+            for (int r = 0; r < 4; ++r) part[(wave * NCT + ct) * 256 + (kq * 4 + r) * 16 + li] = acc[ct][r];
     }
     __syncthreads();
     IDF_RB_STAMP(5);                                     // folded scores MFMA
     {   // softmax over the MEM memory slots of each head: wave = head, token = lane >> 2, the four lanes of a quad take slots
         // q, q+4, q+8 and combine by two quad permutes (all 256 lanes busy; one wave doing all 40 columns of its 16 tokens took 2 k cycles)
-        static_assert(H == 4 && MEM <= 12, "one wave per head, <= 3 slots per lane");
+        static_assert(H == 4 && MEM <= 12 && MEMX <= 16, "one wave per head, <= 3 (compact) / 4 (generic) slots per lane");
 #define IDF_QUAD_XOR1(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false))
 #define IDF_QUAD_XOR2(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false))
         const int tq = lane >> 2, qd = lane & 3;
-        float sc[3], mx = -FLT_MAX;
+        float sc[NSLOT], mx = -FLT_MAX;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int m = qd + 4 * i, idx = wave * MEM + min(m, MEM - 1), ct = idx >> 4, cl = idx & 15, o = tq * 16 + cl;
-            const float v = ((part[(0 * 3 + ct) * 256 + o] + part[(1 * 3 + ct) * 256 + o]) +
-                             (part[(2 * 3 + ct) * 256 + o] + part[(3 * 3 + ct) * 256 + o])) + g0v[i];
-            sc[i] = m < MEM ? v : -FLT_MAX;
+        for (int i = 0; i < NSLOT; ++i) {
+            const int m = qd + 4 * i, idx = ML::col(wave, min(m, mlen - 1)), ct = idx >> 4, cl = idx & 15, o = tq * 16 + cl;
+            const float v = ((part[(0 * NCT + ct) * 256 + o] + part[(1 * NCT + ct) * 256 + o]) +
+                             (part[(2 * NCT + ct) * 256 + o] + part[(3 * NCT + ct) * 256 + o])) + g0v[i];
+            sc[i] = m < mlen ? v : -FLT_MAX;
             mx = fmaxf(mx, sc[i]);
         }
         mx = fmaxf(mx, IDF_QUAD_XOR1(mx));
         mx = fmaxf(mx, IDF_QUAD_XOR2(mx));
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            sc[i] = qd + 4 * i < MEM ? __expf(sc[i] - mx) : 0.f;
+        for (int i = 0; i < NSLOT; ++i) {
+            sc[i] = qd + 4 * i < mlen ? __expf(sc[i] - mx) : 0.f;
             sum += sc[i];
         }
         sum += IDF_QUAD_XOR1(sum);
         sum += IDF_QUAD_XOR2(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (qd + 4 * i < MEM) {
+        for (int i = 0; i < NSLOT; ++i)
+            if (qd + 4 * i < (ML::GEN ? MEMX : MEM)) {        // (generic layout: a head's 16 columns are all written -- zero past mem_len; the planes of the split form were zeroed at entry)
+                const float pv = qd + 4 * i < mlen ? sc[i] * inv : 0.f;
                 if constexpr (H2) {
                     _Float16 hv, lv;
-                    idf_ffn_h2::split1_nf(sc[i] * inv, hv, lv);
-                    ph[tq * PHS + wave * MEM + qd + 4 * i] = hv;
-                    pl[tq * PHS + wave * MEM + qd + 4 * i] = lv;
+                    idf_ffn_h2::split1_nf(pv, hv, lv);
+                    ph[tq * PHS + ML::col(wave, qd + 4 * i)] = hv;
+                    pl[tq * PHS + ML::col(wave, qd + 4 * i)] = lv;
                 } else {
-                    Ps[tq * PS + wave * MEM + qd + 4 * i] = sc[i] * inv;
+                    Ps[tq * PSX + ML::col(wave, qd + 4 * i)] = pv;
                 }
             }
-        if (!H2 && wave == 0 && qd < (HMP - HM + 3) / 4) {
+        if (!ML::GEN && !H2 && wave == 0 && qd < (HMP - HM + 3) / 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (HM + qd * 4 + i < HMP) Ps[tq * PS + HM + qd * 4 + i] = 0.f;
+                if (HM + qd * 4 + i < HMP) Ps[tq * PSX + HM + qd * 4 + i] = 0.f;
         }
     }
     __syncthreads();
@@ -520,8 +557,8 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
                 for (int r = 0; r < 4; ++r) acc[c][r] = (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc;       // VW[b] was divided by vsc
         } else {
 #pragma unroll
-            for (int s = 0; s < HMP / 16; ++s) {
-                const float4 pv = ld4(Ps + li * PS + 16 * s + 4 * kq);
+            for (int s = 0; s < NCT; ++s) {
+                const float4 pv = ld4(Ps + li * PSX + 16 * s + 4 * kq);
                 float4 a[4] = {pv, pv, pv, pv};
                 mma_rounds<4>(acc, a, vw[s]);
             }
@@ -546,10 +583,360 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// The split-f16 row block on EIGHT waves (round 5).  Same arithmetic per product, operand layouts, grid and outputs as rowblock_kernel<QAN, true, NP, true, MS>;
+// what differs is how a workgroup's work is cut.  Round 4's kernel (four waves, one per SIMD) was a chain of short phases -- 15.6 k cycles per workgroup of which the
+// matrix pipe ran 0.4 k -- on 112 of 256 CUs; its phases are latency chains over whatever one wave holds:
+//   * row passes (slab sums, the three LayerNorms, the stencil, the f16 splits): one token row per 32 lanes (two 16-byte chunks per lane) instead of per 16 lanes
+//     (four) -- every pass is half as deep; a row's reductions are a 16-lane DPP reduction + one ds_swizzle exchange with the other half;
+//   * the logits and scores contractions split K over eight waves (one K = 32 step each: three / NCT dependent-free MFMA groups instead of two rounds), P.VW gives a wave
+//     two output tiles instead of four; every wave fetches half the fragments (the fragment orders in memory are unchanged: [K quarter][K step] IS [K eighth]);
+//   * two waves per SIMD: one's loads and LDS traffic run beside the other's VALU work.
+// It still owns its CU (512 threads x 256 registers = the register file, LDS topped up to 160 KiB by the launcher).  Results differ from the four-wave kernel by
+// summation order only (eight K partials instead of four; 32-lane LayerNorm sums); every route of a process takes the same kernel, so bit-identity between routes holds.
+// Reference work being replaced: model/sublayers.py:311-352 (QaN block + cross-attention + the two LayerNorms around them).
+// ------------------------------------------------------------------------------------
+struct Row32 {
+    float4 c[2];                                  // lane l32 of a row's 32 lanes owns the 4-float chunks l32 and 32 + l32
+};
+#define IDF_SWZ_XOR16(v) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F))      // lane i <- lane i ^ 16 (bit-mask mode: and 0x1f, or 0, xor 0x10)
+__device__ __forceinline__ float row32_sum(float v) {
+    v = row16_sum(v);
+    return v + IDF_SWZ_XOR16(v);
+}
+template <int NP>
+struct Row32Raw {
+    float4 t[2][NP];
+    __device__ __forceinline__ void request(const float *__restrict__ row, int l32, size_t stride) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) t[i][s] = ld4(row + s * stride + (i * 32 + l32) * 4);
+    }
+    __device__ __forceinline__ void reduce(Row32 &r) const {      // slabs summed in the order of common.h ld4_sum
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = t[i][0];
+#pragma unroll
+            for (int s = 1; s < NP; ++s) { v.x += t[i][s].x; v.y += t[i][s].y; v.z += t[i][s].z; v.w += t[i][s].w; }
+            r.c[i] = v;
+        }
+    }
+};
+__device__ __forceinline__ void ln_row32_lds(Row32 &r, const float *w, const float *b, int l32) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sum += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
+    const float mean = row32_sum(sum) * (1.0f / 256.0f);
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
+        qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = __builtin_amdgcn_rsqf(row32_sum(qv) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 g = *reinterpret_cast<const float4 *>(w + (i * 32 + l32) * 4), be = *reinterpret_cast<const float4 *>(b + (i * 32 + l32) * 4);
+        r.c[i].x = (r.c[i].x - mean) * rstd * g.x + be.x;
+        r.c[i].y = (r.c[i].y - mean) * rstd * g.y + be.y;
+        r.c[i].z = (r.c[i].z - mean) * rstd * g.z + be.z;
+        r.c[i].w = (r.c[i].w - mean) * rstd * g.w + be.w;
+    }
+}
+__device__ __forceinline__ void row32_load(Row32 &r, const float *row, int l32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * 32 + l32) * 4);
+}
+__device__ __forceinline__ void row32_store(const Row32 &r, float *row, int l32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(row + (i * 32 + l32) * 4) = r.c[i];
+}
+__device__ __forceinline__ void row32_store_wt(const Row32 &r, float *row, int l32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) idf_store16_wt(row + (i * 32 + l32) * 4, r.c[i]);
+}
+__device__ __forceinline__ void row32_zero(Row32 &r) { r.c[0] = r.c[1] = zero4(); }
+__device__ __forceinline__ void row32_store_planes(const Row32 &r, _Float16 *hi_row, _Float16 *lo_row, int l32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint2 h, l;
+        idf_ffn_h2::split4_pk(r.c[i], h, l);
+        *reinterpret_cast<uint2 *>(hi_row + (i * 32 + l32) * 4) = h;
+        *reinterpret_cast<uint2 *>(lo_row + (i * 32 + l32) * 4) = l;
+    }
+}
+
+template <bool QAN, int NP, int MS = MEM>
+__global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
+                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
+                                                        const float *__restrict__ wk, const float *__restrict__ ln1_w,
+                                                        const float *__restrict__ ln1_b, const float *__restrict__ G,
+                                                        const float *__restrict__ g0, const float *__restrict__ VWT,
+                                                        const float *__restrict__ bout, const float *__restrict__ ln2_w,
+                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
+                                                        size_t u_pstride, const float *__restrict__ sa_resid, const float *__restrict__ sa_bias,
+                                                        const float *__restrict__ h2_scale, int mem_len) {
+    using idf_ffn_h2::h8;
+    using ML = MemLay<MS>;
+    constexpr int NCT = ML::NCT, NSLOT = ML::NSLOT, NW8 = 8, NPT = NCT > 3 ? NCT : 3;
+    constexpr int XS = QAN ? (TR + 2) * RS : 0;
+    constexpr int HS = D + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16), PHS = 64 + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16);     // plane strides: conflict-free fragment reads (rowblock_kernel)
+    const int mlen = ML::GEN ? mem_len : MEM;
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * (TR + 2) * HS];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores
+    __shared__ __attribute__((aligned(16))) _Float16 ppl[2 * TR * PHS];            // [hi | lo'][TR][PHS]: probabilities, unwritten columns stay zero
+    _Float16 *const xh = xpl, *const xl = xpl + (TR + 2) * HS, *const ph = ppl, *const pl = ppl + TR * PHS;
+    __shared__ __attribute__((aligned(1024))) float prm[8 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias + self-attention output bias (DMA targets)
+    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + NW8 * NPT * 256];
+    float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
+    float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
+    float *part = x1s + TR * RS;                  // [8 waves][3 taps | NCT score tiles][16x16] K-split partial tiles
+
+    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, u_pstride, sa_resid, sa_bias, h2_scale, mem_len, gridDim.x, gridDim.y);
+    asm volatile("" ::: "v255");                  // EXCLUSIVE CU (ffn_h2.h): 2 waves per SIMD x 256 registers = the register file; the launcher tops the LDS up to 160 KiB
+    const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int rg = tid >> 5, l32 = tid & 31;      // row passes: token row rg of the 16, lane l32 of its 32
+    const size_t rowbase = (size_t)b * T;
+    const float *Gb = G + (size_t)b * ML::G_H2, *g0b = g0 + b * ML::G0N, *VWTb = VWT + (size_t)b * VW_H2;
+    for (int i = tid; i < 2 * TR * PHS / 8; i += 512) reinterpret_cast<float4 *>(ppl)[i] = zero4();
+
+    // ---- first batch of requests (pinned order, the wait below counts): shared vectors by DMA, scalars, token rows, then -- youngest -- the learned-query fragments
+    {
+        const float *srcs[8] = {lnp_w ? lnp_w : ln1_w, lnp_w ? lnp_b : ln1_b, ln1_w, ln1_b, ln2_w, ln2_b, bout, sa_bias ? sa_bias : ln1_b};
+        const uint32_t prm_lds = idf_lds_addr(prm);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
+    }
+    Row32 ra, rb;
+    float4 q[2][3], gv[2][NCT], vw2[2][2][2];     // plane fragments: q[plane][tap], gv[plane][column tile] of this wave's K step; vw2[K step][tile][plane] of its two output tiles
+    float wk_n = 0.f, g0v[NSLOT];
+    const float gsc = h2_scale[2 * b], vsc = h2_scale[2 * b + 1];
+    const int hh = wave & 3;                      // head softmax: waves 0..3, wave = head
+    const int ta = QAN ? t0 - 1 + rg : t0 + rg, tb = t0 + 15 + (lane >> 5);
+    const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && tb < T;
+    Row32Raw<NP> raw_a, raw_b;
+    Row32Raw<1> raw_r;
+    if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) g0v[i] = g0b[ML::col(hh, min((lane & 3) + 4 * i, mlen - 1))];
+    if constexpr (QAN) {
+        if (wave == 0) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, l32, u_pstride);     // halo rows t0+15, t0+16: the two halves of wave 0
+    }
+    raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, l32, u_pstride);
+    if constexpr (!QAN) {
+        if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, l32, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (QAN) {
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q[p2][j] = zero4();
+        if (li < NQ) {                            // [K eighth = wave][tap][plane][kq][NQ][8 halves]
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) q[p2][j] = ld4(Qc + ((((wave * 3 + j) * 2 + p2) * 4 + kq) * NQ + li) * 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (QAN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // everything older than the six learned-query fragment loads has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    raw_a.reduce(ra);
+    if constexpr (QAN) {
+        if (wave == 0) raw_b.reduce(rb);
+    }
+    const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
+                *P_bout = prm + 1536, *P_sab = prm + 1792;
+    auto fetch_g = [&]() {                        // [K eighth = wave][column tile][plane][lane][8 halves]
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) gv[p2][ct] = ld4(Gb + ((((wave * NCT + ct) * 2 + p2) * 64) + lane) * 4);
+    };
+    auto fetch_vw = [&]() {                       // [output column quarter = wave >> 1][K step][column tile 2 (wave & 1) + c][plane][lane][8 halves]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) vw2[s2][c][p2] = ld4(VWTb + ((((((wave >> 1) * 2 + s2) * 4 + 2 * (wave & 1) + c) * 2 + p2) * 64) + lane) * 4);
+    };
+
+    if constexpr (QAN) {
+        if (lnp_w) {
+            ln_row32_lds(ra, P_lnp_w, P_lnp_b, l32);
+            if (wave == 0) ln_row32_lds(rb, P_lnp_w, P_lnp_b, l32);
+        }
+        if (!va) row32_zero(ra);
+        if (!vb) row32_zero(rb);
+        row32_store(ra, xs + rg * RS, l32);
+        row32_store_planes(ra, xh + rg * HS, xl + rg * HS, l32);
+        if (wave == 0) {
+            row32_store(rb, xs + (16 + (lane >> 5)) * RS, l32);
+            row32_store_planes(rb, xh + (16 + (lane >> 5)) * HS, xl + (16 + (lane >> 5)) * HS, l32);
+        }
+        fetch_g();
+        __syncthreads();
+        {   // logits: three 16x16 tiles (taps), this wave contracts K = [32 wave, 32 wave + 32)
+            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_c[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const int koff = 32 * wave + 8 * kq;
+            h8 ah[3], al[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ah[j] = *reinterpret_cast<const h8 *>(xh + (li + j) * HS + koff);
+                al[j] = *reinterpret_cast<const h8 *>(xl + (li + j) * HS + koff);
+            }
+            mma_h2<3>(acc, acc_c, ah, al, q[0], q[1]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * 256 + (kq * 4 + r) * 16 + li] = acc[j][r] + acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
+        }
+        fetch_vw();
+        __syncthreads();
+        float c0, c1, c2;
+        {   // tap softmax + coefficients: both 16-lane halves of a row compute them (query n = l32 & 15), so no exchange is needed before the stencil
+            const int n = min(l32 & 15, NQ - 1);
+            float l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float *pp = part + j * 256 + rg * 16 + n;
+                l[j] = ((pp[0 * 768] + pp[1 * 768]) + (pp[2 * 768] + pp[3 * 768])) + ((pp[4 * 768] + pp[5 * 768]) + (pp[6 * 768] + pp[7 * 768]));
+            }
+            const int tg = t0 + rg;
+            if (tg <= 0) l[0] = -FLT_MAX;
+            if (tg + 1 >= T) l[2] = -FLT_MAX;
+            const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
+            const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
+            const float w = (l32 & 15) < NQ ? wk_n / (e0 + e1 + e2) : 0.f;
+            c0 = row16_sum(w * e0);
+            c1 = row16_sum(w * e1);
+            c2 = row16_sum(w * e2);
+        }
+        {   // u1 = x_t + sum_j c_j x_{t+j-1} ;  x1 = LN1(u1)
+            Row32 xm, xc, xp;
+            row32_load(xm, xs + rg * RS, l32);
+            row32_load(xc, xs + (rg + 1) * RS, l32);
+            row32_load(xp, xs + (rg + 2) * RS, l32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xc.c[i].x = xc.c[i].x + (c0 * xm.c[i].x + c1 * xc.c[i].x + c2 * xp.c[i].x);
+                xc.c[i].y = xc.c[i].y + (c0 * xm.c[i].y + c1 * xc.c[i].y + c2 * xp.c[i].y);
+                xc.c[i].z = xc.c[i].z + (c0 * xm.c[i].z + c1 * xc.c[i].z + c2 * xp.c[i].z);
+                xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
+            }
+            ln_row32_lds(xc, P_ln1_w, P_ln1_b, l32);
+            row32_store_planes(xc, xh + rg * HS, xl + rg * HS, l32);      // (the logits' reads of these planes ended at the barrier above)
+            row32_store(xc, x1s + rg * RS, l32);
+        }
+    } else {
+        if (sa_resid) {                               // u1 = (head partials) + xn + b_o   (workgroup-uniform branch)
+            Row32 rr;
+            raw_r.reduce(rr);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 bo = *reinterpret_cast<const float4 *>(P_sab + (i * 32 + l32) * 4);
+                ra.c[i].x += rr.c[i].x + bo.x;
+                ra.c[i].y += rr.c[i].y + bo.y;
+                ra.c[i].z += rr.c[i].z + bo.z;
+                ra.c[i].w += rr.c[i].w + bo.w;
+            }
+        }
+        if (!va) row32_zero(ra);
+        fetch_g();
+        fetch_vw();
+        ln_row32_lds(ra, P_ln1_w, P_ln1_b, l32);
+        row32_store_planes(ra, xh + rg * HS, xl + rg * HS, l32);
+        row32_store(ra, x1s + rg * RS, l32);
+    }
+    __syncthreads();
+    {   // folded cross-attention scores: NCT 16x16 tiles, this wave's K step
+        f32x4 acc[NCT], acc_c[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = acc_c[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int koff = 32 * wave + 8 * kq;
+        const h8 a_h = *reinterpret_cast<const h8 *>(xh + li * HS + koff), a_l = *reinterpret_cast<const h8 *>(xl + li * HS + koff);
+        h8 ah[NCT], al[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { ah[ct] = a_h; al[ct] = a_l; }
+        mma_h2<NCT>(acc, acc_c, ah, al, gv[0], gv[1]);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * NCT + ct) * 256 + (kq * 4 + r) * 16 + li] = (acc[ct][r] + acc_c[ct][r] * idf_ffn_h2::LO_UNSCALE) * gsc;      // G[b] was divided by gsc (a power of two)
+    }
+    __syncthreads();
+    if (wave < 4) {   // softmax over the memory slots of each head: wave = head, token = lane >> 2, the four lanes of a quad take slots q, q+4, ... (rowblock_kernel)
+        const int tq = lane >> 2, qd = lane & 3;
+        float sc[NSLOT], mx = -FLT_MAX;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int m = qd + 4 * i, idx = ML::col(wave, min(m, mlen - 1)), ct = idx >> 4, cl = idx & 15;
+            const float *pp = part + ct * 256 + tq * 16 + cl;
+            constexpr int WS8 = NCT * 256;
+            const float v = (((pp[0 * WS8] + pp[1 * WS8]) + (pp[2 * WS8] + pp[3 * WS8])) + ((pp[4 * WS8] + pp[5 * WS8]) + (pp[6 * WS8] + pp[7 * WS8]))) + g0v[i];
+            sc[i] = m < mlen ? v : -FLT_MAX;
+            mx = fmaxf(mx, sc[i]);
+        }
+        mx = fmaxf(mx, IDF_QUAD_XOR1(mx));
+        mx = fmaxf(mx, IDF_QUAD_XOR2(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            sc[i] = qd + 4 * i < mlen ? __expf(sc[i] - mx) : 0.f;
+            sum += sc[i];
+        }
+        sum += IDF_QUAD_XOR1(sum);
+        sum += IDF_QUAD_XOR2(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i)
+            if (qd + 4 * i < (ML::GEN ? MEMX : MEM)) {
+                _Float16 hv, lv;
+                idf_ffn_h2::split1_nf(qd + 4 * i < mlen ? sc[i] * inv : 0.f, hv, lv);
+                ph[tq * PHS + ML::col(wave, qd + 4 * i)] = hv;
+                pl[tq * PHS + ML::col(wave, qd + 4 * i)] = lv;
+            }
+    }
+    __syncthreads();
+    {   // u2 = x1 + P.VW + b_out : wave w owns output columns [32 w, 32 w + 32)
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const h8 p_h = *reinterpret_cast<const h8 *>(ph + li * PHS + 32 * s2 + 8 * kq), p_l = *reinterpret_cast<const h8 *>(pl + li * PHS + 32 * s2 + 8 * kq);
+            const h8 ah[2] = {p_h, p_h}, al[2] = {p_l, p_l};
+            const float4 bh[2] = {vw2[s2][0][0], vw2[s2][1][0]}, bl[2] = {vw2[s2][0][1], vw2[s2][1][1]};
+            mma_h2<2>(acc, acc_c, ah, al, bh, bl);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = (wave * 2 + c) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] += (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc + P_bout[col];       // VW[b] was divided by vsc
+        }
+    }
+    __syncthreads();
+    {
+        const int t = t0 + rg;
+        Row32 r;
+        row32_load(r, x1s + rg * RS, l32);
+        ln_row32_lds(r, P_ln2_w, P_ln2_b, l32);
+        if (t < T) row32_store_wt(r, x2_out + (rowbase + t) * D, l32);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Temporal self-attention of the two standard layers: softmax(Q K^T / 8) V per (clip, head), on the MFMA.
 // grid (ceil(T/QT), H, B), 256 threads.  LDS: K,V [TP][68], Q [QT][68], S [QT][TP+4]; TP = T rounded up to 16, QT = 16 or 32 query rows.
 // ------------------------------------------------------------------------------------
-constexpr int AS = HD + 4;
+constexpr int AS = HD + 4;            // row stride (floats) of the V image: its P.V operand reads are scalar (4 k rows x 16 columns per instruction: 68 keeps the four 16-lane groups on disjoint banks)
+constexpr int SPAD = IDF_LDS_STRIDE_SET == 4 ? 4 : 8;         // padding of a score row (floats)
+constexpr int ASK = HD + SPAD;        // row stride of the Q and K images: their S = Q K^T operands are ds_read_b128 of lane (li, kq) -> row li, slot s0 + kq, and a stride of 2 slots mod 16
+                                      // makes those conflict-free (see the row block's HS; round 4 used 68 for all three: every Q / K fragment read took twice its LDS cycles)
 constexpr int ATTN_MAX_T = 208;
 #ifndef IDF_ATTN_RT
 #define IDF_ATTN_RT 1
@@ -568,9 +955,9 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     extern __shared__ __attribute__((aligned(16))) float smx[];
     idf_args_now(qkv, ctx, T, wo_frag, slabs, pstride, gridDim.x);
     IDF_AT_STAMP(0);
-    const int TP = (T + 15) & ~15, SS = TP + 4;
+    const int TP = (T + 15) & ~15, SS = TP + SPAD;       // (TP + 8: the same 2-slots-mod-16 rule for the P.V A-operand reads of the score rows)
     constexpr int QT = 16 * RT;
-    float *Ks = smx, *Vs = Ks + TP * AS, *Qs = Vs + TP * AS, *Ss = Qs + QT * AS;
+    float *Ks = smx, *Vs = Ks + TP * ASK, *Qs = Vs + TP * AS, *Ss = Qs + QT * ASK;
     const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
@@ -597,7 +984,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
         for (int u = 0; u < 8; ++u) {
             const int i = tid + 256 * (it0 + u), j = i >> 4, d4 = (i & 15) * 4;
             if (it0 + u < nsweep) {                                    // workgroup-uniform
-                *reinterpret_cast<float4 *>(Ks + j * AS + d4) = j < T ? kreg[u] : zero4();
+                *reinterpret_cast<float4 *>(Ks + j * ASK + d4) = j < T ? kreg[u] : zero4();
                 *reinterpret_cast<float4 *>(Vs + j * AS + d4) = j < T ? vreg[u] : zero4();
             }
         }
@@ -613,7 +1000,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 #pragma unroll
     for (int u = 0; u < RT; ++u) {
         const int i = tid + 256 * u, r = i >> 4, d4 = (i & 15) * 4;
-        *reinterpret_cast<float4 *>(Qs + r * AS + d4) = q0 + r < T ? qreg[u] : zero4();
+        *reinterpret_cast<float4 *>(Qs + r * ASK + d4) = q0 + r < T ? qreg[u] : zero4();
     }
     __syncthreads();
     IDF_AT_STAMP(1);                                     // K, V, Q in LDS
@@ -625,10 +1012,10 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
             const int koff = 16 * s + 4 * kq;
-            const float4 kv = ld4(Ks + (ct * 16 + li) * AS + koff);
+            const float4 kv = ld4(Ks + (ct * 16 + li) * ASK + koff);
             float4 a[RT], bb[RT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) { a[rt] = ld4(Qs + (rt * 16 + li) * AS + koff); bb[rt] = kv; }
+            for (int rt = 0; rt < RT; ++rt) { a[rt] = ld4(Qs + (rt * 16 + li) * ASK + koff); bb[rt] = kv; }
             mma_rounds<RT>(acc, a, bb);
         }
 #pragma unroll
@@ -721,7 +1108,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Qs[(rt * 16 + kq * 4 + r) * AS + dcol] = acc[rt][r];
+                for (int r = 0; r < 4; ++r) Qs[(rt * 16 + kq * 4 + r) * ASK + dcol] = acc[rt][r];
         }
     }
     IDF_AT_STAMP(4);                                     // P V (+ store)
@@ -736,7 +1123,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
             float4 a[4 * RT], bb[4 * RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float4 av = ld4(Qs + (rt * 16 + li) * AS + koff);
+                const float4 av = ld4(Qs + (rt * 16 + li) * ASK + koff);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { a[rt * 4 + c] = av; bb[rt * 4 + c] = wo[sidx][c]; }
             }
@@ -758,9 +1145,124 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// Clips longer than ATTN_MAX_T frames: the same attention with K / V streamed through LDS in tiles of 64 keys and a running row maximum / sum
+// ("flash" form), fp32 MFMA, the out-projection partial in its tail like self_attn_kernel<true, 1>.  The one-shot kernel parks K and V of a whole
+// (clip, head) in LDS (149 KiB at T = 208); the reference's own bound is its positional table, PositionalEncoding(max_len = 5000) (model/layers.py:10).
+// A correct path for every length the table allows, not a tuned one: per key tile four barriers and one pass over S; the shipped shapes never take it.
+// grid (ceil(T/16), H, B), 256 threads; static LDS ~45 KiB.
+// ------------------------------------------------------------------------------------
+constexpr int KT = 64;                       // keys per tile
+__global__ __launch_bounds__(256) void self_attn_tiled_kernel(const float *__restrict__ qkv, int T, const float *__restrict__ wo_frag,
+                                                              float *__restrict__ slabs, size_t pstride) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * ASK], Vs[KT * AS], Qs[16 * ASK], Ss[16 * (KT + 8)];
+    __shared__ float m_run[16], l_run[16], alpha[16];
+    constexpr int SS = KT + 8;
+    idf_args_now(qkv, T, wo_frag, slabs, pstride, gridDim.x);
+    const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * 16, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const size_t rowbase = (size_t)b * T;
+    float4 wo[4][4];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wo[sidx][c] = ld4(wo_frag + ((((size_t)(h * 4 + wave) * 4 + sidx) * 4 + c) * 64 + lane) * 4);
+    {   // the 16 query rows (zero past the clip), running statistics
+        const int r = tid >> 4, d4 = (tid & 15) * 4;
+        const float4 qv = ld4(qkv + (rowbase + min(q0 + r, T - 1)) * (3 * D) + h * HD + d4);
+        *reinterpret_cast<float4 *>(Qs + r * ASK + d4) = q0 + r < T ? qv : zero4();
+        if (tid < 16) { m_run[tid] = -FLT_MAX; l_run[tid] = 0.f; }
+    }
+    f32x4 o_acc = {0.f, 0.f, 0.f, 0.f};                  // O[16 queries][16 head-dim columns of this wave]: lane (li = column, kq) holds rows 4 kq .. 4 kq + 3
+    const int dcol = wave * 16 + li;
+    for (int k0 = 0; k0 < T; k0 += KT) {
+        __syncthreads();                                 // the previous tile's P.V reads of Ks / Vs / Ss are done (first pass: Qs, statistics written)
+#pragma unroll
+        for (int u = 0; u < KT / 16; ++u) {
+            const int i = tid + 256 * u, j = i >> 4, d4 = (i & 15) * 4;
+            const float *src = qkv + (rowbase + min(k0 + j, T - 1)) * (3 * D) + h * HD + d4;
+            const float4 kv = ld4(src + D), vv = ld4(src + 2 * D);
+            *reinterpret_cast<float4 *>(Ks + j * ASK + d4) = k0 + j < T ? kv : zero4();
+            *reinterpret_cast<float4 *>(Vs + j * AS + d4) = k0 + j < T ? vv : zero4();
+        }
+        __syncthreads();
+        {   // S tile = Q K^T / 8: wave w owns key tile w of the four
+            f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int sg = 0; sg < HD / 16; ++sg) {
+                const int koff = 16 * sg + 4 * kq;
+                const float4 a[1] = {ld4(Qs + li * ASK + koff)}, bb[1] = {ld4(Ks + (wave * 16 + li) * ASK + koff)};
+                mma_rounds<1>(acc, a, bb);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ss[(kq * 4 + r) * SS + wave * 16 + li] = k0 + wave * 16 + li < T ? acc[0][r] * 0.125f : -FLT_MAX;
+        }
+        __syncthreads();
+        {   // running softmax: the 16-lane group of row i holds columns li, 16 + li, 32 + li, 48 + li of the tile
+            const int i = wave * 4 + kq;
+            float *row = Ss + i * SS;
+            float v[4], mx = -FLT_MAX;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] = row[16 * c + li]; mx = fmaxf(mx, v[c]); }
+            mx = row16_max(mx);
+            const float m_old = m_run[i], m_new = fmaxf(m_old, mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] = k0 + 16 * c + li < T ? __expf(v[c] - m_new) : 0.f;
+                sum += v[c];
+                row[16 * c + li] = v[c];
+            }
+            sum = row16_sum(sum);
+            if (li == 0) {
+                const float al = __expf(m_old - m_new);     // first tile: exp(-FLT_MAX - m) = 0
+                alpha[i] = al;
+                l_run[i] = l_run[i] * al + sum;
+                m_run[i] = m_new;
+            }
+        }
+        __syncthreads();
+        {   // O = O alpha + P V
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_acc[r] *= alpha[kq * 4 + r];
+            f32x4 acc[1] = {o_acc};
+#pragma unroll
+            for (int sg = 0; sg < KT / 16; ++sg) {
+                const int koff = 16 * sg + 4 * kq;
+                const float *vp = Vs + koff * AS + dcol;
+                const float4 a[1] = {ld4(Ss + li * SS + koff)}, bb[1] = {make_float4(vp[0], vp[AS], vp[2 * AS], vp[3 * AS])};
+                mma_rounds<1>(acc, a, bb);
+            }
+            o_acc = acc[0];
+        }
+    }
+    __syncthreads();                                     // every wave is past its reads of Qs (S phase of the last tile)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Qs[(kq * 4 + r) * ASK + dcol] = o_acc[r] * __builtin_amdgcn_rcpf(l_run[kq * 4 + r]);       // context tile, A-operand (row-major) form
+    __syncthreads();
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const float4 av = ld4(Qs + li * ASK + 16 * sidx + 4 * kq);
+        const float4 a[4] = {av, av, av, av};
+        mma_rounds<4>(o, a, wo[sidx]);
+    }
+    float *slab = slabs + (size_t)h * pstride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = q0 + kq * 4 + r;
+        if (t < T) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) idf_store4_wt(slab + (rowbase + t) * D + (wave * 4 + c) * 16 + li, o[c][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Per-sample memory folding (interdiff_mdm_prepare_memory)
 // ------------------------------------------------------------------------------------
-// kv[l][r][c] = cond[r][:] . Wkv_l[c][:] + bkv_l[c];  r = m*B + b (reference layout [MEM,B,D]), c < 512
+// kv[l][r][c] = cond[r][:] . Wkv_l[c][:] + bkv_l[c];  r = m*B + b (reference layout [mem_len,B,D]), c < 512
 __global__ __launch_bounds__(256) void mem_kv_kernel(const float *__restrict__ arena, const idf_mdm_weights w,
                                                      const float *__restrict__ cond, int R, float *__restrict__ kv) {
     const int l = blockIdx.z, r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
@@ -776,25 +1278,30 @@ __global__ __launch_bounds__(256) void mem_kv_kernel(const float *__restrict__ a
     kv[((size_t)l * R + r) * 512 + c] = s + arena[w.layer[l].ca_kv_b + c];
 }
 
-// fragment order of the fp32 forms (see G_FRAG): the reader's lane is kq * 16 + li
-__device__ __forceinline__ int g_slot(int col, int k) {            // score column col (0..47), feature k (0..255)
+// fragment order of the fp32 forms (see G_FRAG): the reader's lane is kq * 16 + li; NCT = column tiles of the layout (MemLay)
+template <int NCT>
+__device__ __forceinline__ int g_slot(int col, int k) {            // score column col (0 .. 16 NCT - 1), feature k (0..255)
     const int ks = k >> 4, kq = (k >> 2) & 3, e = k & 3, ct = col >> 4, li = col & 15;
-    return ((ks * 3 + ct) * 64 + kq * 16 + li) * 4 + e;
+    return ((ks * NCT + ct) * 64 + kq * 16 + li) * 4 + e;
 }
-__device__ __forceinline__ int vw_slot(int o, int col) {           // output feature o (0..255), probability column col (0..47)
+template <int NCT>
+__device__ __forceinline__ int vw_slot(int o, int col) {           // output feature o (0..255), probability column col (0 .. 16 NCT - 1)
     const int wave = o >> 6, c = (o >> 4) & 3, li = o & 15, sidx = col >> 4, kq = (col >> 2) & 3, e = col & 3;
-    return (((wave * (HMP / 16) + sidx) * 4 + c) * 64 + kq * 16 + li) * 4 + e;
+    return (((wave * NCT + sidx) * 4 + c) * 64 + kq * 16 + li) * 4 + e;
 }
 
 // G[l][b][h*MEM+m][i] = 1/8 sum_d Wq[h*64+d][i] K[m,b][h*64+d];  g0 = 1/8 sum_d bq[h*64+d] K[..]
 // VWT[l][b][o][h*MEM+m] = sum_d V[m,b][h*64+d] Wo[o][h*64+d]   (columns 40..47 zero)
-// grid (HM, B, L), 256 threads (thread = i / o)
+// grid (H * mem_len, B, L), 256 threads (thread = i / o).  Generic layout (MS == MEMX): the buffers were zeroed by the caller, only the columns of present slots are written.
+template <int MS>
 __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__ arena, const idf_mdm_weights w,
                                                        const float *__restrict__ kv, int B, float *__restrict__ G,
-                                                       float *__restrict__ g0, float *__restrict__ VWT) {
-    const int hm = blockIdx.x, b = blockIdx.y, l = blockIdx.z, h = hm / MEM, m = hm - h * MEM, i = threadIdx.x;
+                                                       float *__restrict__ g0, float *__restrict__ VWT, int mem_len) {
+    using ML = MemLay<MS>;
+    const int mlen = ML::GEN ? mem_len : MEM;
+    const int hm = blockIdx.x, b = blockIdx.y, l = blockIdx.z, h = hm / mlen, m = hm - h * mlen, i = threadIdx.x, col = ML::col(h, m);
     __shared__ float kd[HD], vd[HD];
-    const float *row = kv + ((size_t)l * (MEM * B) + (size_t)m * B + b) * 512;
+    const float *row = kv + ((size_t)l * (mlen * B) + (size_t)m * B + b) * 512;
     if (i < HD) kd[i] = row[h * HD + i];
     else if (i < 2 * HD) vd[i - HD] = row[D + h * HD + (i - HD)];
     __syncthreads();
@@ -804,17 +1311,17 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
         sg += Wq[(size_t)(h * HD + d) * D + i] * kd[d];
         sv += vd[d] * Wo[(size_t)i * D + h * HD + d];
     }
-    float *Gf = G + ((size_t)l * B + b) * G_FRAG, *Vf = VWT + ((size_t)l * B + b) * D * HMP;
-    Gf[g_slot(hm, i)] = sg * 0.125f;
-    Vf[vw_slot(i, hm)] = sv;
-    if (hm < HMP - HM) {
-        Gf[g_slot(HM + hm, i)] = 0.f;
-        Vf[vw_slot(i, HM + hm)] = 0.f;
+    float *Gf = G + ((size_t)l * B + b) * ML::G_FRAG, *Vf = VWT + ((size_t)l * B + b) * ML::VWT_F;
+    Gf[g_slot<ML::NCT>(col, i)] = sg * 0.125f;
+    Vf[vw_slot<ML::NCT>(i, col)] = sv;
+    if (!ML::GEN && hm < HMP - HM) {
+        Gf[g_slot<ML::NCT>(HM + hm, i)] = 0.f;
+        Vf[vw_slot<ML::NCT>(i, HM + hm)] = 0.f;
     }
     if (i == 0) {
         float s = 0.f;
         for (int d = 0; d < HD; ++d) s += bq[h * HD + d] * kd[d];
-        g0[((size_t)l * B + b) * HM + hm] = s * 0.125f;
+        g0[((size_t)l * B + b) * ML::G0N + col] = s * 0.125f;
     }
 }
 
@@ -822,14 +1329,17 @@ __global__ __launch_bounds__(256) void mem_fold_kernel(const float *__restrict__
 // weights), so each (layer, clip) matrix is divided by a power of two that puts its largest magnitude in [2^13, 2^14) -- exact, the f16 pair then keeps
 // 22 bits of every element down to 2^-27 of the largest -- and the row block multiplies the fp32 result back (sc[l][b] = {2^eG, 2^eV}).
 // grid (B, L), 256 threads; once per sample.
+template <int MS>
 __global__ __launch_bounds__(256) void mem_fold_h2_kernel(const float *__restrict__ G, const float *__restrict__ VWT, int B,
                                                           float *__restrict__ Gh2, float *__restrict__ VWh2, float *__restrict__ sc) {
+    using ML = MemLay<MS>;
+    constexpr int NCT = ML::NCT, HMPX = ML::HMPX;
     const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
-    const float *Gf = G + ((size_t)l * B + b) * G_FRAG, *Vf = VWT + ((size_t)l * B + b) * D * HMP;
+    const float *Gf = G + ((size_t)l * B + b) * ML::G_FRAG, *Vf = VWT + ((size_t)l * B + b) * ML::VWT_F;
     __shared__ float red[2][256];
     float ag = 0.f, av = 0.f;
-    for (int i = tid; i < G_FRAG; i += 256) ag = fmaxf(ag, fabsf(Gf[i]));
-    for (int i = tid; i < D * HMP; i += 256) av = fmaxf(av, fabsf(Vf[i]));
+    for (int i = tid; i < ML::G_FRAG; i += 256) ag = fmaxf(ag, fabsf(Gf[i]));
+    for (int i = tid; i < ML::VWT_F; i += 256) av = fmaxf(av, fabsf(Vf[i]));
     red[0][tid] = ag;
     red[1][tid] = av;
     __syncthreads();
@@ -843,16 +1353,16 @@ __global__ __launch_bounds__(256) void mem_fold_h2_kernel(const float *__restric
     // amax 2^-e in [2^13, 2^14); a matrix of zeros (or non-finite values, which then stay what they are) is left alone
     const int eg = (red[0][0] > 0.f && red[0][0] < INFINITY) ? ilogbf(red[0][0]) - 13 : 0, ev = (red[1][0] > 0.f && red[1][0] < INFINITY) ? ilogbf(red[1][0]) - 13 : 0;
     const float dg = ldexpf(1.0f, -eg), dv = ldexpf(1.0f, -ev);
-    float *Go = Gh2 + ((size_t)l * B + b) * G_H2, *Vo = VWh2 + ((size_t)l * B + b) * VW_H2;
-    for (int it = tid; it < 4 * 2 * 3 * 64; it += 256) {
-        const int lane = it & 63, ct = (it >> 6) % 3, s2 = (it / 192) & 1, wv = it / 384, kq = lane >> 4, li = lane & 15;
+    float *Go = Gh2 + ((size_t)l * B + b) * ML::G_H2, *Vo = VWh2 + ((size_t)l * B + b) * VW_H2;
+    for (int it = tid; it < 4 * 2 * NCT * 64; it += 256) {
+        const int lane = it & 63, ct = (it >> 6) % NCT, s2 = (it / (64 * NCT)) & 1, wv = it / (128 * NCT), kq = lane >> 4, li = lane & 15;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Gf[g_slot(16 * ct + li, 64 * wv + 32 * s2 + 8 * kq + e)] * dg;
+        for (int e = 0; e < 8; ++e) v[e] = Gf[g_slot<NCT>(16 * ct + li, 64 * wv + 32 * s2 + 8 * kq + e)] * dg;
         uint2 h0, l0, h1, l1;
         idf_ffn_h2::split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
         idf_ffn_h2::split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
-        uint4 *dst = reinterpret_cast<uint4 *>(Go) + (((wv * 2 + s2) * 3 + ct) * 2) * 64 + lane;
+        uint4 *dst = reinterpret_cast<uint4 *>(Go) + (((wv * 2 + s2) * NCT + ct) * 2) * 64 + lane;
         dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
         dst[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
@@ -862,7 +1372,7 @@ __global__ __launch_bounds__(256) void mem_fold_h2_kernel(const float *__restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int col = 32 * s2 + 8 * kq + e;
-            v[e] = col < HMP ? Vf[vw_slot(64 * wv + 16 * c + li, min(col, HMP - 1))] * dv : 0.f;
+            v[e] = col < HMPX ? Vf[vw_slot<NCT>(64 * wv + 16 * c + li, min(col, HMPX - 1))] * dv : 0.f;
         }
         uint2 h0, l0, h1, l1;
         idf_ffn_h2::split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
@@ -881,13 +1391,22 @@ __global__ __launch_bounds__(256) void mem_fold_h2_kernel(const float *__restric
 int attn_opt_in() {
     static std::atomic<uint64_t> lds_ok{0};
     static std::atomic<uint64_t> lds_ok_op{0};
-    const int bytes = (int)(((size_t)2 * ATTN_MAX_T * AS + 32 * AS + 32 * (ATTN_MAX_T + 4)) * sizeof(float));
+    const int bytes = (int)(((size_t)ATTN_MAX_T * (ASK + AS) + 32 * ASK + 32 * (ATTN_MAX_T + SPAD)) * sizeof(float));
     const int rc = idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel<false, 2>), bytes, lds_ok);
     return rc != IDF_OK ? rc : idf_opt_in_lds(reinterpret_cast<const void *>(self_attn_kernel<true, ATTN_RT>), bytes, lds_ok_op);
 }
 inline size_t attn_lds_bytes(int T, int rt) {
     const int TP = (T + 15) & ~15;
-    return ((size_t)2 * TP * AS + 16 * rt * AS + 16 * rt * (TP + 4)) * sizeof(float);
+    return ((size_t)TP * (ASK + AS) + 16 * rt * ASK + 16 * rt * (TP + SPAD)) * sizeof(float);
+}
+
+// self-attention + out-projection partials of one standard layer: the one-shot kernel up to ATTN_MAX_T frames, the K/V-tiled one beyond
+inline void launch_self_attn_outproj(hipStream_t s, const float *qkv, int B, int T, const float *wo_frag, float *parts, size_t pstride) {
+    if (T <= ATTN_MAX_T)
+        hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s, qkv, nullptr, T,
+                           wo_frag, parts, pstride);
+    else
+        hipLaunchKernelGGL(self_attn_tiled_kernel, dim3((unsigned)idf_cdiv(T, 16), H, B), dim3(256), 0, s, qkv, T, wo_frag, parts, pstride);
 }
 
 struct Ws {
@@ -1003,42 +1522,68 @@ extern "C" int interdiff_gemm_f32(const float *A, int32_t lda, const float *W, c
 struct MemCtx {
     const float *G, *VWT, *g0, *Gh2, *VWh2, *sc;
 };
+template <int MS>
 static inline MemCtx memctx_carve(const float *m, int B) {
+    using ML = MemLay<MS>;
     MemCtx c;
     c.G = m;
-    c.VWT = c.G + (size_t)L * B * G_FRAG;
-    c.g0 = c.VWT + (size_t)L * B * D * HMP;
-    c.Gh2 = c.g0 + (size_t)L * B * HM;
-    c.VWh2 = c.Gh2 + (size_t)L * B * G_H2;
+    c.VWT = c.G + (size_t)L * B * ML::G_FRAG;
+    c.g0 = c.VWT + (size_t)L * B * ML::VWT_F;
+    c.Gh2 = c.g0 + (size_t)L * B * ML::G0N;
+    c.VWh2 = c.Gh2 + (size_t)L * B * ML::G_H2;
     c.sc = c.VWh2 + (size_t)L * B * VW_H2;
     return c;
 }
-extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) {
-    return (size_t)L * B * (G_FRAG + D * HMP + HM + G_H2 + VW_H2 + 2);
+template <int MS>
+static inline size_t memctx_floats_t(int32_t B) {
+    using ML = MemLay<MS>;
+    return (size_t)L * B * (ML::G_FRAG + ML::VWT_F + ML::G0N + ML::G_H2 + VW_H2 + 2);
+}
+// memory length of a handle: w->mem_len (0 = the default IDF_MDM_MEM); the compact layout serves exactly IDF_MDM_MEM, the generic one every 1 .. IDF_MDM_MEM_MAX
+static inline int idf_mem_len(const idf_mdm_weights *w) { return w->mem_len ? w->mem_len : MEM; }
+extern "C" size_t interdiff_mdm_memctx_floats(int32_t B) { return memctx_floats_t<MEM>(B); }
+extern "C" size_t interdiff_mdm_memctx_floats_for(int32_t B, int32_t mem_len) {
+    if (mem_len < 1 || mem_len > MEMX) return 0;
+    return mem_len == MEM ? memctx_floats_t<MEM>(B) : memctx_floats_t<MEMX>(B);
 }
 
 extern "C" size_t interdiff_mdm_workspace_bytes(int32_t B, int32_t T) {
     const size_t N = (size_t)B * T;
     const size_t fwd = N * WS_ROW_FLOATS * sizeof(float);
-    const size_t prep = (size_t)L * MEM * B * 512 * sizeof(float);
+    const size_t prep = (size_t)L * MEMX * B * 512 * sizeof(float);         // interdiff_mdm_prepare_memory's K/V projections at the longest memory
     return idf_align(fwd > prep ? fwd : prep);
 }
 
-extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B, float *memctx,
-                                            void *ws, size_t ws_bytes, void *stream) {
-    if (!w || !cond || !memctx || !ws || B <= 0) return IDF_E_INVAL;
-    if (ws_bytes < (size_t)L * MEM * B * 512 * sizeof(float)) return IDF_E_NOMEM;
-    hipStream_t s = idf_stream(stream);
+namespace {
+template <int MS>
+int prepare_memory_t(const idf_mdm_weights *w, const float *cond, int32_t B, float *memctx, void *ws, size_t ws_bytes, hipStream_t s) {
+    const int mlen = idf_mem_len(w);
+    if (ws_bytes < (size_t)L * mlen * B * 512 * sizeof(float)) return IDF_E_NOMEM;
     float *kv = reinterpret_cast<float *>(ws);
-    const MemCtx mc = memctx_carve(memctx, B);
+    const MemCtx mc = memctx_carve<MS>(memctx, B);
     float *G = const_cast<float *>(mc.G), *VWT = const_cast<float *>(mc.VWT), *g0 = const_cast<float *>(mc.g0);
     idf_prof_mark(IDF_K_MEM_PREP, s);
-    hipLaunchKernelGGL(mem_kv_kernel, dim3(2, MEM * B, L), dim3(256), 0, s, w->arena, *w, cond, MEM * B, kv);
-    hipLaunchKernelGGL(mem_fold_kernel, dim3(HM, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VWT);
-    hipLaunchKernelGGL(mem_fold_h2_kernel, dim3(B, L), dim3(256), 0, s, G, VWT, B, const_cast<float *>(mc.Gh2), const_cast<float *>(mc.VWh2), const_cast<float *>(mc.sc));
+    if (MemLay<MS>::GEN) {       // generic layout: only the columns of present slots are written below
+        if (hipMemsetAsync(memctx, 0, memctx_floats_t<MS>(B) * sizeof(float), s) != hipSuccess) return IDF_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(mem_kv_kernel, dim3(2, mlen * B, L), dim3(256), 0, s, w->arena, *w, cond, mlen * B, kv);
+    hipLaunchKernelGGL(mem_fold_kernel<MS>, dim3(H * mlen, B, L), dim3(256), 0, s, w->arena, *w, kv, B, G, g0, VWT, mlen);
+    hipLaunchKernelGGL(mem_fold_h2_kernel<MS>, dim3(B, L), dim3(256), 0, s, G, VWT, B, const_cast<float *>(mc.Gh2), const_cast<float *>(mc.VWh2), const_cast<float *>(mc.sc));
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
+}
+}  // namespace
+
+// cond [mem_len,B,256] with mem_len = w->mem_len (0 = IDF_MDM_MEM = 10): the reference takes the memory length from the command line (eval_smpl_short.py:376
+// --past_len; model/diffusion_smpl.py:195-223 encodes that many past frames).  Length 10 -- every BASELINE config -- takes the compact layout of the folded memory
+// (40 score columns); any other length 1 .. IDF_MDM_MEM_MAX a generic one (64 columns, one 16-column tile per head, absent slots masked): same kernels, one more
+// column tile in the row block.  memctx must hold interdiff_mdm_memctx_floats_for(B, mem_len) floats.
+extern "C" int interdiff_mdm_prepare_memory(const idf_mdm_weights *w, const float *cond, int32_t B, float *memctx,
+                                            void *ws, size_t ws_bytes, void *stream) {
+    if (!w || !cond || !memctx || !ws || B <= 0 || w->mem_len < 0 || w->mem_len > MEMX) return IDF_E_INVAL;
+    return idf_mem_len(w) == MEM ? prepare_memory_t<MEM>(w, cond, B, memctx, ws, ws_bytes, idf_stream(stream))
+                                 : prepare_memory_t<MEMX>(w, cond, B, memctx, ws, ws_bytes, idf_stream(stream));
 }
 
 namespace {
@@ -1059,7 +1604,7 @@ extern "C" size_t interdiff_mdm_encode_workspace_bytes(int32_t B, int32_t Tp) {
 extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, const float *x_past, int32_t B, int32_t Tp,
                                     float *cond, void *ws, size_t ws_bytes, void *stream) {
     if (!w || !pc || !x_past || !cond || !ws || B <= 0 || Tp <= 0) return IDF_E_INVAL;
-    if (!w->has_encoder || Tp > w->max_T || Tp > ATTN_MAX_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
+    if (!w->has_encoder || Tp > w->max_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
     if (ws_bytes < interdiff_mdm_encode_workspace_bytes(B, Tp)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const float *ar = w->arena;
@@ -1085,21 +1630,20 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
         if (ly.is_qan) {
             if (u_np == NSL)
                 hipLaunchKernelGGL((rowblock_kernel<true, false, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr);
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr, nullptr, MEM);
             else
                 hipLaunchKernelGGL((rowblock_kernel<true, false, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr);
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride, nullptr, nullptr, nullptr, MEM);
         } else {
             Args g{};
             g.A = u_in; g.lda = D; g.K = D; g.lnw = lnp_w; g.lnb = lnp_b; g.W = ar + ly.sa_in_w; g.bias = ar + ly.sa_in_b;
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             if (const int rc = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0,
                                        (w->tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr); rc != IDF_OK) return rc;
-            hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s,
-                               k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
+            launch_self_attn_outproj(s, k.qkv, B, T, ar + ly.sa_out_frag, k.parts, pstride);
             hipLaunchKernelGGL((rowblock_kernel<false, false, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
                                ar + ly.ln_w[0], ar + ly.ln_b[0], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.x2, T, 0, pstride,
-                               k.xn, ar + ly.sa_out_b);
+                               k.xn, ar + ly.sa_out_b, nullptr, MEM);
         }
         if (const int rc = idf_launch_layer_ffn(s, ly, ar, w->tune, k.x2, N, k.parts); rc != IDF_OK) return rc;
         u_in = k.parts;
@@ -1109,7 +1653,7 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
     }
     // cond[t][b][:] = LN2_last(u[b*T + t])
     hipLaunchKernelGGL((rowblock_kernel<false, false, NSL>), rb_grid, dim3(256), 0, s, u_in, nullptr, nullptr, nullptr, nullptr, lnp_w, lnp_b,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, pstride, nullptr, nullptr);       // after 8 layers u_in is always the slabs
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cond, T, 1, pstride, nullptr, nullptr, nullptr, MEM);       // after 8 layers u_in is always the slabs
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
@@ -1117,13 +1661,26 @@ extern "C" int interdiff_mdm_encode(const idf_mdm_weights *w, const float *pc, c
 namespace {
 // dynamic LDS that tops a split-f16 row block's static LDS up to the CU's whole 160 KiB (exclusive CU, see the kernel), verified per (kernel, device):
 // -1 = the kernel does not get its CU there (common.h idf_exclusive_cu) and the caller launches the fp32 row block
+template <int MS>
 int rb_h2_qan_dyn() {
     static idf_excl_cache excl;
-    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<true, true, NSL, true>), "rowblock_kernel<QaN, split-f16>", 256, excl);
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<true, true, NSL, true, MS>), MS == MEM ? "rowblock_kernel<QaN, split-f16>" : "rowblock_kernel<QaN, split-f16, any memory length>", 256, excl);
 }
+// the eight-wave form (rowblock8_kernel: the shipped split-f16 row block since round 5; tune[IDF_TUNE_MISC] == 8 keeps round 4's four-wave kernel for A/B)
+template <int MS>
+int rb8_qan_dyn() {
+    static idf_excl_cache excl;
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<true, NSL, MS>), MS == MEM ? "rowblock8_kernel<QaN, split-f16>" : "rowblock8_kernel<QaN, split-f16, any memory length>", 512, excl);
+}
+template <int MS>
+int rb8_std_dyn() {
+    static idf_excl_cache excl;
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<false, H, MS>), MS == MEM ? "rowblock8_kernel<std, split-f16>" : "rowblock8_kernel<std, split-f16, any memory length>", 512, excl);
+}
+template <int MS>
 int rb_h2_std_dyn() {
     static idf_excl_cache excl;
-    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<false, true, H, true>), "rowblock_kernel<std, split-f16>", 256, excl);
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<false, true, H, true, MS>), MS == MEM ? "rowblock_kernel<std, split-f16>" : "rowblock_kernel<std, split-f16, any memory length>", 256, excl);
 }
 
 // the sampler-step operands of interdiff_mdm_forward_step (null x: plain forward, x0 written out)
@@ -1135,16 +1692,21 @@ struct StepPost {
     int64_t *state, *ts;
 };
 
-int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
-                     void *ws, size_t ws_bytes, void *stream, const StepPost &post, int32_t flags = 0) {
+template <int MS>
+int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
+                       void *ws, size_t ws_bytes, void *stream, const StepPost &post, int32_t flags) {
+    using ML = MemLay<MS>;
+    constexpr int G_FRAG = ML::G_FRAG, G_H2 = ML::G_H2;
+    const int mlen = idf_mem_len(w);
     if (!w || !memctx || !x || !ts || (!x0 && !post.x) || !ws || B <= 0 || T <= 0) return IDF_E_INVAL;
-    if (T > w->max_T || T > ATTN_MAX_T || w->C > 256 || w->C < 1) return IDF_E_INVAL;
+    if (T > w->max_T || w->C > 256 || w->C < 1 || mlen < 1 || mlen > MEMX || (MS == MEM) != (mlen == MEM)) return IDF_E_INVAL;
+    if (T > ATTN_MAX_T && w->tune[IDF_TUNE_GEMM_OUTPROJ] != 0) return IDF_E_INVAL;          // (the A/B route with the out-projection as its own GEMM exists for T <= ATTN_MAX_T only)
     if (ws_bytes < interdiff_mdm_workspace_bytes(B, T)) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const float *ar = w->arena;
     const int N = B * T, C = w->C;
     Ws k = carve(ws, N);
-    const MemCtx mc = memctx_carve(memctx, B);
+    const MemCtx mc = memctx_carve<MS>(memctx, B);
     const float *G = mc.G, *VWT = mc.VWT, *g0 = mc.g0;
     const int32_t *tune = w->tune;
 
@@ -1155,7 +1717,7 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     idf_tail_h2::TailArgs ta{};
     if (tail_h2) {
         ta.win = ar + w->in_w_h2; ta.in_b = ar + w->in_b; ta.temb = ar + w->temb_table; ta.pe = ar + w->pe; ta.ts = ts; ta.n_steps = w->n_steps;
-        ta.u0 = k.uA; ta.M = N; ta.T = T; ta.x_tok = x;
+        ta.u0 = k.uA; ta.M = N; ta.T = T; ta.x_tok = x; ta.plain_ids = tune[IDF_TUNE_MISC] == 7 ? 1 : 0;
         if (!(post.x && (flags & IDF_STEP_EMBED_READY))) {
             idf_prof_mark(IDF_K_EMBED, s);
             if (const int rc = idf_tail_h2::launch_tail(s, 0, ta); rc != IDF_OK) return rc;
@@ -1189,25 +1751,31 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];
-        const float *Gl = G + (size_t)l * B * G_FRAG, *VWTl = VWT + (size_t)l * B * D * HMP, *g0l = g0 + (size_t)l * B * HM;
+        const float *Gl = G + (size_t)l * B * G_FRAG, *VWTl = VWT + (size_t)l * B * ML::VWT_F, *g0l = g0 + (size_t)l * B * ML::G0N;
         // split-f16 row block: tune[IDF_TUNE_FFN_MATH] == 1 (2 = split-f16 feed-forward and QKV only), for layers whose LayerNorm outputs the packer proved to stay in the f16 range
         const bool rb_h2 = tune[IDF_TUNE_FFN_MATH] == 1 && ly.rb_h2_ok != 0 && (!ly.is_qan || (ly.qc_h2 != 0 && u_np == NSL));
         const float *Gh = mc.Gh2 + (size_t)l * B * G_H2, *VWh = mc.VWh2 + (size_t)l * B * VW_H2, *scl = mc.sc + (size_t)l * B * 2;
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
-            const int dyn = rb_h2 ? rb_h2_qan_dyn() : -1;
-            if (dyn >= 0) {
-                rowblock_kernel<true, true, NSL, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
+            const bool rb8 = tune[IDF_TUNE_MISC] != 8;
+            const int dyn8 = rb_h2 && rb8 ? rb8_qan_dyn<MS>() : -1;
+            const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_qan_dyn<MS>() : -1;
+            if (dyn8 >= 0) {
+                rowblock8_kernel<true, NSL, MS><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, scl);
+                                   ar + ly.ln_b[1], k.x2, T, pstride, nullptr, nullptr, scl, mlen);
+            } else if (dyn >= 0) {
+                rowblock_kernel<true, true, NSL, true, MS><<<rb_grid, dim3(256), (size_t)dyn, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, scl, mlen);
             } else if (u_np == NSL)
-                hipLaunchKernelGGL((rowblock_kernel<true, true, NSL>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                hipLaunchKernelGGL((rowblock_kernel<true, true, NSL, false, MS>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr);
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, nullptr, mlen);
             else
-                hipLaunchKernelGGL((rowblock_kernel<true, true, 1>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
+                hipLaunchKernelGGL((rowblock_kernel<true, true, 1, false, MS>), rb_grid, dim3(256), 0, s, u_in, lnp_w, lnp_b, ar + ly.qc, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr);
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, nullptr, nullptr, nullptr, mlen);
         } else {
             // xn = LN_prev(u_in) ; qkv = xn.Win^T + b
             Args g{};
@@ -1224,23 +1792,27 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
                 // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's
                 // slab buffer (its previous contents were consumed by the QKV kernel), summed with xn + bo by the row block
                 int rc_ah2 = IDF_NOT_EXCLUSIVE;
-                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] == 5) {      // NOT the default: the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) measured 1.5 % slower over whole samples than the fp32 kernel with two workgroups per CU (profiles/r04_attn_split_f16_ab.txt); MISC = 5 selects it
+                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] == 5 && T <= ATTN_MAX_T) {      // NOT the default: the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) measured 1.5 % slower over whole samples than the fp32 kernel with two workgroups per CU (profiles/r04_attn_split_f16_ab.txt); MISC = 5 selects it
                     rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride);
                     if (rc_ah2 != IDF_OK && rc_ah2 != IDF_NOT_EXCLUSIVE) return rc_ah2;
                 }
-                if (rc_ah2 == IDF_NOT_EXCLUSIVE)
-                hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256),
-                                   attn_lds_bytes(T, ATTN_RT), s, k.qkv, nullptr, T, ar + ly.sa_out_frag, k.parts, pstride);
+                if (rc_ah2 == IDF_NOT_EXCLUSIVE) launch_self_attn_outproj(s, k.qkv, B, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
-                const int dyn = rb_h2 ? rb_h2_std_dyn() : -1;
-                if (dyn >= 0) {
-                    rowblock_kernel<false, true, H, true><<<rb_grid, dim3(256), (size_t)dyn, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
+                const bool rb8 = tune[IDF_TUNE_MISC] != 8;
+                const int dyn8 = rb_h2 && rb8 ? rb8_std_dyn<MS>() : -1;
+                const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_std_dyn<MS>() : -1;
+                if (dyn8 >= 0) {
+                    rowblock8_kernel<false, H, MS><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, scl);
+                                   ar + ly.ln_b[1], k.x2, T, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
+                } else if (dyn >= 0) {
+                    rowblock_kernel<false, true, H, true, MS><<<rb_grid, dim3(256), (size_t)dyn, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
                 } else
-                hipLaunchKernelGGL((rowblock_kernel<false, true, H>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
+                hipLaunchKernelGGL((rowblock_kernel<false, true, H, false, MS>), rb_grid, dim3(256), 0, s, k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b);
+                                   ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, nullptr, mlen);
             } else {                                   // A/B runs: the out-projection as a separate GEMM (tools/kbench.py)
                 hipLaunchKernelGGL((self_attn_kernel<false, 2>), dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds_bytes(T, 2), s, k.qkv, k.ctx, T,
                                    nullptr, nullptr, (size_t)0);
@@ -1250,9 +1822,9 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
                 idf_prof_mark(IDF_K_GEMM_OUTPROJ, s);
                 run_gemm<A_PLAIN, E_RESID>(tune[IDF_TUNE_GEMM_OUTPROJ], s, o);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
-                hipLaunchKernelGGL((rowblock_kernel<false>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
+                hipLaunchKernelGGL((rowblock_kernel<false, true, 1, false, MS>), rb_grid, dim3(256), 0, s, u_tmp, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, 0, (size_t)0, nullptr, nullptr);
+                                   ar + ly.ln_b[1], k.x2, T, 0, (size_t)0, nullptr, nullptr, nullptr, mlen);
             }
         }
         // u3 = x2 + linear2(gelu(linear1(x2))) as NSL partial slabs (ffn.h); their sum is taken by the next reader
@@ -1289,6 +1861,12 @@ int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float 
     idf_prof_mark(-1, s);
     IDF_CHECK_LAUNCH();
     return IDF_OK;
+}
+int mdm_forward_impl(const idf_mdm_weights *w, const float *memctx, const float *x, const int64_t *ts, int32_t B, int32_t T, float *x0,
+                     void *ws, size_t ws_bytes, void *stream, const StepPost &post, int32_t flags = 0) {
+    if (!w || w->mem_len < 0 || w->mem_len > MEMX) return IDF_E_INVAL;
+    return idf_mem_len(w) == MEM ? mdm_forward_impl_t<MEM>(w, memctx, x, ts, B, T, x0, ws, ws_bytes, stream, post, flags)
+                                 : mdm_forward_impl_t<MEMX>(w, memctx, x, ts, B, T, x0, ws, ws_bytes, stream, post, flags);
 }
 }  // namespace
 
@@ -1345,8 +1923,14 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
         idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
     }
-    rb_h2_qan_dyn();
-    rb_h2_std_dyn();
+    rb_h2_qan_dyn<MEM>();
+    rb_h2_std_dyn<MEM>();
+    rb_h2_qan_dyn<MEMX>();
+    rb_h2_std_dyn<MEMX>();
+    rb8_qan_dyn<MEM>();
+    rb8_std_dyn<MEM>();
+    rb8_qan_dyn<MEMX>();
+    rb8_std_dyn<MEMX>();
     idf_tail_h2::tail_exclusive_ok(false);
     idf_tail_h2::tail_exclusive_ok(true);
     return idf_excl_report(buf, cap);

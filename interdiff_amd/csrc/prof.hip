@@ -112,3 +112,40 @@ extern "C" int interdiff_debug_lds_sentinel(uint32_t *out, int32_t n_wg, int32_t
     IDF_CHECK_LAUNCH();
     return IDF_OK;
 }
+
+// ---- f16-MFMA "aggressor" of the co-residency probes (tools/coresidency_probe.hip, tools/hook_stage_probe.py; DESIGN.md "exclusive CU"): a kernel that only
+// loops over v_mfma_f32_16x16x32_f16 on register operands and streaming global loads, with small LDS / register needs so that it shares CUs with whatever
+// runs on another stream -- the one pattern that has been seen to corrupt a co-resident wave's VALU results.  Diagnostic only: nothing in the product launches it.
+namespace {
+typedef _Float16 idf_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void f16_aggressor_kernel(const float4 *__restrict__ src, size_t n4, float *__restrict__ sink, int iters, int with_loads) {
+    const int tid = threadIdx.x;
+    idf_h8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * ((tid + e) % 37) - 0.15f); b[e] = (_Float16)(0.02f * ((tid * 3 + e) % 29) - 0.2f); }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t p = ((size_t)blockIdx.x * 256 + tid) % n4;
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, b, c3, 0, 0, 0);
+        if (with_loads) {
+            const float4 v = src[p];
+            p += 256 * 977;
+            if (p >= n4) p -= n4;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int r = 0; r < 4; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    if (s == 123.456f) sink[0] = s;            // never true: keeps everything alive
+}
+}  // namespace
+
+extern "C" int interdiff_debug_f16_aggressor(const float *src, size_t n_floats, float *sink, int32_t iters, int32_t grid, int32_t with_loads, void *stream) {
+    if (!src || !sink || n_floats < 4096 || iters <= 0 || grid <= 0) return IDF_E_INVAL;
+    hipLaunchKernelGGL(f16_aggressor_kernel, dim3((unsigned)grid), dim3(256), 0, idf_stream(stream), reinterpret_cast<const float4 *>(src), n_floats / 4, sink, iters, with_loads);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+}

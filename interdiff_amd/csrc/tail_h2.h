@@ -53,6 +53,7 @@ struct TailArgs {
     int n_steps;
     float *u0;                    // [M][256]
     int M, T;
+    int plain_ids;                // A/B only (tune[IDF_TUNE_MISC] == 7): workgroup id -> row tile as in round 4 (tile = id); 0 = XCD-affine (below)
 };
 
 template <int MODE, bool RAGGED>
@@ -65,7 +66,12 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
     __shared__ float sc[TRW];
     __shared__ __attribute__((aligned(16))) float us[EMBED ? TRW * USS : 4];             // u0 tile on its way out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * TRW, M = a.M, T = a.T;
+    // XCD-affine row tiles (round 5): workgroup id runs on XCD id % 8; giving an XCD CONSECUTIVE tiles puts the rows of clips {2x, 2x + 1} (B = 16, T = 100) on XCD x
+    // like the row block, the attention, the feed-forward and the QKV kernels already do -- the five slabs this kernel sums were written by that XCD, and the u0 / x rows
+    // it writes are read by that XCD's QKV workgroups next (any order is correct: every workgroup computes the same tile).
+    const int nwg = gridDim.x, wid = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = wid & 7;
+    const int tile = a.plain_ids ? wid : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
+    const int m0 = tile * TRW, M = a.M, T = a.T;
     const int rown = (wave & 3) * 4 + kq;                 // row passes (waves 0..3): one 16-lane group per token row
     const bool rowpass = wave < 4;
 

@@ -196,7 +196,7 @@ class GaussianDiffusion:
                     sl=sl, x=st.x[sl], ts=st.ts[sl], gt=st.gt[sl] if has_mask else None, mask=st.mask[sl] if has_mask else None,
                     state=st.state if c == 0 else torch.zeros(8, dtype=torch.int64, device=dev),
                     cond=torch.empty(cond.shape[0], h, cond.shape[2], device=dev),
-                    memctx=torch.empty(model.memctx_floats(h), dtype=torch.float32, device=dev),
+                    memctx=torch.empty(model.memctx_floats(h, cond.shape[0]) if getattr(model, 'accepts_batch_rows', False) else model.memctx_floats(h), dtype=torch.float32, device=dev),
                     ws=torch.empty(model.workspace_bytes(h, img.shape[-1]), dtype=torch.uint8, device=dev), stream=torch.cuda.Stream(dev)))
         if split:
             for ch in st.chains:                      # this sample's memory, folded per chain (its layout is per batch)

@@ -22,6 +22,7 @@ import torch
 from . import _lib
 
 D, FF, HEADS, NQ, MEM, LAYERS = 256, 1024, 4, 10, 10, 8
+MEM_MAX = 16                # IDF_MDM_MEM_MAX: longest memory (cond rows) the library folds; MEM = 10 takes the compact fast layout
 QAN_LAYERS = (1, 2, 3, 4, 5, 6)
 ROTARY_DEFAULT = True
 FFN_MATH_DEFAULT = 'split'
@@ -450,6 +451,10 @@ class MDM:
         self.rowblock_math = os.environ.get('INTERDIFF_ROWBLOCK_MATH', ROWBLOCK_MATH_DEFAULT)
         if self.rowblock_math not in ('split', 'exact'):
             raise ValueError("rowblock_math must be 'split' or 'exact'")
+        # the split-f16 row block: 8 = the eight-wave kernel (csrc/denoiser.hip rowblock8_kernel, shipped since round 5), 4 = round 4's four-wave kernel (A/B runs)
+        self.rowblock_waves = int(os.environ.get('INTERDIFF_ROWBLOCK_WAVES', '8'))
+        if self.rowblock_waves not in (4, 8):
+            raise ValueError('rowblock_waves must be 4 or 8')
         self.pn = self.pn_arena = None
         if 'pcEmbedding.Linear.weight' in state_dict:
             self.pn, self.pn_arena = pack_pointnet2(state_dict, self.device)
@@ -502,8 +507,14 @@ class MDM:
         self._memctx_pool.clear()
         self._ws = self._ws_shape = self._memctx = self._mem_key = self._mem_cond = None
 
-    def memctx_floats(self, B):
-        return self.lib.interdiff_mdm_memctx_floats(B)
+    def memctx_floats(self, B, mem_len=None):
+        """Floats of a folded-memory buffer for B clips at memory length ``mem_len`` (default: the length of the last ``prepare_memory``, else 10)."""
+        return self.lib.interdiff_mdm_memctx_floats_for(B, mem_len or self.mem_len)
+
+    @property
+    def mem_len(self):
+        """Memory length (rows of ``cond``) the handle is set to: eval_smpl_short.py:376 takes it from the CLI (--past_len); 10 in every BASELINE config."""
+        return int(self.w.mem_len) or MEM
 
     def workspace_bytes(self, B, T):
         return self.lib.interdiff_mdm_workspace_bytes(B, T)
@@ -512,12 +523,13 @@ class MDM:
         """Fold the constant memory ``cond`` [MEM,B,256] into the per-sample cross-attention operands.  ``into``: a caller-owned
         buffer of ``memctx_floats(B)`` floats to fill instead of the model's own (a chain of a split batch, diffusion.py); the
         model's notion of "current memory" is left alone then."""
-        if cond.shape[0] != MEM or cond.shape[2] != D:
-            raise ValueError('cond must be [%d,B,%d]' % (MEM, D))
+        if not (1 <= cond.shape[0] <= MEM_MAX) or cond.shape[2] != D:
+            raise ValueError('cond must be [1..%d,B,%d]' % (MEM_MAX, D))
         B = cond.shape[1]
         given = cond
         cond = cond.contiguous()
-        need = self.lib.interdiff_mdm_memctx_floats(B)
+        self.w.mem_len = cond.shape[0]              # the handle's memory length: every forward on this memory reads it (10: compact layout; else the generic one)
+        need = self.lib.interdiff_mdm_memctx_floats_for(B, cond.shape[0])
         if into is not None:
             if into.numel() != need or into.dtype != torch.float32 or not into.is_contiguous():
                 raise ValueError('into must be %d contiguous floats' % need)
@@ -526,11 +538,12 @@ class MDM:
                                                              _lib.dptr(into), _lib.dptr(ws), ws.numel(), _lib.stream()),
                        'mdm_prepare_memory')
             return into
-        # one buffer per batch size, reused for every sample and never released: its address may be baked into a captured hipGraph
-        memctx = self._memctx_pool.get(B)
+        # one buffer per (batch size, memory length), reused for every sample and never released: its address may be baked into a captured hipGraph
+        pool_key = B if cond.shape[0] == MEM else (B, cond.shape[0])
+        memctx = self._memctx_pool.get(pool_key)
         if memctx is None or memctx.numel() != need:
             memctx = torch.empty(need, dtype=torch.float32, device=self.device)
-            self._memctx_pool[B] = memctx
+            self._memctx_pool[pool_key] = memctx
         ws = self._workspace(B, 16)
         _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                          _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),
@@ -598,7 +611,7 @@ class MDM:
 
     def ffn_graph_key(self, rows):
         """What a captured launch sequence bakes in about the feed-forward block (the sampler's graph cache key, diffusion.py)."""
-        return (self.ffn_class_for_rows(rows), self.ffn_math, self.ffn_rows, getattr(self, 'rowblock_math', 'exact'))
+        return (self.ffn_class_for_rows(rows), self.ffn_math, self.ffn_rows, getattr(self, 'rowblock_math', 'exact'), getattr(self, 'rowblock_waves', 8))
 
     def _pick_ffn_tile(self, rows, own_rows=None):
         """The fused feed-forward block has 16-, 32- and 64-row kernels (csrc/ffn.h); the 32-row one agrees with the other two to
@@ -615,6 +628,8 @@ class MDM:
                 tile = 16 if own_rows <= self.FFN16_MAX_ROWS else 64
         self.w.tune[_lib.TUNE['ffn']] = {16: 2, 64: 3}.get(tile, 1)
         self.w.tune[_lib.TUNE['ffn_math']] = (1 if getattr(self, 'rowblock_math', 'exact') == 'split' else 2) if getattr(self, 'ffn_math', 'exact') == 'split' else 0
+        if self.w.tune[_lib.TUNE['misc']] in (0, 8):            # (other values of the A/B switch are left to whoever set them)
+            self.w.tune[_lib.TUNE['misc']] = 8 if getattr(self, 'rowblock_waves', 8) == 4 else 0
 
     def arithmetic_report(self):
         """Which arithmetic every contraction of a denoiser forward takes under the current ``ffn_math`` / ``rowblock_math`` selection, layer by
@@ -649,8 +664,8 @@ class MDM:
             if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
                 self.prepare_memory(cond)
             memctx = self._memctx
-        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats(B):
-            raise ValueError('memctx was folded for another batch size')
+        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats_for(B, self.mem_len):
+            raise ValueError('memctx was folded for another batch size or memory length')
         if one != 1 or Cc != self.w.C:
             raise ValueError('x must be [B,1,%d,T]' % self.w.C)
         x = x.contiguous()
@@ -694,8 +709,8 @@ class MDM:
             if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
                 self.prepare_memory(cond)
             memctx = self._memctx
-        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats(B):
-            raise ValueError('memctx was folded for another batch size')
+        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats_for(B, self.mem_len):
+            raise ValueError('memctx was folded for another batch size or memory length')
         if ws is None:
             ws = self._workspace(B, T)
         flags = (_lib.STEP_EMBED_READY if embed_ready else 0) | (_lib.STEP_EMBED_NEXT if embed_next else 0)

@@ -385,11 +385,13 @@ def _poses_fp64(sample, batch):
                 body_rotations=R.rotation_6d_to_matrix(b6[..., :132].reshape(T, B, 22, 6)), markers=verts[:, :, MARKERS67], joints=jtr)
 
 
-def _full_size_report(mdm, smpl):
-    """The measurements of test_full_size_end_to_end_golden (also run per arithmetic variant by tests/pose_error_spread.py)."""
+def _full_size_report(mdm, smpl, names=('full.npz', 'full64.npz'), dump_steps=None):
+    """The measurements of test_full_size_end_to_end_golden (also run per arithmetic variant by tests/pose_error_spread.py).  ``names`` / ``dump_steps``:
+    the fixture pair (reference run, fp64 twin) and its dump indices -- the well-conditioned twin fixture of round 5 is ('fullwc.npz', 'fullwc64.npz')."""
     from interdiff_amd import eval as ev
     from interdiff_amd.diffusion import create_gaussian_diffusion
-    z, z64 = fx.golden('full.npz'), fx.golden('full64.npz')
+    z, z64 = fx.golden(names[0]), fx.golden(names[1])
+    dump_steps = dump_steps or fx.FULL_DUMPS
     T, B, P = fx.FULL_SHAPE
     past = fx.PAST
     batch, noise, stream = fx.full_inputs()
@@ -408,7 +410,7 @@ def _full_size_report(mdm, smpl):
         return out
     y = ev.model_kwargs_for(bd, past)
     dumps = diff.p_sample_loop(mdm, tuple(noise.shape), noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': y}, denoised_fn=hook,
-                               dump_steps=fx.FULL_DUMPS, step_noise=lambda i, x: stream.next_like(x).to(DEV))
+                               dump_steps=dump_steps, step_noise=lambda i, x: stream.next_like(x).to(DEV))
     assert dec['t'] == list(z['corr_t']) == [500 - 50 * k for k in range(11)]
     cond, contact = np.stack(dec['condition']), np.stack(dec['contact'])
     n_dec = cond.size
@@ -420,7 +422,7 @@ def _full_size_report(mdm, smpl):
     rep['reference_vs_fp64_marker_flips'] = float((_pick(z['contact']) != _pick(z64['contact'])).sum()) / n_dec
     rep['hip_vs_fp64_marker_flips'] = float((_pick(contact) != _pick(z64['contact'])).sum()) / n_dec
     per_dump = {}
-    for s_, d in zip(fx.FULL_DUMPS, dumps):
+    for s_, d in zip(dump_steps, dumps):
         k = 'dump_%d' % s_
         per_dump[str(s_)] = dict(hip_vs_reference=rel(d, z[k]), hip_vs_fp64=rel(d, z64[k]), reference_vs_fp64=rel(z[k], z64[k]))
     rep['sampler_state_rel_err_by_loop_index'] = per_dump
@@ -516,6 +518,84 @@ def test_full_size_end_to_end_golden(mdm, smpl):
         yard = rep['final_outputs_reference_vs_fp64'][k]
         assert rep['final_outputs_hip_vs_fp64'][k] <= max(1e-4, 2 * yard), ('final %s vs fp64' % k, rep['final_outputs_hip_vs_fp64'][k], yard)
         assert e <= max(1e-4, 3 * yard), ('final %s vs reference' % k, e, yard)
+
+
+@pytest.mark.parametrize('math', ['split', 'exact'])
+def test_full_size_end_to_end_well_conditioned_golden_flat_1e4(smpl, math):
+    """North_star's tolerance on the quantities it names -- final poses and object trajectories within 1e-4 relative of the reference's own
+    eval_smpl_short.py path -- at BASELINE config #2 (B=16, T=100, P=2048, 1000 steps, 11 corrections, injected noise), as a FLAT gate: no yardstick
+    term, every pose quantity, under both arithmetics (shipped split-f16 and exact fp32 MFMA).  The fixture (tests/golden/fullwc.npz = the REFERENCE's
+    sampler + MDM + denoised_fn + sample_once_proj / get_gt / metrics, fullwc64.npz = the oracle's fp64 twin; `make_golden.py fullwc`, `fullwc64`) differs
+    from full.npz in ONE thing: the synthetic denoiser's output heads are well conditioned (tests/fixtures.py mdm_weights_wc: 0.05 x the random heads
+    around a bias that is a valid pose), so the Gram-Schmidt step of rot6d -> matrix is nowhere near singular and fp32 CAN deliver 1e-4 -- on full.npz
+    (random-init heads, |cos| of a joint's two 3-vectors up to 0.99998) the reference's own fp32 run is 1e-3 from the exact answer and no fp32
+    implementation can be held to 1e-4 there (test_full_size_end_to_end_golden keeps that fixture for the sampler state, the decisions and the metrics)."""
+    from interdiff_amd.mdm import MDM
+    model = MDM(fx.mdm_weights_wc(), device=DEV)
+    model.ffn_math = math
+    if math == 'split':
+        assert model.arithmetic_report()['all_split'], model.arithmetic_report()      # the fixture's weights pass every f16 range proof: nothing silently on the exact kernels
+    rep, per_dump, fin, fin_same, rot_anchor = _full_size_report(model, smpl, names=('fullwc.npz', 'fullwc64.npz'), dump_steps=fx.FULLWC_DUMPS)
+    rep['arithmetic'] = math
+    fx.record_parity('full_size_end_to_end_well_conditioned_%s' % math, **rep)
+    print(rep)
+    FLAT = 1e-4
+    for s_, e in per_dump.items():
+        assert e['hip_vs_reference'] <= FLAT, ('sampler state', s_, e)
+    assert rep['condition_flips_vs_reference'] == 0 and rep['contact_marker_flips_vs_reference'] == 0
+    for k, e in fin.items():                       # obj translation / rotation, body translation + hands, body rotations, markers, joints: HIP vs the reference
+        assert e <= FLAT, ('final %s vs reference' % k, e)
+    for k, e in rep['final_outputs_hip_vs_fp64'].items():
+        assert e <= FLAT, ('final %s vs fp64' % k, e)
+    for k, e in fin_same.items():                  # conversion / body-model kernels on the reference's own final sample
+        assert e <= FLAT, ('on the reference sample: %s' % k, e)
+    # the fixture does what it was built for: the reference's own fp32 run is well inside 1e-4 of the exact answer on every pose quantity
+    for k, e in rep['final_outputs_reference_vs_fp64'].items():
+        assert e <= 5e-5, ('yardstick: reference vs fp64 %s' % k, e)
+    for k, e in rep['metrics_rel_err_vs_reference'].items():
+        assert e <= (2e-3 if k == 'penetrate' else 2e-4), (k, e)
+
+
+def test_exclusive_cu_claims_are_verified_and_hold(mdm, smpl):
+    """Every kernel that issues the f16 MFMA must own its CU (DESIGN.md "exclusive CU"): (i) the launchers' own verification -- occupancy query == 1,
+    160 KiB of LDS, >= 256 registers allocated -- passes for every such kernel on this device (a kernel that fails runs as its fp32 counterpart: on MI355X none
+    may); (ii) the effect the rule exists for does not show: the hook's SMPL stage (one-wave pose kernel + skinning) computes the same bits alone and while the
+    split-f16 feed-forward kernel runs on a second stream (the reproducer of round 4, tools/hook_stage_probe.py, as a test)."""
+    from interdiff_amd import _lib
+    from interdiff_amd.mdm import ffn_parts
+    txt, bad = _lib.exclusive_cu_report()
+    print(txt)
+    assert bad == 0, txt
+    rows = [ln for ln in txt.strip().split('\n') if ln]
+    assert len(rows) >= 16 and all('exclusive' in ln and 'NOT' not in ln for ln in rows), txt      # 3 + 2 + 1 + 2 + 8 kernel instantiations
+    fx.record_parity('exclusive_cu_report', kernels=len(rows), not_exclusive=bad, table=rows)
+    assert mdm.ffn_math == 'split'
+    g = torch.Generator().manual_seed(0)
+    N = 800
+    pose, betas, trans = (0.3 * torch.randn(N, 156, generator=g)).to(DEV), torch.randn(N, 10, generator=g).to(DEV), (0.3 * torch.randn(N, 3, generator=g)).to(DEV)
+    x2, parts = torch.randn(N, 256, generator=g).to(DEV), torch.empty(5, N, 256, device=DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def victim(load):
+        torch.cuda.synchronize()
+        if load:
+            with torch.cuda.stream(sb):
+                for i in range(200):
+                    mdm.ffn_rows = 16 if i & 1 else 32
+                    ffn_parts(mdm, x2, i % 8, out=parts)
+            mdm.ffn_rows = 0
+        with torch.cuda.stream(sa):
+            v, j, _, _ = smpl(pose, th_betas=betas, th_trans=trans, want_v_posed=False)
+            v, j = v.clone(), j.clone()
+        torch.cuda.synchronize()
+        return v, j
+    v0, j0 = victim(False)
+    differing = 0
+    for rep in range(8):
+        v, j = victim(True)
+        differing += 0 if (torch.equal(v, v0) and torch.equal(j, j0)) else 1
+    fx.record_parity('smpl_stage_beside_split_f16_ffn', runs=8, runs_that_differ=differing)
+    assert differing == 0, 'the SMPL stage computed different bits beside the split-f16 feed-forward kernel in %d of 8 runs' % differing
 
 
 def test_evaluate_batch_and_sample_once(mdm, smpl):
@@ -1077,11 +1157,68 @@ def test_denoiser_edge_sizes(mdm, B, T):
 
 
 @pytest.mark.gpu
-def test_denoiser_rejects_unsupported_sizes(mdm):
-    """Above the longest supported clip the entry point refuses (IDF_E_INVAL -> RuntimeError); nothing falls back."""
-    x, ts, cond = fx.mdm_inputs(1, 224)
-    with pytest.raises((RuntimeError, ValueError)):
-        mdm(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+@pytest.mark.parametrize('M,B,T', [(15, 3, 35), (10, 2, 300), (16, 2, 20), (1, 2, 17), (7, 1, 224)])
+def test_denoiser_any_memory_length_and_long_clips(lib, M, B, T):
+    """The two hard limits of rounds 1-4, lifted behind slower-but-correct paths (round 5):
+      * memory length != 10 -- the reference takes --past_len from the CLI (eval_smpl_short.py:376-377; cond = the encoded past frames, model/diffusion_smpl.py:195-223);
+        lengths 1..16 take the generic layout of the folded memory (one 16-column score tile per head, absent slots masked; csrc/denoiser.hip MemLay);
+      * clips longer than 208 frames -- the reference's bound is PositionalEncoding(max_len=5000) (model/layers.py:10); they take the K/V-tiled self-attention.
+    Against oracle/denoiser.py (1e-4) and its float64 run (the split-f16 form as close to fp64 as the exact form, like test_mdm_forward_split_f16_vs_exact_and_fp64),
+    both arithmetics; then back to the default shape on the same handle (the compact layout must be undisturbed)."""
+    from interdiff_amd.mdm import MDM
+    sd = fx.mdm_weights()
+    sd64 = {k: torch.as_tensor(v).double() for k, v in sd.items()}
+    rs = np.random.RandomState(7000 + 100 * M + T)
+    x = torch.from_numpy(rs.standard_normal((B, 1, 144, T)).astype(np.float32))
+    ts = torch.from_numpy(rs.randint(0, 1000, size=B).astype(np.int64))
+    cond = torch.from_numpy(rs.standard_normal((M, B, 256)).astype(np.float32))
+    ref = oden.mdm_forward(sd, x, ts, cond)
+    ref64 = oden.mdm_forward(sd64, x.double(), ts, cond.double())
+    err = {}
+    for math in ('exact', 'split'):
+        m = MDM(sd, device=DEV)
+        m.ffn_math = math
+        got = m(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})
+        assert m.mem_len == M
+        close(got, ref, 1e-4, 'M=%d B=%d T=%d %s vs oracle' % (M, B, T, math))
+        err[math] = rel(got, ref64)
+        # the same handle, back at the default memory length and a short clip: the compact layout / one-shot attention again, bit-identical to a fresh model
+        x2, ts2, c2 = fx.mdm_inputs(2, 12)
+        again = m(x2.to(DEV), ts2.to(DEV), y={'cond': c2.to(DEV)})
+        assert m.mem_len == 10
+        fresh = MDM(sd, device=DEV)
+        fresh.ffn_math = math
+        assert torch.equal(again, fresh(x2.to(DEV), ts2.to(DEV), y={'cond': c2.to(DEV)}))
+    fx.record_parity('denoiser_M%d_B%d_T%d_vs_fp64' % (M, B, T), exact=err['exact'], split=err['split'])
+    assert err['split'] <= max(2 * err['exact'], 2e-6) and err['exact'] <= 1e-5, err
+
+
+@pytest.mark.gpu
+def test_sampler_with_a_longer_memory_and_a_long_clip(lib, smpl):
+    """The lifted limits through the SAMPLER: 30 plain steps + inpainting at memory length 15 (T = 35, the reference's clip length with --past_len 15) on the graph
+    route against the CPU oracle's p_sample_loop fed the materialised Philox stream (1e-4), graph route == eager route bit for bit; the same at T = 240 (K/V-tiled
+    attention), memory length 10."""
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    diff = create_gaussian_diffusion('cosine', 1000)
+    for M, B, T, n in ((15, 3, 35, 30), (10, 2, 240, 12)):
+        model = MDM(fx.mdm_weights(), device=DEV)
+        rs = np.random.RandomState(7100 + M + T)
+        gt = torch.from_numpy(rs.standard_normal((B, 1, 144, T)).astype(np.float32))
+        cond = torch.from_numpy(rs.standard_normal((M, B, 256)).astype(np.float32))
+        noise = torch.from_numpy(rs.standard_normal((B, 1, 144, T)).astype(np.float32))
+        mask = torch.zeros_like(gt, dtype=torch.bool)
+        mask[..., :M] = True
+        y = dict(cond=cond, inpainted_motion=gt, inpainting_mask=mask)
+        kw = dict(noise=noise.to(DEV), clip_denoised=False, model_kwargs={'y': dev(y)}, n_steps=n, first_t=900)
+        timed = diff.p_sample_loop(model, tuple(noise.shape), seed=23, **kw)
+        eager = diff.p_sample_loop(model, tuple(noise.shape), use_graph=False, step_noise=_philox_step(lib, 23), **kw)
+        assert torch.equal(timed, eager), 'M=%d T=%d: graph route differs from eager: %g' % (M, T, (timed - eager).abs().max())
+        stream = _philox_step(lib, 23)
+        ref = odf.p_sample_loop(lambda x, t, yy: oden.mdm_forward(fx.mdm_weights(), x, t, yy['cond']), tuple(noise.shape), odf.make_schedule(1000), noise.clone(),
+                                lambda i, x: stream(i, x.to(DEV)).cpu(), {'y': y}, n_steps=n, first_t=900)
+        e = close(timed, ref, 1e-4, 'sampler M=%d T=%d vs oracle' % (M, T))
+        fx.record_parity('sampler_M%d_T%d_%dsteps_vs_oracle' % (M, T, n), worst_rel_err=e, asserted=1e-4)
 
 
 @pytest.mark.gpu

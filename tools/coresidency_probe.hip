@@ -14,7 +14,10 @@ void idf_prof_mark_slow(int, hipStream_t) {}
 
 // The victim restated with switches (VAR): 0 = as csrc/smpl.hip; 1 = a real s_barrier where the compiler elides __syncthreads() for a one-wave workgroup;
 // 2 = 4 KiB of unused LDS behind the arrays (is it the TAIL of the allocation?); 3 = the parent table copied to LDS first (is it the scalar loads?);
-// 4 = debug: also writes the parent indices and the chain matrices of joints 49..51 it saw
+// 4 = debug: also writes the parent indices and the chain matrices of joints 49..51 it saw; 5 = all 64 lanes active in the Rodrigues part;
+// 6 (round 5) = the Rodrigues block between s_setprio 3 / s_nop fences (does raising the victim's issue priority or draining the VALU pipe around the block matter?);
+// 7 (round 5) = every product of the quaternion -> matrix block through an opaque register (asm volatile "+v"): no packed-fp32 instruction can be formed there
+// whatever the vectoriser does (the whole-binary form of the same question is the -fno-slp-vectorize build: build_tools/coresidency_probe_noslp)
 template <int VAR>
 __global__ __launch_bounds__(64) void pose_victim(const idf_smpl_model m, const float *__restrict__ pose, const float *__restrict__ betas,
                                                   const float *__restrict__ trans, float *__restrict__ feat, float *__restrict__ A, float *__restrict__ jtr,
@@ -29,7 +32,25 @@ __global__ __launch_bounds__(64) void pose_victim(const idf_smpl_model m, const 
     if (VAR == 3) par_s[j] = j < J ? m.parents[j] : 0;
     if (VAR == 5 || j < J) {           // VAR 5: all 64 lanes run the Rodrigues / joint code (lanes >= J on joint J - 1's inputs, into the spare rows): no partial exec mask
         const int jj = VAR == 5 ? min(j, J - 1) : j;
+        if (VAR == 6) asm volatile("s_setprio 3\n s_nop 7\n s_nop 7" ::: "memory");
+        if (VAR == 7) {
+            const float *a = pose + n * 3 * J + 3 * jj;
+            auto pin = [](float v) { asm volatile("" : "+v"(v)); return v; };
+            const float ex = a[0] + 1e-8f, ey = a[1] + 1e-8f, ez = a[2] + 1e-8f;
+            const float ang = sqrtf(pin(pin(ex * ex) + pin(ey * ey)) + pin(ez * ez));
+            const float half = ang * 0.5f, sn = sinf(half);
+            float w = cosf(half), x = pin(sn * pin(a[0] / ang)), y = pin(sn * pin(a[1] / ang)), z = pin(sn * pin(a[2] / ang));
+            const float nq = sqrtf(pin(pin(pin(w * w) + pin(x * x)) + pin(y * y)) + pin(z * z));
+            w = pin(w / nq); x = pin(x / nq); y = pin(y / nq); z = pin(z / nq);
+            const float w2 = pin(w * w), x2 = pin(x * x), y2 = pin(y * y), z2 = pin(z * z);
+            const float wx = pin(w * x), wy = pin(w * y), wz = pin(w * z), xy = pin(x * y), xz = pin(x * z), yz = pin(y * z);
+            float *mm = Rs + j * 9;
+            mm[0] = pin(pin(pin(w2 + x2) - y2) - z2); mm[1] = pin(pin(2 * xy) - pin(2 * wz)); mm[2] = pin(pin(2 * wy) + pin(2 * xz));
+            mm[3] = pin(pin(2 * wz) + pin(2 * xy)); mm[4] = pin(pin(pin(w2 - x2) + y2) - z2); mm[5] = pin(pin(2 * yz) - pin(2 * wx));
+            mm[6] = pin(pin(2 * xz) - pin(2 * wy)); mm[7] = pin(pin(2 * wx) + pin(2 * yz)); mm[8] = pin(pin(pin(w2 - x2) - y2) + z2);
+        } else
         rot::rodrigues_smpl(pose + n * 3 * J + 3 * jj, Rs + j * 9);
+        if (VAR == 6) asm volatile("s_nop 7\n s_nop 7\n s_setprio 0" ::: "memory");
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float s = m.jt[jj * 3 + c];
@@ -221,9 +242,10 @@ int main(int argc, char **argv) {
     // ---- which part of the victim is it?  the aggressor that reproduces ("f16 MFMA + global loads") against the victim's variants
     float *dbg;
     CK(hipMalloc(&dbg, (size_t)N * 64 * 4 * 2));
-    const char *vn[] = {"as shipped", "real s_barrier at every __syncthreads", "4 KiB of unused LDS behind the arrays", "parent table in LDS (no scalar loads in the chain)", "debug stores", "all 64 lanes active in the Rodrigues part (no partial exec)"};
+    const char *vn[] = {"as shipped", "real s_barrier at every __syncthreads", "4 KiB of unused LDS behind the arrays", "parent table in LDS (no scalar loads in the chain)", "debug stores", "all 64 lanes active in the Rodrigues part (no partial exec)",
+                        "Rodrigues block between s_setprio 3 / s_nop fences", "quaternion -> matrix block with every product pinned to a scalar fp32 op (no packed fp32)"};
     std::vector<float> dref((size_t)N * 64), dgot((size_t)N * 64);
-    for (int var = 0; var < 6; ++var) {
+    for (int var = 0; var < 8; ++var) {
         auto vict = [&](float *Aout, float *Jout, float *D) {
             switch (var) {
             case 0: hipLaunchKernelGGL(pose_victim<0>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
@@ -231,6 +253,8 @@ int main(int argc, char **argv) {
             case 2: hipLaunchKernelGGL(pose_victim<2>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
             case 3: hipLaunchKernelGGL(pose_victim<3>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
             case 5: hipLaunchKernelGGL(pose_victim<5>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
+            case 6: hipLaunchKernelGGL(pose_victim<6>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
+            case 7: hipLaunchKernelGGL(pose_victim<7>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
             default: hipLaunchKernelGGL(pose_victim<4>, dim3((unsigned)N), dim3(64), 0, sa, m, pose, betas, trans, feat, Aout, Jout, D); break;
             }
         };

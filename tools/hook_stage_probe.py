@@ -1,4 +1,12 @@
-"""Which stage of the correction hook is sensitive to concurrent kernels on another stream?  (not product code)"""
+"""Which stage of the correction hook is sensitive to concurrent kernels on another stream?  (not product code)
+
+    python tools/hook_stage_probe.py                 the product's own split-f16 feed-forward kernel as the neighbour (exclusive CU since round 4: expected identical)
+    python tools/hook_stage_probe.py aggr [reps]     the library's diagnostic f16-MFMA + streaming-load kernel (interdiff_debug_f16_aggressor: small LDS / register
+                                                     needs, so it DOES share CUs) beside the hook's stages -- the victims of round 5's co-residency question:
+                                                     smpl_pose_kernel + smpl_blend_skin_kernel (verts, jtr), corr_contact_kernel (o2h, idx), objproj_kernel (proj)
+    INTERDIFF_HIP_LIB=build_ab/noslp/libinterdiff_hip.so python tools/hook_stage_probe.py aggr
+                                                     the same with the library built with -fno-slp-vectorize (no compiler-formed packed-fp32 instruction in any victim)
+"""
 import os
 import sys
 import torch
@@ -33,7 +41,16 @@ verts_ref = smpl(pose, th_betas=betas, th_trans=trans, want_v_posed=False)[0].cl
 torch.cuda.synchronize()
 
 
+AGGR_SRC = torch.zeros(64 << 20, device='cuda')          # 256 MB to stream through
+AGGR_SINK = torch.zeros(16, device='cuda')
+
+
 def load_kernels(kind):
+    if kind in ('aggr', 'aggr_noloads'):
+        from interdiff_amd import _lib
+        with torch.cuda.stream(Bs):
+            _lib.check(_lib.load().interdiff_debug_f16_aggressor(_lib.dptr(AGGR_SRC), AGGR_SRC.numel(), _lib.dptr(AGGR_SINK), 5000, 1024, 1 if kind == 'aggr' else 0, _lib.stream()), 'aggressor')
+        return
     with torch.cuda.stream(Bs):
         for i in range(300 if kind else 0):
             if kind == 'torch':
@@ -67,11 +84,24 @@ def stages(kind):
 
 
 ref = stages(None)
-for kind in (None, ('split', 16), ('split', 32), ('split', 16), ('split', 32), ('split', 16), ('split', 32)):
-    for rep in range(4):
+if len(sys.argv) > 1 and sys.argv[1] == 'aggr':
+    from interdiff_amd import _lib
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    print('library', _lib.LIB_PATH)
+    kinds = (None, 'aggr_noloads', 'aggr')
+else:
+    reps, kinds = 4, (None, ('split', 16), ('split', 32), ('split', 16), ('split', 32), ('split', 16), ('split', 32))
+tally = {}
+for kind in kinds:
+    for rep in range(reps):
         got = stages(kind)
         bad = {k: float((ref[k].float() - got[k].float()).abs().max()) for k in ref if not torch.equal(ref[k], got[k])}
         print('load', kind, 'rep', rep, bad if bad else 'identical', flush=True)
+        for k in ref:
+            tally[(str(kind), k)] = tally.get((str(kind), k), 0) + (1 if k in bad else 0)
         if 'jtr' in bad:
             nb = (ref['jtr'] != got['jtr']).any(dim=2).nonzero()
             print('   jtr frames', sorted(set(nb[:, 0].tolist()))[:12], 'joints', sorted(set(nb[:, 1].tolist()))[:20], 'n', nb.shape[0], flush=True)
+print('summary (runs of %d in which a stage output differs from the stage run alone):' % reps)
+for kind in kinds:
+    print('  neighbour %-14s' % (kind,), {k: tally[(str(kind), k)] for k in ref})

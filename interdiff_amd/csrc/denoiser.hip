@@ -934,8 +934,8 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
 // grid (ceil(T/QT), H, B), 256 threads.  LDS: K,V [TP][68], Q [QT][68], S [QT][TP+4]; TP = T rounded up to 16, QT = 16 or 32 query rows.
 // ------------------------------------------------------------------------------------
 constexpr int AS = HD + 4;            // row stride (floats) of the V image: its P.V operand reads are scalar (4 k rows x 16 columns per instruction: 68 keeps the four 16-lane groups on disjoint banks)
-constexpr int SPAD = IDF_LDS_STRIDE_SET == 4 ? 4 : 8;         // padding of a score row (floats)
-constexpr int ASK = HD + SPAD;        // row stride of the Q and K images: their S = Q K^T operands are ds_read_b128 of lane (li, kq) -> row li, slot s0 + kq, and a stride of 2 slots mod 16
+constexpr int SPAD = IDF_LDS_STRIDE_SET == 5 ? 8 : 4;         // padding of a score row (floats); set 6 = set 5 with round 4's score rows (their softmax sweeps prefer 4)
+constexpr int ASK = HD + (IDF_LDS_STRIDE_SET == 4 ? 4 : 8);        // row stride of the Q and K images: their S = Q K^T operands are ds_read_b128 of lane (li, kq) -> row li, slot s0 + kq, and a stride of 2 slots mod 16
                                       // makes those conflict-free (see the row block's HS; round 4 used 68 for all three: every Q / K fragment read took twice its LDS cycles)
 constexpr int ATTN_MAX_T = 208;
 #ifndef IDF_ATTN_RT

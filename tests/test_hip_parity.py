@@ -1069,6 +1069,35 @@ def test_optimize_batch_and_full_schedule(phys):
 
 
 @pytest.mark.gpu
+def test_optimize_config5_named_per_gpu_batch(phys):
+    """BASELINE config #5 at its named per-GPU share (optimization.py on generated HOIs, B = 128 over 8 GPUs = 16 clips per GPU) with clips of the reference's own
+    length, T = 35 (10 past + 25 future; optimization.py:19-173 takes whatever T a clip has), P = 2048 object points: the sixteen clips side by side through the
+    kernels -- one Adam step, then loss parts and the gradients of all six parameter groups at the stepped parameters -- against the autograd oracle
+    (oracle/optimization.py, pinned to the reference's own optimize() by tests/golden/optim.npz) on two of the sixteen; and batch == alone for those two."""
+    from oracle import optimization as oo
+    B, T, P = 16, 35, 2048
+    clips = [fx.optim_inputs(seed=9500 + i, T=T, P=P) for i in range(B)]
+    batch = [torch.stack([c[k] for c in clips]).cuda() for k in range(6)]
+    res = phys.optimize(*batch, iters=[151])
+    assert res['losses'].shape == (1, B, 4) and torch.isfinite(res['losses']).all()
+    parts, grads = phys.loss_and_grads(res['params'], *batch, 152)
+    model = fx.smpl_model()
+    worst = {}
+    for i in (3, 12):
+        alone = phys.optimize(*[a.cuda() for a in clips[i]], iters=[151])
+        for k in ('pose', 'trans', 'obj_angles', 'obj_trans'):
+            assert (res[k][i] - alone[k]).abs().max().item() <= 1e-5, (i, k)
+        ref_parts, ref_grads = oo.loss_and_grads(model, {k: v[i].cpu() for k, v in res['params'].items()}, *clips[i], 152)
+        np.testing.assert_allclose(parts[i].cpu().numpy(), ref_parts.numpy(), rtol=2e-4, atol=1e-5)
+        for n in oo.PARAM_ORDER:
+            ref = ref_grads[n].numpy()
+            e = np.abs(grads[n][i].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+            worst[n] = max(worst.get(n, 0.0), float(e))
+            assert np.abs(grads[n][i].cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, (i, n, e)
+    fx.record_parity('post_optimisation_config5_16clips_T35_P2048_vs_autograd_oracle', clips_checked=2, **{'grad_' + k: v for k, v in worst.items()})
+
+
+@pytest.mark.gpu
 def test_config1_skeleton_plumbing_sampler(lib):
     """BASELINE config #1 (eval_skeleton_no_correction.py: HO-GCN skeleton tokens C = 63+36+7 = 106, B=1, T=20, a 50-step
     cosine schedule, identity denoised_fn :82-83).  The skeleton denoiser is not a kernel target (SURVEY.md §2 row 8);
@@ -1215,7 +1244,7 @@ def test_sampler_with_a_longer_memory_and_a_long_clip(lib, smpl):
         eager = diff.p_sample_loop(model, tuple(noise.shape), use_graph=False, step_noise=_philox_step(lib, 23), **kw)
         assert torch.equal(timed, eager), 'M=%d T=%d: graph route differs from eager: %g' % (M, T, (timed - eager).abs().max())
         stream = _philox_step(lib, 23)
-        ref = odf.p_sample_loop(lambda x, t, yy: oden.mdm_forward(fx.mdm_weights(), x, t, yy['cond']), tuple(noise.shape), odf.make_schedule(1000), noise.clone(),
+        ref = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(fx.mdm_weights(), x, t, y["cond"]), tuple(noise.shape), odf.make_schedule(1000), noise.clone(),
                                 lambda i, x: stream(i, x.to(DEV)).cpu(), {'y': y}, n_steps=n, first_t=900)
         e = close(timed, ref, 1e-4, 'sampler M=%d T=%d vs oracle' % (M, T))
         fx.record_parity('sampler_M%d_T%d_%dsteps_vs_oracle' % (M, T, n), worst_rel_err=e, asserted=1e-4)

@@ -3,16 +3,20 @@
 //     hipcc --offload-arch=gfx950 -O3 tools/coresidency_repro.hip -o coresidency_repro && ./coresidency_repro
 //     hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize tools/coresidency_repro.hip -o coresidency_repro_noslp && ./coresidency_repro_noslp
 //
-// Observation (MI355X, gfx950, ROCm 7.2): a one-wave workgroup that runs plain fp32 VALU code with a PARTIAL exec mask (52 of 64 lanes)
-// occasionally computes WRONG values in lanes 48..51 while, on another stream, a kernel that issues v_mfma_f32_16x16x32_f16 together with
-// streaming global loads is resident on the same CU.  The same victim next to an fp32-MFMA aggressor, next to the f16 MFMAs alone or next
-// to the loads alone is bit-stable.  Nothing is shared between the two kernels (no common buffer, no LDS overlap, different streams).
+// Observation (MI355X, gfx950, ROCm 7.2): a one-wave workgroup whose fp32 VALU code contains PACKED fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32, formed here by the SLP vectoriser) and runs with a PARTIAL exec mask (52 of 64 lanes) occasionally computes WRONG values in lanes 48..51
+// while, on another stream, a kernel that issues v_mfma_f32_16x16x32_f16 is resident on the same CU.  The same victim next to an fp32-MFMA aggressor or next
+// to loads alone is bit-stable; the same victim compiled WITHOUT packed fp32 instructions (-fno-slp-vectorize) is bit-stable next to every aggressor.
+// Nothing is shared between the two kernels (no common buffer, no LDS overlap, different streams).
 //
 // VICTIM:    `victim`, 64 threads: lane j < 52 turns an axis-angle vector into a rotation matrix (quaternion route, ~60 fp32 VALU ops that the
 //            SLP vectoriser turns into v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32), stores the nine entries.  1600 workgroups per launch.
 // AGGRESSOR: `aggressor`, 256 threads: a loop of four v_mfma_f32_16x16x32_f16 on register operands + one 16-byte streaming load per lane.
 // The program runs the victim alone (reference bits), then 48 victim launches beside the aggressor, and counts launches / lanes that differ;
-// then the control runs (aggressor without loads; aggressor with fp32 MFMAs).  Expected on an affected system: "f16 MFMA + loads" > 0, controls 0.
+// then the other aggressor forms (f16 MFMAs without loads; fp32 MFMAs; loads alone).  Seen on MI355X / ROCm 7.2 with the default build: one of the two f16-MFMA
+// forms differs in 30 - 100 % of the victim launches, always lanes 48..51 (which of the two depends on how the two kernels' phases line up: this small victim reacts to
+// "f16 MFMA only", the original SMPL kernel in tools/coresidency_probe.hip to "f16 MFMA + loads"); the fp32-MFMA and loads-only forms: 0.  With -fno-slp-vectorize
+// (no v_pk_*_f32 instruction in the victim): 0 everywhere.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -118,8 +122,8 @@ int main(int argc, char **argv) {
         printf("%-28s: %ld of %d victim launches differ from the victim run alone, %ld words; lanes:", names[kind], bad_launches, trials * REP, bad_words);
         for (int l = 0; l < 64; ++l) if (lane_hist[l]) printf(" %d(%d)", l, lane_hist[l]);
         printf("\n");
-        if (kind == 1 && bad_launches) affected = 1;
+        if ((kind == 1 || kind == 2) && bad_launches) affected = 1;
     }
-    printf(affected ? "AFFECTED: a co-resident f16-MFMA + load kernel changed the victim's results\n" : "not reproduced on this system / build\n");
+    printf(affected ? "AFFECTED: a co-resident kernel issuing v_mfma_f32_16x16x32_f16 changed the victim's results\n" : "not reproduced on this system / build\n");
     return 0;
 }

@@ -46,10 +46,10 @@ AGGR_SINK = torch.zeros(16, device='cuda')
 
 
 def load_kernels(kind):
-    if kind in ('aggr', 'aggr_noloads'):
+    if kind in ('aggr', 'aggr_noloads'):            # 60 000 iterations: several milliseconds, longer than any stage below (the contact scan is 1.3 ms)
         from interdiff_amd import _lib
         with torch.cuda.stream(Bs):
-            _lib.check(_lib.load().interdiff_debug_f16_aggressor(_lib.dptr(AGGR_SRC), AGGR_SRC.numel(), _lib.dptr(AGGR_SINK), 5000, 1024, 1 if kind == 'aggr' else 0, _lib.stream()), 'aggressor')
+            _lib.check(_lib.load().interdiff_debug_f16_aggressor(_lib.dptr(AGGR_SRC), AGGR_SRC.numel(), _lib.dptr(AGGR_SINK), 60000, 1024, 1 if kind == 'aggr' else 0, _lib.stream()), 'aggressor')
         return
     with torch.cuda.stream(Bs):
         for i in range(300 if kind else 0):

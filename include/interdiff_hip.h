@@ -182,7 +182,10 @@ typedef struct {
     /* memory length of the NEXT interdiff_mdm_prepare_memory / forward calls on this handle: rows of cond [mem_len,B,256].  0 = IDF_MDM_MEM (10).  Any 1 ..
      * IDF_MDM_MEM_MAX is served; 10 takes the compact (fast) layout of the folded memory, other lengths a generic one (one more score-column tile in the row
      * block).  A memctx folded at one length must be consumed at the same length (its size differs: interdiff_mdm_memctx_floats_for). */
-    int32_t mem_len, reserved0;
+    int32_t mem_len;
+    /* tokens per workgroup of the split-f16 row block (csrc/denoiser.hip rowblock8_kernel): 0 = by the launch (8 while B x ceil(T / 8) workgroups fit the chip in one
+     * round, else 16), 8 / 16 = forced (A/B runs).  Both forms compute the same bits. */
+    int32_t rb_tokens;
 } idf_mdm_weights;
 
 /* The token GEMM of the denoiser as a standalone op: C[M,N] = epi(A[M,K] . W[N,K]^T + bias) on the fp32 MFMA

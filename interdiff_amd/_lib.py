@@ -38,7 +38,7 @@ class MdmWeights(C.Structure):
     _fields_ = [('C', i32), ('n_steps', i32), ('arena', vp),
                 ('in_w', i64), ('in_b', i64), ('out_w', i64), ('out_b', i64),
                 ('temb_table', i64), ('pe', i64), ('max_T', i32), ('has_encoder', i32),
-                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64), ('tail_h2_ok', i64), ('mem_len', i32), ('reserved0', i32)]
+                ('layer', MdmLayer * MDM_LAYERS), ('enc_layer', MdmLayer * MDM_LAYERS), ('tune', i32 * 8), ('out_w_h2', i64), ('in_w_h2', i64), ('tail_h2_ok', i64), ('mem_len', i32), ('rb_tokens', i32)]
 
 
 class PnMlp(C.Structure):

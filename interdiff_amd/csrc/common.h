@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
+#include <mutex>
+#include <string>
+#include <vector>
 #include "../../include/interdiff_hip.h"
 
 #define IDF_WAVE 64
@@ -48,8 +51,29 @@ struct idf_excl_entry {
     const char *name;
     int threads, num_regs, static_lds, dyn_lds, blocks_per_cu, ok, dev;
 };
-int idf_excl_report(char *buf, int cap);                // prof.hip: the table as text, returns the number of non-exclusive rows
-void idf_excl_record(const idf_excl_entry &e);          // prof.hip (one table per process, mutex inside; not on any hot path: once per kernel and device)
+// one table per process (C++17 inline variables: every translation unit, and every probe build that includes a kernel file whole, sees the same one); not on
+// any hot path: touched once per (kernel, device)
+inline std::mutex g_idf_excl_mu;
+inline std::vector<idf_excl_entry> g_idf_excl;
+inline void idf_excl_record(const idf_excl_entry &e) {
+    std::lock_guard<std::mutex> lk(g_idf_excl_mu);
+    for (idf_excl_entry &o : g_idf_excl)
+        if (o.dev == e.dev && std::string(o.name) == e.name) { o = e; return; }
+    g_idf_excl.push_back(e);
+}
+inline int idf_excl_report(char *buf, int cap) {        // the table as text; returns the number of non-exclusive rows
+    std::lock_guard<std::mutex> lk(g_idf_excl_mu);
+    int bad = 0, n = 0;
+    buf[0] = 0;
+    for (const idf_excl_entry &e : g_idf_excl) {
+        bad += e.ok ? 0 : 1;
+        const int w = snprintf(buf + n, (size_t)(cap - n), "%-52s dev %d  threads %3d  regs %3d  lds %6d + %6d  workgroups_per_cu %d  %s\n", e.name, e.dev, e.threads, e.num_regs,
+                               e.static_lds, e.dyn_lds, e.blocks_per_cu, e.ok ? "exclusive" : "NOT exclusive -> fp32 kernel");
+        if (w < 0 || w >= cap - n) break;
+        n += w;
+    }
+    return bad;
+}
 struct idf_excl_cache {
     std::atomic<uint64_t> yes{0}, no{0};
     std::atomic<int> dyn{-1};
@@ -83,6 +107,19 @@ static inline int idf_exclusive_cu(const void *fn, const char *name, int threads
     fprintf(stderr, "interdiff_hip: %s does not get its CU to itself on device %d (regs %d, LDS %d + %d, %d workgroups per CU): the fp32-MFMA kernel runs instead\n",
             name, dev, e.num_regs, e.static_lds, e.dyn_lds, e.blocks_per_cu);
     return -1;
+}
+
+// CUs of the current device (256 on MI355X): how many one-per-CU workgroups one round holds (launch geometry choices only; cached per device)
+static inline int idf_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cached[dev & 63].load(std::memory_order_acquire);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev & 63].store(n, std::memory_order_release);
+    }
+    return n;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -595,78 +595,106 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 // summation order only (eight K partials instead of four; 32-lane LayerNorm sums); every route of a process takes the same kernel, so bit-identity between routes holds.
 // Reference work being replaced: model/sublayers.py:311-352 (QaN block + cross-attention + the two LayerNorms around them).
 // ------------------------------------------------------------------------------------
-struct Row32 {
-    float4 c[2];                                  // lane l32 of a row's 32 lanes owns the 4-float chunks l32 and 32 + l32
+// Token rows of the eight-wave row block: LPR lanes per row (32 with 16 tokens per workgroup, 64 with 8), lane lr owns the 4-float chunks lr, LPR + lr, ...
+// The two forms compute the SAME bits: every per-element operation is the same, and a row's two LayerNorm sums are taken over one fixed tree whatever LPR is --
+// leaves = the 64 chunks' partial sums, then chunk k + chunk k + 32, then the 16-lane rotation tree inside {0..15} and {16..31}, then the two halves -- so the number of
+// tokens a workgroup takes is a pure performance choice (like the row tile of ffn_h2.h): shards / chains of a batch that pick differently still agree bit for bit.
+template <int LPR>
+struct RowL {
+    static constexpr int CPL = 64 / LPR;          // chunks per lane: 2 or 1
+    float4 c[CPL];
 };
 #define IDF_SWZ_XOR16(v) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F))      // lane i <- lane i ^ 16 (bit-mask mode: and 0x1f, or 0, xor 0x10)
-__device__ __forceinline__ float row32_sum(float v) {
+// sum over a row's 64 chunk partials; `v` = this lane's partial(s) already added in chunk order (LPR = 32: chunk lr + chunk 32 + lr)
+template <int LPR>
+__device__ __forceinline__ float rowl_sum(float v) {
+    if constexpr (LPR == 64) v += __shfl_xor(v, 32);      // chunk k + chunk k ^ 32: what the 32-lane form adds inside a lane (commutative: both lanes hold the same bits)
     v = row16_sum(v);
     return v + IDF_SWZ_XOR16(v);
 }
-template <int NP>
-struct Row32Raw {
-    float4 t[2][NP];
-    __device__ __forceinline__ void request(const float *__restrict__ row, int l32, size_t stride) {
+template <int LPR, int NP>
+struct RowLRaw {
+    static constexpr int CPL = 64 / LPR;
+    float4 t[CPL][NP];
+    __device__ __forceinline__ void request(const float *__restrict__ row, int lr, size_t stride) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < CPL; ++i)
 #pragma unroll
-            for (int s = 0; s < NP; ++s) t[i][s] = ld4(row + s * stride + (i * 32 + l32) * 4);
+            for (int sl = 0; sl < NP; ++sl) t[i][sl] = ld4(row + sl * stride + (i * LPR + lr) * 4);
     }
-    __device__ __forceinline__ void reduce(Row32 &r) const {      // slabs summed in the order of common.h ld4_sum
+    __device__ __forceinline__ void reduce(RowL<LPR> &r) const {      // slabs summed in the order of common.h ld4_sum
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CPL; ++i) {
             float4 v = t[i][0];
 #pragma unroll
-            for (int s = 1; s < NP; ++s) { v.x += t[i][s].x; v.y += t[i][s].y; v.z += t[i][s].z; v.w += t[i][s].w; }
+            for (int sl = 1; sl < NP; ++sl) { v.x += t[i][sl].x; v.y += t[i][sl].y; v.z += t[i][sl].z; v.w += t[i][sl].w; }
             r.c[i] = v;
         }
     }
 };
-__device__ __forceinline__ void ln_row32_lds(Row32 &r, const float *w, const float *b, int l32) {
-    float sum = 0.f;
+template <int LPR>
+__device__ __forceinline__ void ln_rowl_lds(RowL<LPR> &r, const float *w, const float *b, int lr) {
+    // no FMA contraction in the row passes of this kernel: WHICH product of `a * a + b * b` (or of a * b + c written over two statements) the backend fuses is its own choice per
+    // instantiation, and the 8- and the 16-token form must round alike (every product and every sum rounded on its own, like the sampler update of gemm.h)
+#pragma clang fp contract(off)
+    constexpr int CPL = 64 / LPR;
+    float sum = (r.c[0].x + r.c[0].y) + (r.c[0].z + r.c[0].w);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sum += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
-    const float mean = row32_sum(sum) * (1.0f / 256.0f);
+    for (int i = 1; i < CPL; ++i) sum += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
+    const float mean = rowl_sum<LPR>(sum) * (1.0f / 256.0f);
     float qv = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CPL; ++i) {
         const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
-        qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        const float qi = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        qv = i == 0 ? qi : qv + qi;
     }
-    const float rstd = __builtin_amdgcn_rsqf(row32_sum(qv) * (1.0f / 256.0f) + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(rowl_sum<LPR>(qv) * (1.0f / 256.0f) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float4 g = *reinterpret_cast<const float4 *>(w + (i * 32 + l32) * 4), be = *reinterpret_cast<const float4 *>(b + (i * 32 + l32) * 4);
+    for (int i = 0; i < CPL; ++i) {
+        const float4 g = *reinterpret_cast<const float4 *>(w + (i * LPR + lr) * 4), be = *reinterpret_cast<const float4 *>(b + (i * LPR + lr) * 4);
         r.c[i].x = (r.c[i].x - mean) * rstd * g.x + be.x;
         r.c[i].y = (r.c[i].y - mean) * rstd * g.y + be.y;
         r.c[i].z = (r.c[i].z - mean) * rstd * g.z + be.z;
         r.c[i].w = (r.c[i].w - mean) * rstd * g.w + be.w;
     }
 }
-__device__ __forceinline__ void row32_load(Row32 &r, const float *row, int l32) {
+template <int LPR>
+__device__ __forceinline__ void rowl_load(RowL<LPR> &r, const float *row, int lr) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * 32 + l32) * 4);
+    for (int i = 0; i < 64 / LPR; ++i) r.c[i] = *reinterpret_cast<const float4 *>(row + (i * LPR + lr) * 4);
 }
-__device__ __forceinline__ void row32_store(const Row32 &r, float *row, int l32) {
+template <int LPR>
+__device__ __forceinline__ void rowl_store(const RowL<LPR> &r, float *row, int lr) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(row + (i * 32 + l32) * 4) = r.c[i];
+    for (int i = 0; i < 64 / LPR; ++i) *reinterpret_cast<float4 *>(row + (i * LPR + lr) * 4) = r.c[i];
 }
-__device__ __forceinline__ void row32_store_wt(const Row32 &r, float *row, int l32) {
+template <int LPR>
+__device__ __forceinline__ void rowl_store_wt(const RowL<LPR> &r, float *row, int lr) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) idf_store16_wt(row + (i * 32 + l32) * 4, r.c[i]);
+    for (int i = 0; i < 64 / LPR; ++i) idf_store16_wt(row + (i * LPR + lr) * 4, r.c[i]);
 }
-__device__ __forceinline__ void row32_zero(Row32 &r) { r.c[0] = r.c[1] = zero4(); }
-__device__ __forceinline__ void row32_store_planes(const Row32 &r, _Float16 *hi_row, _Float16 *lo_row, int l32) {
+template <int LPR>
+__device__ __forceinline__ void rowl_zero(RowL<LPR> &r) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 64 / LPR; ++i) r.c[i] = zero4();
+}
+template <int LPR>
+__device__ __forceinline__ void rowl_store_planes(const RowL<LPR> &r, _Float16 *hi_row, _Float16 *lo_row, int lr) {
+#pragma unroll
+    for (int i = 0; i < 64 / LPR; ++i) {
         uint2 h, l;
         idf_ffn_h2::split4_pk(r.c[i], h, l);
-        *reinterpret_cast<uint2 *>(hi_row + (i * 32 + l32) * 4) = h;
-        *reinterpret_cast<uint2 *>(lo_row + (i * 32 + l32) * 4) = l;
+        *reinterpret_cast<uint2 *>(hi_row + (i * LPR + lr) * 4) = h;
+        *reinterpret_cast<uint2 *>(lo_row + (i * LPR + lr) * 4) = l;
     }
 }
 
-template <bool QAN, int NP, int MS = MEM>
+// TV = tokens per workgroup: 16 (grid ceil(T/16) x B) or 8 (grid ceil(T/8) x B).  The row passes are bound by the CU's VALU issue (tools/rowblock_probe.hip: eight waves
+// instead of four changed them by 6 % -- the same instructions on the same four SIMDs), so what shortens them is FEWER ROWS PER CU: with eight tokens the launch is
+// 208 workgroups at B = 16, T = 100 -- one round on 256 CUs instead of 112 -- each with half the row work; the MFMA tiles stay 16 rows tall (rows >= TV + 2 of the A
+// operands are whatever LDS holds: they only reach output rows nobody stores).  The launcher takes 8 whenever the launch still fits the chip in one round.
+template <bool QAN, int NP, int MS = MEM, int TV = 16>
 __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
                                                         const float *__restrict__ lnp_b, const float *__restrict__ Qc,
                                                         const float *__restrict__ wk, const float *__restrict__ ln1_w,
@@ -676,28 +704,33 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
                                                         const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
                                                         size_t u_pstride, const float *__restrict__ sa_resid, const float *__restrict__ sa_bias,
                                                         const float *__restrict__ h2_scale, int mem_len) {
+#pragma clang fp contract(off)                    // (see ln_rowl_lds: the two token counts must compute the same bits)
     using idf_ffn_h2::h8;
     using ML = MemLay<MS>;
+    static_assert(TV == 16 || TV == 8, "tokens per workgroup");
     constexpr int NCT = ML::NCT, NSLOT = ML::NSLOT, NW8 = 8, NPT = NCT > 3 ? NCT : 3;
+    constexpr int LPR = 512 / TV;                 // lanes per token row in the row passes
+    constexpr int PTR = 17, PTS = 16 * PTR;       // K-split partial tiles: row stride 17 floats (the head softmax reads a tile column-wise: 16 would be a 4-way bank conflict)
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     constexpr int HS = D + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16), PHS = 64 + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16);     // plane strides: conflict-free fragment reads (rowblock_kernel)
     const int mlen = ML::GEN ? mem_len : MEM;
-    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * (TR + 2) * HS];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * (TR + 2) * HS];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores (TV + 2 rows are written)
     __shared__ __attribute__((aligned(16))) _Float16 ppl[2 * TR * PHS];            // [hi | lo'][TR][PHS]: probabilities, unwritten columns stay zero
     _Float16 *const xh = xpl, *const xl = xpl + (TR + 2) * HS, *const ph = ppl, *const pl = ppl + TR * PHS;
     __shared__ __attribute__((aligned(1024))) float prm[8 * 256];        // LN_prev / LN1 / LN2 gamma, beta + cross-attention output bias + self-attention output bias (DMA targets)
-    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + NW8 * NPT * 256];
-    float *xs = sm;                               // [TR+2][RS]  LN_prev rows t0-1 .. t0+16 (QAN)
+    __shared__ __attribute__((aligned(16))) float sm[XS + TR * RS + NW8 * NPT * PTS];
+    float *xs = sm;                               // [TV+2 of TR+2][RS]  LN_prev rows t0-1 .. t0+TV (QAN)
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
-    float *part = x1s + TR * RS;                  // [8 waves][3 taps | NCT score tiles][16x16] K-split partial tiles
+    float *part = x1s + TR * RS;                  // [8 waves][3 taps | NCT score tiles][16][17] K-split partial tiles
 
     idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, u_pstride, sa_resid, sa_bias, h2_scale, mem_len, gridDim.x, gridDim.y);
     asm volatile("" ::: "v255");                  // EXCLUSIVE CU (ffn_h2.h): 2 waves per SIMD x 256 registers = the register file; the launcher tops the LDS up to 160 KiB
-    const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TR;
+    const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int rg = tid >> 5, l32 = tid & 31;      // row passes: token row rg of the 16, lane l32 of its 32
+    const int rg = tid / LPR, lr = tid % LPR;     // row passes: token row rg of the TV, lane lr of its LPR; threads of rows 0 and 1 also take the two halo rows (QAN)
     const size_t rowbase = (size_t)b * T;
+    IDF_RB_STAMP(0);
     const float *Gb = G + (size_t)b * ML::G_H2, *g0b = g0 + b * ML::G0N, *VWTb = VWT + (size_t)b * VW_H2;
     for (int i = tid; i < 2 * TR * PHS / 8; i += 512) reinterpret_cast<float4 *>(ppl)[i] = zero4();
 
@@ -709,24 +742,25 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
         for (int i = 0; i < 8; ++i)
             if (i == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
     }
-    Row32 ra, rb;
+    RowL<LPR> ra, rb;
     float4 q[2][3], gv[2][NCT], vw2[2][2][2];     // plane fragments: q[plane][tap], gv[plane][column tile] of this wave's K step; vw2[K step][tile][plane] of its two output tiles
     float wk_n = 0.f, g0v[NSLOT];
     const float gsc = h2_scale[2 * b], vsc = h2_scale[2 * b + 1];
     const int hh = wave & 3;                      // head softmax: waves 0..3, wave = head
-    const int ta = QAN ? t0 - 1 + rg : t0 + rg, tb = t0 + 15 + (lane >> 5);
-    const bool va = ta >= 0 && ta < T, vb = QAN && wave == 0 && tb < T;
-    Row32Raw<NP> raw_a, raw_b;
-    Row32Raw<1> raw_r;
+    const int ta = QAN ? t0 - 1 + rg : t0 + rg, tb = t0 + TV - 1 + rg;
+    const bool halo = QAN && rg < 2;
+    const bool va = ta >= 0 && ta < T, vb = halo && tb < T;
+    RowLRaw<LPR, NP> raw_a, raw_b;
+    RowLRaw<LPR, 1> raw_r;
     if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) g0v[i] = g0b[ML::col(hh, min((lane & 3) + 4 * i, mlen - 1))];
     if constexpr (QAN) {
-        if (wave == 0) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, l32, u_pstride);     // halo rows t0+15, t0+16: the two halves of wave 0
+        if (halo) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, lr, u_pstride);     // halo rows t0 + TV - 1, t0 + TV: the threads of rows 0 and 1 (wave-uniform: LPR >= 32)
     }
-    raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, l32, u_pstride);
+    raw_a.request(u_in + (rowbase + min(max(ta, 0), T - 1)) * D, lr, u_pstride);
     if constexpr (!QAN) {
-        if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, l32, 0);
+        if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, lr, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (QAN) {
@@ -742,12 +776,14 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    IDF_RB_STAMP(9);                                     // every request of the first batch issued
     if constexpr (QAN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // everything older than the six learned-query fragment loads has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDF_RB_STAMP(10);                                    // this wave's share has landed
     __syncthreads();
     raw_a.reduce(ra);
     if constexpr (QAN) {
-        if (wave == 0) raw_b.reduce(rb);
+        if (halo) raw_b.reduce(rb);
     }
     const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
                 *P_bout = prm + 1536, *P_sab = prm + 1792;
@@ -768,19 +804,20 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
 
     if constexpr (QAN) {
         if (lnp_w) {
-            ln_row32_lds(ra, P_lnp_w, P_lnp_b, l32);
-            if (wave == 0) ln_row32_lds(rb, P_lnp_w, P_lnp_b, l32);
+            ln_rowl_lds<LPR>(ra, P_lnp_w, P_lnp_b, lr);
+            if (halo) ln_rowl_lds<LPR>(rb, P_lnp_w, P_lnp_b, lr);
         }
-        if (!va) row32_zero(ra);
-        if (!vb) row32_zero(rb);
-        row32_store(ra, xs + rg * RS, l32);
-        row32_store_planes(ra, xh + rg * HS, xl + rg * HS, l32);
-        if (wave == 0) {
-            row32_store(rb, xs + (16 + (lane >> 5)) * RS, l32);
-            row32_store_planes(rb, xh + (16 + (lane >> 5)) * HS, xl + (16 + (lane >> 5)) * HS, l32);
+        if (!va) rowl_zero<LPR>(ra);
+        if (!vb) rowl_zero<LPR>(rb);
+        rowl_store<LPR>(ra, xs + rg * RS, lr);
+        rowl_store_planes<LPR>(ra, xh + rg * HS, xl + rg * HS, lr);
+        if (halo) {
+            rowl_store<LPR>(rb, xs + (TV + rg) * RS, lr);
+            rowl_store_planes<LPR>(rb, xh + (TV + rg) * HS, xl + (TV + rg) * HS, lr);
         }
         fetch_g();
         __syncthreads();
+        IDF_RB_STAMP(1);                                 // rows loaded (+ slab sum), LN_prev, planes
         {   // logits: three 16x16 tiles (taps), this wave contracts K = [32 wave, 32 wave + 32)
             f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_c[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             const int koff = 32 * wave + 8 * kq;
@@ -794,66 +831,70 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * 256 + (kq * 4 + r) * 16 + li] = acc[j][r] + acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
+                for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * PTS + (kq * 4 + r) * PTR + li] = acc[j][r] + acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
         }
         fetch_vw();
         __syncthreads();
+        IDF_RB_STAMP(2);                                 // logits MFMA
         float c0, c1, c2;
-        {   // tap softmax + coefficients: both 16-lane halves of a row compute them (query n = l32 & 15), so no exchange is needed before the stencil
-            const int n = min(l32 & 15, NQ - 1);
+        {   // tap softmax + coefficients: every 16-lane group of a row computes them (query n = lane & 15), so no exchange is needed before the stencil
+            const int n = min(li, NQ - 1);
             float l[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float *pp = part + j * 256 + rg * 16 + n;
-                l[j] = ((pp[0 * 768] + pp[1 * 768]) + (pp[2 * 768] + pp[3 * 768])) + ((pp[4 * 768] + pp[5 * 768]) + (pp[6 * 768] + pp[7 * 768]));
+                const float *pp = part + j * PTS + rg * PTR + n;
+                constexpr int WS3 = 3 * PTS;
+                l[j] = ((pp[0 * WS3] + pp[1 * WS3]) + (pp[2 * WS3] + pp[3 * WS3])) + ((pp[4 * WS3] + pp[5 * WS3]) + (pp[6 * WS3] + pp[7 * WS3]));
             }
             const int tg = t0 + rg;
             if (tg <= 0) l[0] = -FLT_MAX;
             if (tg + 1 >= T) l[2] = -FLT_MAX;
             const float mx = fmaxf(l[0], fmaxf(l[1], l[2]));
             const float e0 = __expf(l[0] - mx), e1 = __expf(l[1] - mx), e2 = __expf(l[2] - mx);
-            const float w = (l32 & 15) < NQ ? wk_n / (e0 + e1 + e2) : 0.f;
+            const float w = li < NQ ? wk_n / (e0 + e1 + e2) : 0.f;
             c0 = row16_sum(w * e0);
             c1 = row16_sum(w * e1);
             c2 = row16_sum(w * e2);
         }
+        IDF_RB_STAMP(3);                                 // tap softmax + coefficient sums
         {   // u1 = x_t + sum_j c_j x_{t+j-1} ;  x1 = LN1(u1)
-            Row32 xm, xc, xp;
-            row32_load(xm, xs + rg * RS, l32);
-            row32_load(xc, xs + (rg + 1) * RS, l32);
-            row32_load(xp, xs + (rg + 2) * RS, l32);
+            RowL<LPR> xm, xc, xp;
+            rowl_load<LPR>(xm, xs + rg * RS, lr);
+            rowl_load<LPR>(xc, xs + (rg + 1) * RS, lr);
+            rowl_load<LPR>(xp, xs + (rg + 2) * RS, lr);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 64 / LPR; ++i) {
                 xc.c[i].x = xc.c[i].x + (c0 * xm.c[i].x + c1 * xc.c[i].x + c2 * xp.c[i].x);
                 xc.c[i].y = xc.c[i].y + (c0 * xm.c[i].y + c1 * xc.c[i].y + c2 * xp.c[i].y);
                 xc.c[i].z = xc.c[i].z + (c0 * xm.c[i].z + c1 * xc.c[i].z + c2 * xp.c[i].z);
                 xc.c[i].w = xc.c[i].w + (c0 * xm.c[i].w + c1 * xc.c[i].w + c2 * xp.c[i].w);
             }
-            ln_row32_lds(xc, P_ln1_w, P_ln1_b, l32);
-            row32_store_planes(xc, xh + rg * HS, xl + rg * HS, l32);      // (the logits' reads of these planes ended at the barrier above)
-            row32_store(xc, x1s + rg * RS, l32);
+            ln_rowl_lds<LPR>(xc, P_ln1_w, P_ln1_b, lr);
+            rowl_store_planes<LPR>(xc, xh + rg * HS, xl + rg * HS, lr);      // (the logits' reads of these planes ended at the barrier above)
+            rowl_store<LPR>(xc, x1s + rg * RS, lr);
         }
     } else {
         if (sa_resid) {                               // u1 = (head partials) + xn + b_o   (workgroup-uniform branch)
-            Row32 rr;
+            RowL<LPR> rr;
             raw_r.reduce(rr);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 bo = *reinterpret_cast<const float4 *>(P_sab + (i * 32 + l32) * 4);
+            for (int i = 0; i < 64 / LPR; ++i) {
+                const float4 bo = *reinterpret_cast<const float4 *>(P_sab + (i * LPR + lr) * 4);
                 ra.c[i].x += rr.c[i].x + bo.x;
                 ra.c[i].y += rr.c[i].y + bo.y;
                 ra.c[i].z += rr.c[i].z + bo.z;
                 ra.c[i].w += rr.c[i].w + bo.w;
             }
         }
-        if (!va) row32_zero(ra);
+        if (!va) rowl_zero<LPR>(ra);
         fetch_g();
         fetch_vw();
-        ln_row32_lds(ra, P_ln1_w, P_ln1_b, l32);
-        row32_store_planes(ra, xh + rg * HS, xl + rg * HS, l32);
-        row32_store(ra, x1s + rg * RS, l32);
+        ln_rowl_lds<LPR>(ra, P_ln1_w, P_ln1_b, lr);
+        rowl_store_planes<LPR>(ra, xh + rg * HS, xl + rg * HS, lr);
+        rowl_store<LPR>(ra, x1s + rg * RS, lr);
     }
     __syncthreads();
+    IDF_RB_STAMP(4);                                     // stencil + LN1
     {   // folded cross-attention scores: NCT 16x16 tiles, this wave's K step
         f32x4 acc[NCT], acc_c[NCT];
 #pragma unroll
@@ -867,17 +908,18 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(wave * NCT + ct) * 256 + (kq * 4 + r) * 16 + li] = (acc[ct][r] + acc_c[ct][r] * idf_ffn_h2::LO_UNSCALE) * gsc;      // G[b] was divided by gsc (a power of two)
+            for (int r = 0; r < 4; ++r) part[(wave * NCT + ct) * PTS + (kq * 4 + r) * PTR + li] = (acc[ct][r] + acc_c[ct][r] * idf_ffn_h2::LO_UNSCALE) * gsc;      // G[b] was divided by gsc (a power of two)
     }
     __syncthreads();
+    IDF_RB_STAMP(5);                                     // folded scores MFMA
     if (wave < 4) {   // softmax over the memory slots of each head: wave = head, token = lane >> 2, the four lanes of a quad take slots q, q+4, ... (rowblock_kernel)
         const int tq = lane >> 2, qd = lane & 3;
         float sc[NSLOT], mx = -FLT_MAX;
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int m = qd + 4 * i, idx = ML::col(wave, min(m, mlen - 1)), ct = idx >> 4, cl = idx & 15;
-            const float *pp = part + ct * 256 + tq * 16 + cl;
-            constexpr int WS8 = NCT * 256;
+            const float *pp = part + ct * PTS + tq * PTR + cl;
+            constexpr int WS8 = NCT * PTS;
             const float v = (((pp[0 * WS8] + pp[1 * WS8]) + (pp[2 * WS8] + pp[3 * WS8])) + ((pp[4 * WS8] + pp[5 * WS8]) + (pp[6 * WS8] + pp[7 * WS8]))) + g0v[i];
             sc[i] = m < mlen ? v : -FLT_MAX;
             mx = fmaxf(mx, sc[i]);
@@ -903,6 +945,7 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
             }
     }
     __syncthreads();
+    IDF_RB_STAMP(6);                                     // head softmax
     {   // u2 = x1 + P.VW + b_out : wave w owns output columns [32 w, 32 w + 32)
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -916,17 +959,20 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
         for (int c = 0; c < 2; ++c) {
             const int col = (wave * 2 + c) * 16 + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] += (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc + P_bout[col];       // VW[b] was divided by vsc
+            for (int r = 0; r < 4; ++r)
+                if (TV == 16 || kq * 4 + r < TV) x1s[(kq * 4 + r) * RS + col] += (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc + P_bout[col];       // VW[b] was divided by vsc
         }
     }
     __syncthreads();
+    IDF_RB_STAMP(7);                                     // P.VW MFMA
     {
         const int t = t0 + rg;
-        Row32 r;
-        row32_load(r, x1s + rg * RS, l32);
-        ln_row32_lds(r, P_ln2_w, P_ln2_b, l32);
-        if (t < T) row32_store_wt(r, x2_out + (rowbase + t) * D, l32);
+        RowL<LPR> r;
+        rowl_load<LPR>(r, x1s + rg * RS, lr);
+        ln_rowl_lds<LPR>(r, P_ln2_w, P_ln2_b, lr);
+        if (t < T) rowl_store_wt<LPR>(r, x2_out + (rowbase + t) * D, lr);
     }
+    IDF_RB_STAMP(8);                                     // LN2 + store
 }
 
 // ------------------------------------------------------------------------------------
@@ -1667,15 +1713,25 @@ int rb_h2_qan_dyn() {
     return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock_kernel<true, true, NSL, true, MS>), MS == MEM ? "rowblock_kernel<QaN, split-f16>" : "rowblock_kernel<QaN, split-f16, any memory length>", 256, excl);
 }
 // the eight-wave form (rowblock8_kernel: the shipped split-f16 row block since round 5; tune[IDF_TUNE_MISC] == 8 keeps round 4's four-wave kernel for A/B)
-template <int MS>
+template <int MS, int TV>
 int rb8_qan_dyn() {
     static idf_excl_cache excl;
-    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<true, NSL, MS>), MS == MEM ? "rowblock8_kernel<QaN, split-f16>" : "rowblock8_kernel<QaN, split-f16, any memory length>", 512, excl);
+    static const char *const nm[4] = {"rowblock8_kernel<QaN, split-f16, 16 tokens>", "rowblock8_kernel<QaN, split-f16, 8 tokens>", "rowblock8_kernel<QaN, split-f16, 16 tokens, any memory length>",
+                                      "rowblock8_kernel<QaN, split-f16, 8 tokens, any memory length>"};
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<true, NSL, MS, TV>), nm[(MS == MEM ? 0 : 2) + (TV == 8 ? 1 : 0)], 512, excl);
 }
-template <int MS>
+template <int MS, int TV>
 int rb8_std_dyn() {
     static idf_excl_cache excl;
-    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<false, H, MS>), MS == MEM ? "rowblock8_kernel<std, split-f16>" : "rowblock8_kernel<std, split-f16, any memory length>", 512, excl);
+    static const char *const nm[4] = {"rowblock8_kernel<std, split-f16, 16 tokens>", "rowblock8_kernel<std, split-f16, 8 tokens>", "rowblock8_kernel<std, split-f16, 16 tokens, any memory length>",
+                                      "rowblock8_kernel<std, split-f16, 8 tokens, any memory length>"};
+    return idf_exclusive_cu(reinterpret_cast<const void *>(rowblock8_kernel<false, H, MS, TV>), nm[(MS == MEM ? 0 : 2) + (TV == 8 ? 1 : 0)], 512, excl);
+}
+// tokens per workgroup of the eight-wave row block: w->rb_tokens (8 / 16), or 0 = eight whenever the launch still fits the chip in one round of workgroups (the two forms
+// compute the same bits: rowblock8_kernel)
+inline int rb8_tokens(const idf_mdm_weights *w, int B, int T) {
+    if (w->rb_tokens == 8 || w->rb_tokens == 16) return w->rb_tokens;
+    return (int64_t)B * idf_cdiv(T, 8) <= idf_cu_count() ? 8 : 16;
 }
 template <int MS>
 int rb_h2_std_dyn() {
@@ -1749,6 +1805,8 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
     const float *lnp_w = nullptr, *lnp_b = nullptr;   // LayerNorm still to be applied to u_in (none for layer 0)
     if (attn_opt_in() != IDF_OK) return IDF_E_LAUNCH;
     const dim3 rb_grid((unsigned)idf_cdiv(T, TR), B);
+    const int tv8 = rb8_tokens(w, B, T);
+    const dim3 rb8_grid((unsigned)idf_cdiv(T, 8), B);
     for (int l = 0; l < L; ++l) {
         const idf_mdm_layer &ly = w->layer[l];
         const float *Gl = G + (size_t)l * B * G_FRAG, *VWTl = VWT + (size_t)l * B * ML::VWT_F, *g0l = g0 + (size_t)l * B * ML::G0N;
@@ -1758,10 +1816,14 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
         if (ly.is_qan) {
             idf_prof_mark(IDF_K_ROWBLOCK_QAN, s);
             const bool rb8 = tune[IDF_TUNE_MISC] != 8;
-            const int dyn8 = rb_h2 && rb8 ? rb8_qan_dyn<MS>() : -1;
+            const int dyn8 = rb_h2 && rb8 ? (tv8 == 8 ? rb8_qan_dyn<MS, 8>() : rb8_qan_dyn<MS, 16>()) : -1;
             const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_qan_dyn<MS>() : -1;
-            if (dyn8 >= 0) {
-                rowblock8_kernel<true, NSL, MS><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
+            if (dyn8 >= 0 && tv8 == 8) {
+                rowblock8_kernel<true, NSL, MS, 8><<<rb8_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, pstride, nullptr, nullptr, scl, mlen);
+            } else if (dyn8 >= 0) {
+                rowblock8_kernel<true, NSL, MS, 16><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, pstride, nullptr, nullptr, scl, mlen);
             } else if (dyn >= 0) {
@@ -1799,10 +1861,14 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                 if (rc_ah2 == IDF_NOT_EXCLUSIVE) launch_self_attn_outproj(s, k.qkv, B, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
                 const bool rb8 = tune[IDF_TUNE_MISC] != 8;
-                const int dyn8 = rb_h2 && rb8 ? rb8_std_dyn<MS>() : -1;
+                const int dyn8 = rb_h2 && rb8 ? (tv8 == 8 ? rb8_std_dyn<MS, 8>() : rb8_std_dyn<MS, 16>()) : -1;
                 const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_std_dyn<MS>() : -1;
-                if (dyn8 >= 0) {
-                    rowblock8_kernel<false, H, MS><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
+                if (dyn8 >= 0 && tv8 == 8) {
+                    rowblock8_kernel<false, H, MS, 8><<<rb8_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
+                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, T, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
+                } else if (dyn8 >= 0) {
+                    rowblock8_kernel<false, H, MS, 16><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
                 } else if (dyn >= 0) {
@@ -1927,10 +1993,14 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
     rb_h2_std_dyn<MEM>();
     rb_h2_qan_dyn<MEMX>();
     rb_h2_std_dyn<MEMX>();
-    rb8_qan_dyn<MEM>();
-    rb8_std_dyn<MEM>();
-    rb8_qan_dyn<MEMX>();
-    rb8_std_dyn<MEMX>();
+    rb8_qan_dyn<MEM, 16>();
+    rb8_std_dyn<MEM, 16>();
+    rb8_qan_dyn<MEM, 8>();
+    rb8_std_dyn<MEM, 8>();
+    rb8_qan_dyn<MEMX, 16>();
+    rb8_std_dyn<MEMX, 16>();
+    rb8_qan_dyn<MEMX, 8>();
+    rb8_std_dyn<MEMX, 8>();
     idf_tail_h2::tail_exclusive_ok(false);
     idf_tail_h2::tail_exclusive_ok(true);
     return idf_excl_report(buf, cap);

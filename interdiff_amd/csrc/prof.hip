@@ -52,33 +52,6 @@ extern "C" int interdiff_profile_end(double *ms_per_kind, int64_t *count_per_kin
     return IDF_OK;
 }
 
-// ---- verdicts of the exclusive-CU check (common.h idf_exclusive_cu): one row per (kernel name, device), the latest verdict wins
-#include <mutex>
-#include <string>
-namespace {
-std::mutex g_excl_mu;
-std::vector<idf_excl_entry> g_excl;
-}  // namespace
-void idf_excl_record(const idf_excl_entry &e) {
-    std::lock_guard<std::mutex> lk(g_excl_mu);
-    for (idf_excl_entry &o : g_excl)
-        if (o.dev == e.dev && std::string(o.name) == e.name) { o = e; return; }
-    g_excl.push_back(e);
-}
-int idf_excl_report(char *buf, int cap) {
-    std::lock_guard<std::mutex> lk(g_excl_mu);
-    int bad = 0, n = 0;
-    buf[0] = 0;
-    for (const idf_excl_entry &e : g_excl) {
-        bad += e.ok ? 0 : 1;
-        const int w = snprintf(buf + n, (size_t)(cap - n), "%-42s dev %d  threads %3d  regs %3d  lds %6d + %6d  workgroups_per_cu %d  %s\n", e.name, e.dev, e.threads, e.num_regs,
-                               e.static_lds, e.dyn_lds, e.blocks_per_cu, e.ok ? "exclusive" : "NOT exclusive -> fp32 kernel");
-        if (w < 0 || w >= cap - n) break;
-        n += w;
-    }
-    return bad;
-}
-
 // ---- LDS sentinel (tools/lds_sentinel_probe.py): a one-wave workgroup fills its 6 KiB of LDS with a pattern and keeps re-reading it;
 // any word that changes was written by somebody else.  Diagnostic only.
 namespace {

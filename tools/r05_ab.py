@@ -1,5 +1,6 @@
 """Round-5 same-process A/Bs on one box (not product code): settings alternate, every setting measured `reps` times.
 
+    python tools/r05_ab.py rb_tokens [reps]       eight-wave row block with 8 vs 16 tokens per workgroup (R05_CLIPS=32: at BASELINE config #3's batch, two chains)
     python tools/r05_ab.py rowblock_waves [reps]  the split-f16 row block: eight-wave kernel (shipped) vs round 4's four-wave kernel (tune[IDF_TUNE_MISC] = 8)
     python tools/r05_ab.py tail_order [reps]      step-tail workgroup order: XCD-affine row tiles (shipped, tune[IDF_TUNE_MISC] = 0) vs plain ids (= 7, round 4)
     INTERDIFF_HIP_LIB=<variant .so> python tools/r05_ab.py once     one measurement of whatever library is loaded (forward + whole samples): for library-level A/Bs
@@ -40,11 +41,20 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     torch.set_grad_enabled(False)
     dev = torch.device('cuda:0')
+    bench.B_PER_GPU = int(os.environ.get('R05_CLIPS', bench.B_PER_GPU))       # (32: BASELINE config #3, stepped as two chains)
     model, corr, bt, y, _ = bench.build_world(dev, 0)
     diff = create_gaussian_diffusion('cosine', bench.STEPS)
     print('library', _lib.LIB_PATH, flush=True)
     if what == 'once':
         print('sample', json.dumps(dict(setting=os.environ.get('R05_LABEL', 'loaded library'), **measure(model, corr, bt, y, diff, dev))), flush=True)
+        return
+    if what == 'rb_tokens':                            # tokens per workgroup of the eight-wave row block: the launcher's choice (8 while the launch fits one round) vs 16 forced
+        for rep in range(reps):
+            for label, tok in (('rb_tokens auto (8 at this shape)', 0), ('rb_tokens 16 (forced)', 16), ('rb_tokens 8 (forced)', 8)):
+                model.w.rb_tokens = tok
+                model.__dict__.pop('_graph_cache', None)
+                print('sample', json.dumps(dict(setting=label, clips=bench.B_PER_GPU, **measure(model, corr, bt, y, diff, dev))), flush=True)
+        model.w.rb_tokens = 0
         return
     settings = {'tail_order': (('xcd_affine_tail (shipped)', 0), ('plain_id_tail (round 4)', 7)),
                 'rowblock_waves': (('rowblock8_kernel (eight waves, shipped)', 0), ('rowblock_kernel (four waves, round 4)', 8))}[what]

@@ -20,7 +20,9 @@ void idf_prof_mark_slow(int, hipStream_t) {}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char **argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 100, h2 = argc > 3 ? atoi(argv[3]) : 0;     // h2 = 1: the split-f16 row block
+    const int B = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 100, h2 = argc > 3 ? atoi(argv[3]) : 0;     // h2 = 1: the split-f16 row block (round 5: the eight-wave rowblock8_kernel)
+    const int tokens = argc > 5 ? atoi(argv[5]) : 0;                                                                       // tokens per workgroup of the eight-wave kernel: 8 / 16 (0: the launcher's choice)
+    const int waves4 = argc > 4 ? atoi(argv[4]) : 0;                                                                       // 1 (with h2 = 1): round 4's four-wave split-f16 kernel instead
     // a weights struct whose every offset points into one big random arena (layout irrelevant for timing)
     const size_t arena_floats = (size_t)40 << 20;
     std::vector<float> h(arena_floats);
@@ -47,6 +49,9 @@ int main(int argc, char **argv) {
         for (int k = 0; k < 3; ++k) { ly.ln_w[k] = take(256); ly.ln_b[k] = take(256); }
     }
     if (h2) w.tune[IDF_TUNE_FFN_MATH] = 1;
+    if (h2 == 1 && waves4) w.tune[IDF_TUNE_MISC] = 8;
+    w.rb_tokens = tokens;
+    const int tv = (h2 == 1 && !waves4) ? (tokens ? tokens : (B * ((T + 7) / 8) <= 256 ? 8 : 16)) : 16;
     if (h2 == 2) w.tune[IDF_TUNE_MISC] = 5;       // the split-f16 attention kernel (csrc/attn_h2.h)        // (no split-f16 FFN / QKV streams are set: those stay exact)
     if (off > arena_floats) { printf("arena too small\n"); return 1; }
     float *memctx, *x, *x0;
@@ -61,7 +66,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 5; ++i)
         if (interdiff_mdm_forward(&w, memctx, x, ts, B, T, x0, ws, wsb, nullptr) != 0) { printf("forward failed\n"); return 1; }
     CK(hipDeviceSynchronize());
-    const int nwg = ((T + 15) / 16) * B;
+    const int nwg = ((T + tv - 1) / tv) * B;
     std::vector<long long> st((size_t)nwg * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_rb_stamps), st.size() * 8));
     const char *names[9] = {"", "rows + slab sum + LN_prev (+ Qc requested)", "logits MFMA (waits Qc)", "tap softmax + coefficients", "stencil + LN1",
@@ -69,7 +74,7 @@ int main(int argc, char **argv) {
     double acc[9] = {0}, tot = 0;
     for (int wgi = 0; wgi < nwg; ++wgi)
         for (int i = 1; i < 9; ++i) acc[i] += (double)(st[(size_t)wgi * 16 + i] - st[(size_t)wgi * 16 + i - 1]);
-    printf("QaN row block%s (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", h2 ? ", split-f16 contractions" : "", B, T, nwg);
+    printf("QaN row block%s (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", h2 ? (waves4 || h2 != 1 ? ", split-f16 contractions, four waves" : (tv == 8 ? ", split-f16 contractions, EIGHT waves, 8 tokens per workgroup (rowblock8_kernel)" : ", split-f16 contractions, EIGHT waves, 16 tokens per workgroup (rowblock8_kernel)")) : "", B, T, nwg);
     for (int i = 1; i < 9; ++i) { printf("  %-46s %8.0f\n", names[i], acc[i] / nwg); tot += acc[i] / nwg; }
     printf("  total %.0f\n", tot);
     double a9 = 0, a10 = 0, spread = 0;

@@ -179,8 +179,8 @@ def main():
         txt = open(path).read()
         new = txt
         for name, body in blocks.items():
-            pat = re.compile(r'(<!-- BEGIN GENERATED %s -->\n)(.*?)(\n<!-- END GENERATED %s -->)' % (name, name), re.S)
-            new = pat.sub(lambda m, body=body: m.group(1) + body + m.group(3), new)
+            pat = re.compile(r'(<!-- BEGIN GENERATED %s -->\n)(.*?)(<!-- END GENERATED %s -->)' % (name, name), re.S)
+            new = pat.sub(lambda m, body=body: m.group(1) + body + '\n' + m.group(3), new)
         targets.append((path, new, False))
     for path, new, whole in targets:
         old = open(path).read() if os.path.exists(path) else None

@@ -3,6 +3,7 @@ logic (no GPU compute calls)."""
 import os
 import re
 import subprocess
+import sys
 import numpy as np
 import pytest
 import torch
@@ -576,3 +577,13 @@ def test_io_smplh_npz_and_dataset_batch_adaptor(tmp_path):
     assert torch.equal(raw['obj_points'], batch['obj_points'][:, :, :3].float())
     assert all(v.dtype == torch.float32 and v.is_contiguous() for v in raw.values())
     assert raw['body_pose'].shape == (T, B, 66) and raw['beta'].shape == (T, B, 10) and raw['obj_points'].shape == (B, P, 3)
+
+
+def test_documents_quote_the_measurement_files():
+    """DESIGN.md / BASELINE.md / README.md carry their measured tables between GENERATED markers, rendered by tools/render_tables.py from profiles/r05_bench.json,
+    parity_r05.json and r05_kernel_stats_bench.txt: the committed documents must be exactly what the committed measurement files render to (no hand-typed numbers)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'render_tables.py'), '--check'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for doc in ('DESIGN.md', 'BASELINE.md', 'README.md'):
+        txt = open(os.path.join(ROOT, doc)).read()
+        assert txt.count('<!-- BEGIN GENERATED') == txt.count('<!-- END GENERATED') >= 2, doc

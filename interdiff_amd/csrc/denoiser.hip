@@ -596,21 +596,28 @@ __global__ __launch_bounds__(256) void rowblock_kernel(const float *__restrict__
 // Reference work being replaced: model/sublayers.py:311-352 (QaN block + cross-attention + the two LayerNorms around them).
 // ------------------------------------------------------------------------------------
 // Token rows of the eight-wave row block: LPR lanes per row (32 with 16 tokens per workgroup, 64 with 8), lane lr owns the 4-float chunks lr, LPR + lr, ...
-// The two forms compute the SAME bits: every per-element operation is the same, and a row's two LayerNorm sums are taken over one fixed tree whatever LPR is --
-// leaves = the 64 chunks' partial sums, then chunk k + chunk k + 32, then the 16-lane rotation tree inside {0..15} and {16..31}, then the two halves -- so the number of
-// tokens a workgroup takes is a pure performance choice (like the row tile of ffn_h2.h): shards / chains of a batch that pick differently still agree bit for bit.
+// The two forms compute the SAME bits: every per-element operation is the same, and a row's two LayerNorm sums are taken over ONE fixed tree whatever LPR is --
+// leaves = the 64 chunks' partial sums; T_r = the 16-lane rotation tree (row16_sum) over chunks 16 r .. 16 r + 15, r = 0..3; sum = (T0 + T1) + (T2 + T3) -- so the number
+// of tokens a workgroup takes is a pure performance choice (like the row tile of ffn_h2.h): shards / chains of a batch that pick differently still agree bit for bit.
+// With 64 lanes per row that tree is common.h's wave_sum (DPP + four v_readlane: no LDS-crossbar instruction on the row passes' critical path -- a first version
+// exchanged halves with ds_bpermute / ds_swizzle and spent ~250 cycles per reduction, six reductions per workgroup in a row); with 32 lanes a lane's two chunks belong
+// to T_r and T_(r+2), so both are reduced over the 16-lane row and the halves exchanged with one ds_swizzle each.
 template <int LPR>
 struct RowL {
     static constexpr int CPL = 64 / LPR;          // chunks per lane: 2 or 1
     float4 c[CPL];
 };
 #define IDF_SWZ_XOR16(v) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F))      // lane i <- lane i ^ 16 (bit-mask mode: and 0x1f, or 0, xor 0x10)
-// sum over a row's 64 chunk partials; `v` = this lane's partial(s) already added in chunk order (LPR = 32: chunk lr + chunk 32 + lr)
+// p0 / p1: this lane's partial sums of its chunk(s) (p1 only with two chunks per lane)
 template <int LPR>
-__device__ __forceinline__ float rowl_sum(float v) {
-    if constexpr (LPR == 64) v += __shfl_xor(v, 32);      // chunk k + chunk k ^ 32: what the 32-lane form adds inside a lane (commutative: both lanes hold the same bits)
-    v = row16_sum(v);
-    return v + IDF_SWZ_XOR16(v);
+__device__ __forceinline__ float rowl_tree(float p0, float p1) {
+    if constexpr (LPR == 64) {
+        return wave_sum(p0);                      // row16_sum, then (T0 + T1) + (T2 + T3) through scalar registers
+    } else {
+        const float t0 = row16_sum(p0), t1 = row16_sum(p1);      // lanes 0..15: T0, T2; lanes 16..31: T1, T3
+        const float s01 = t0 + IDF_SWZ_XOR16(t0), s23 = t1 + IDF_SWZ_XOR16(t1);
+        return s01 + s23;
+    }
 }
 template <int LPR, int NP>
 struct RowLRaw {
@@ -638,18 +645,17 @@ __device__ __forceinline__ void ln_rowl_lds(RowL<LPR> &r, const float *w, const 
     // instantiation, and the 8- and the 16-token form must round alike (every product and every sum rounded on its own, like the sampler update of gemm.h)
 #pragma clang fp contract(off)
     constexpr int CPL = 64 / LPR;
-    float sum = (r.c[0].x + r.c[0].y) + (r.c[0].z + r.c[0].w);
+    float p[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 1; i < CPL; ++i) sum += (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
-    const float mean = rowl_sum<LPR>(sum) * (1.0f / 256.0f);
-    float qv = 0.f;
+    for (int i = 0; i < CPL; ++i) p[i] = (r.c[i].x + r.c[i].y) + (r.c[i].z + r.c[i].w);
+    const float mean = rowl_tree<LPR>(p[0], p[1]) * (1.0f / 256.0f);
+    float q[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const float a0 = r.c[i].x - mean, a1 = r.c[i].y - mean, a2 = r.c[i].z - mean, a3 = r.c[i].w - mean;
-        const float qi = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        qv = i == 0 ? qi : qv + qi;
+        q[i] = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
-    const float rstd = __builtin_amdgcn_rsqf(rowl_sum<LPR>(qv) * (1.0f / 256.0f) + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(rowl_tree<LPR>(q[0], q[1]) * (1.0f / 256.0f) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const float4 g = *reinterpret_cast<const float4 *>(w + (i * LPR + lr) * 4), be = *reinterpret_cast<const float4 *>(b + (i * LPR + lr) * 4);
@@ -657,6 +663,42 @@ __device__ __forceinline__ void ln_rowl_lds(RowL<LPR> &r, const float *w, const 
         r.c[i].y = (r.c[i].y - mean) * rstd * g.y + be.y;
         r.c[i].z = (r.c[i].z - mean) * rstd * g.z + be.z;
         r.c[i].w = (r.c[i].w - mean) * rstd * g.w + be.w;
+    }
+}
+// The same LayerNorm on TWO independent rows at once (a token row and a halo row of the same lanes): same operations per row in the same order -- same bits as two
+// calls --, written side by side so that the two rows' reduction chains overlap instead of following each other behind a branch (the waves that own a halo row were
+// the last to reach the barrier: tools/rowblock_probe.hip).
+template <int LPR>
+__device__ __forceinline__ void ln2_rowl_lds(RowL<LPR> &ra, RowL<LPR> &rb, const float *w, const float *b, int lr) {
+#pragma clang fp contract(off)
+    constexpr int CPL = 64 / LPR;
+    float pa[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        pa[i] = (ra.c[i].x + ra.c[i].y) + (ra.c[i].z + ra.c[i].w);
+        pb[i] = (rb.c[i].x + rb.c[i].y) + (rb.c[i].z + rb.c[i].w);
+    }
+    const float ma = rowl_tree<LPR>(pa[0], pa[1]) * (1.0f / 256.0f), mb = rowl_tree<LPR>(pb[0], pb[1]) * (1.0f / 256.0f);
+    float qa[2] = {0.f, 0.f}, qb[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const float a0 = ra.c[i].x - ma, a1 = ra.c[i].y - ma, a2 = ra.c[i].z - ma, a3 = ra.c[i].w - ma;
+        const float b0 = rb.c[i].x - mb, b1 = rb.c[i].y - mb, b2 = rb.c[i].z - mb, b3 = rb.c[i].w - mb;
+        qa[i] = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        qb[i] = (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+    }
+    const float rsa = __builtin_amdgcn_rsqf(rowl_tree<LPR>(qa[0], qa[1]) * (1.0f / 256.0f) + 1e-5f), rsb = __builtin_amdgcn_rsqf(rowl_tree<LPR>(qb[0], qb[1]) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const float4 g = *reinterpret_cast<const float4 *>(w + (i * LPR + lr) * 4), be = *reinterpret_cast<const float4 *>(b + (i * LPR + lr) * 4);
+        ra.c[i].x = (ra.c[i].x - ma) * rsa * g.x + be.x;
+        ra.c[i].y = (ra.c[i].y - ma) * rsa * g.y + be.y;
+        ra.c[i].z = (ra.c[i].z - ma) * rsa * g.z + be.z;
+        ra.c[i].w = (ra.c[i].w - ma) * rsa * g.w + be.w;
+        rb.c[i].x = (rb.c[i].x - mb) * rsb * g.x + be.x;
+        rb.c[i].y = (rb.c[i].y - mb) * rsb * g.y + be.y;
+        rb.c[i].z = (rb.c[i].z - mb) * rsb * g.z + be.z;
+        rb.c[i].w = (rb.c[i].w - mb) * rsb * g.w + be.w;
     }
 }
 template <int LPR>
@@ -781,9 +823,11 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IDF_RB_STAMP(10);                                    // this wave's share has landed
     __syncthreads();
+    IDF_RB_STAMP(11);                                    // every wave's share has landed
     raw_a.reduce(ra);
     if constexpr (QAN) {
         if (halo) raw_b.reduce(rb);
+        else rowl_zero<LPR>(rb);                  // (waves without a halo row run the two-row LayerNorm below on zeros: a few VALU slots, no second latency chain)
     }
     const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
                 *P_bout = prm + 1536, *P_sab = prm + 1792;
@@ -804,8 +848,8 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
 
     if constexpr (QAN) {
         if (lnp_w) {
-            ln_rowl_lds<LPR>(ra, P_lnp_w, P_lnp_b, lr);
-            if (halo) ln_rowl_lds<LPR>(rb, P_lnp_w, P_lnp_b, lr);
+            if (halo) ln2_rowl_lds<LPR>(ra, rb, P_lnp_w, P_lnp_b, lr);      // its own row and its halo row side by side (same bits as two single-row calls)
+            else ln_rowl_lds<LPR>(ra, P_lnp_w, P_lnp_b, lr);
         }
         if (!va) rowl_zero<LPR>(ra);
         if (!vb) rowl_zero<LPR>(rb);
@@ -816,6 +860,7 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
             rowl_store_planes<LPR>(rb, xh + (TV + rg) * HS, xl + (TV + rg) * HS, lr);
         }
         fetch_g();
+        IDF_RB_STAMP(12);                                // this wave is done with its LN_prev rows (before the barrier)
         __syncthreads();
         IDF_RB_STAMP(1);                                 // rows loaded (+ slab sum), LN_prev, planes
         {   // logits: three 16x16 tiles (taps), this wave contracts K = [32 wave, 32 wave + 32)

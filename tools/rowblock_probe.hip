@@ -88,6 +88,14 @@ int main(int argc, char **argv) {
     (void)spread;
     printf("  inside the first phase: entry -> all requests issued %.0f, -> first batch landed (wave 0) %.0f; workgroup entry times spread over %lld cycles\n",
            a9 / nwg, a10 / nwg, last - first);
+    if (h2 == 1 && !waves4) {
+        double a11 = 0, a12 = 0;
+        for (int wgi = 0; wgi < nwg; ++wgi) {
+            a11 += (double)(st[(size_t)wgi * 16 + 11] - st[(size_t)wgi * 16]);
+            a12 += (double)(st[(size_t)wgi * 16 + 12] - st[(size_t)wgi * 16]);
+        }
+        printf("    -> past the barrier behind the landing (every wave's rows are there) %.0f, -> wave 0 done with its rows (two LayerNorms: its own + a halo row), before the second barrier %.0f\n", a11 / nwg, a12 / nwg);
+    }
     {
         const int nat = ((T + 16 * ATTN_RT - 1) / (16 * ATTN_RT)) * 4 * B;
         std::vector<long long> sa((size_t)nat * 8);

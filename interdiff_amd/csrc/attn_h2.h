@@ -50,12 +50,12 @@ __device__ __forceinline__ float pow2_scale(float amax, float &up) {
     return __builtin_bit_cast(float, (uint32_t)((127 - e) << 23));
 }
 
-__global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restrict__ qkv, int T, const float *__restrict__ wo_h2,
+__global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restrict__ qkv, int T, int nwg, const float *__restrict__ wo_h2,
                                                            float *__restrict__ slabs, size_t pstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     asm volatile("" ::: "v255");                         // exclusive CU: 2 waves per SIMD x 256 registers (+ the launcher's 160 KiB of LDS)
     __shared__ float red[3][NWV];
-    idf_args_now(qkv, T, wo_h2, slabs, pstride, gridDim.x);
+    // (all ten argument dwords, the grid size among them, arrive preloaded in SGPRs: build.py)
     const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31, VTS = TPP + 8, SS = TP + 4;
     _Float16 *kh = reinterpret_cast<_Float16 *>(smraw), *kl = kh + TP * KHS;                 // K planes [TP][KHS]
     _Float16 *vth = kh + k_region_halves(TP, TPP), *vtl = vth + HD * VTS;                    // V^T planes [64][VTS]
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     _Float16 *qh = reinterpret_cast<_Float16 *>(Ss + QT * SS), *ql = qh + QT * KHS;          // Q planes [32][KHS], later the context planes
     _Float16 *ph = kh, *pl = kh + QT * VTS;                                                  // probability planes [32][VTS] over K (the region is sized for the larger of the two)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int nwg = gridDim.x, id = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int id = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);      // XCD-affine: the query tiles of a (clip, head) share its K / V in one L2
     const int nqt = (T + QT - 1) / QT, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT;
     const size_t rowbase = (size_t)b * T;
@@ -277,7 +277,7 @@ inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, co
     const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
     if (dyn < 0) return IDF_NOT_EXCLUSIVE;
     if (T > MAX_T || (int)lds_bytes(T) > dyn) return IDF_E_INVAL;
-    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, wo_h2, slabs, pstride);
+    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, (int)(idf_cdiv(T, QT) * H * B), wo_h2, slabs, pstride);
     return IDF_OK;
 }
 

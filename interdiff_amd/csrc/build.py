@@ -14,7 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libinterdiff_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-Wno-inline-asm']        # the asm LDS-DMA names m0 as a clobber on purpose (csrc/common.h idf_dma16_*)
+         '-Wno-inline-asm',        # the asm LDS-DMA names m0 as a clobber on purpose (csrc/common.h idf_dma16_*)
+         # gfx950 kernel-argument preloading: the leading arguments of every kernel (as many as fit the 14 free user SGPRs) are in registers when a wave
+         # starts instead of behind an s_load round trip to the argument segment -- 22 kernel starts per denoising step; same-box A/B of the whole library
+         # -1.0 % per step (profiles/r05_lib_ab_preload.txt).  Kernels whose first loads matter order their arguments for it (denoiser.hip rowblock8_kernel).
+         '-mllvm', '-amdgpu-kernarg-preload-count=16']
 FLAGS += os.environ.get('IDF_EXTRA_HIPCC_FLAGS', '').split()      # A/B builds (e.g. -DIDF_WT_MODE=2); empty for the product
 
 

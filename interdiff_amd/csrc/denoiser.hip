@@ -737,15 +737,17 @@ __device__ __forceinline__ void rowl_store_planes(const RowL<LPR> &r, _Float16 *
 // 208 workgroups at B = 16, T = 100 -- one round on 256 CUs instead of 112 -- each with half the row work; the MFMA tiles stay 16 rows tall (rows >= TV + 2 of the A
 // operands are whatever LDS holds: they only reach output rows nobody stores).  The launcher takes 8 whenever the launch still fits the chip in one round.
 template <bool QAN, int NP, int MS = MEM, int TV = 16>
-__global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict__ u_in, const float *__restrict__ lnp_w,
-                                                        const float *__restrict__ lnp_b, const float *__restrict__ Qc,
+__global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict__ u_in, int T, int ntile, int nclip, int mem_len, size_t u_pstride,
+                                                        const float *__restrict__ sa_resid, const float *__restrict__ Qc,
+                                                        const float *__restrict__ lnp_w, const float *__restrict__ lnp_b,
                                                         const float *__restrict__ wk, const float *__restrict__ ln1_w,
                                                         const float *__restrict__ ln1_b, const float *__restrict__ G,
                                                         const float *__restrict__ g0, const float *__restrict__ VWT,
                                                         const float *__restrict__ bout, const float *__restrict__ ln2_w,
-                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out, int T,
-                                                        size_t u_pstride, const float *__restrict__ sa_resid, const float *__restrict__ sa_bias,
-                                                        const float *__restrict__ h2_scale, int mem_len) {
+                                                        const float *__restrict__ ln2_b, float *__restrict__ x2_out,
+                                                        const float *__restrict__ sa_bias, const float *__restrict__ h2_scale) {
+    // Argument order: what the token-row addresses need comes first -- the library is built with kernel-argument preloading (build.py), the leading 14 dwords are in
+    // SGPRs when the wave starts, and the rows are requested before anything else is even read from the argument segment.  1-D grid of ntile * nclip workgroups.
 #pragma clang fp contract(off)                    // (see ln_rowl_lds: the two token counts must compute the same bits)
     using idf_ffn_h2::h8;
     using ML = MemLay<MS>;
@@ -755,7 +757,6 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     constexpr int PTR = 17, PTS = 16 * PTR;       // K-split partial tiles: row stride 17 floats (the head softmax reads a tile column-wise: 16 would be a 4-way bank conflict)
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     constexpr int HS = D + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16), PHS = 64 + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16);     // plane strides: conflict-free fragment reads (rowblock_kernel)
-    const int mlen = ML::GEN ? mem_len : MEM;
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * (TR + 2) * HS];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores (TV + 2 rows are written)
     __shared__ __attribute__((aligned(16))) _Float16 ppl[2 * TR * PHS];            // [hi | lo'][TR][PHS]: probabilities, unwritten columns stay zero
     _Float16 *const xh = xpl, *const xl = xpl + (TR + 2) * HS, *const ph = ppl, *const pl = ppl + TR * PHS;
@@ -765,38 +766,21 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     float *x1s = sm + XS;                         // [TR][RS]    x1, then u2 in place
     float *part = x1s + TR * RS;                  // [8 waves][3 taps | NCT score tiles][16][17] K-split partial tiles
 
-    idf_args_now(u_in, lnp_w, lnp_b, Qc, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, T, u_pstride, sa_resid, sa_bias, h2_scale, mem_len, gridDim.x, gridDim.y);
-    asm volatile("" ::: "v255");                  // EXCLUSIVE CU (ffn_h2.h): 2 waves per SIMD x 256 registers = the register file; the launcher tops the LDS up to 160 KiB
-    const int lid = xcd_logical_id(), b = lid / (int)gridDim.x, t0 = (lid - b * (int)gridDim.x) * TV;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int rg = tid / LPR, lr = tid % LPR;     // row passes: token row rg of the TV, lane lr of its LPR; threads of rows 0 and 1 also take the two halo rows (QAN)
-    const size_t rowbase = (size_t)b * T;
     IDF_RB_STAMP(0);
-    const float *Gb = G + (size_t)b * ML::G_H2, *g0b = g0 + b * ML::G0N, *VWTb = VWT + (size_t)b * VW_H2;
-    for (int i = tid; i < 2 * TR * PHS / 8; i += 512) reinterpret_cast<float4 *>(ppl)[i] = zero4();
-
-    // ---- first batch of requests (pinned order, the wait below counts): shared vectors by DMA, scalars, token rows, then -- youngest -- the learned-query fragments
-    {
-        const float *srcs[8] = {lnp_w ? lnp_w : ln1_w, lnp_w ? lnp_b : ln1_b, ln1_w, ln1_b, ln2_w, ln2_b, bout, sa_bias ? sa_bias : ln1_b};
-        const uint32_t prm_lds = idf_lds_addr(prm);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i == wave) idf_dma16_s(idf_uniform_ptr(srcs[i]), (uint32_t)(lane << 4), prm_lds + (uint32_t)(i * 1024));
-    }
-    RowL<LPR> ra, rb;
-    float4 q[2][3], gv[2][NCT], vw2[2][2][2];     // plane fragments: q[plane][tap], gv[plane][column tile] of this wave's K step; vw2[K step][tile][plane] of its two output tiles
-    float wk_n = 0.f, g0v[NSLOT];
-    const float gsc = h2_scale[2 * b], vsc = h2_scale[2 * b + 1];
-    const int hh = wave & 3;                      // head softmax: waves 0..3, wave = head
+    asm volatile("" ::: "v255");                  // EXCLUSIVE CU (ffn_h2.h): 2 waves per SIMD x 256 registers = the register file; the launcher tops the LDS up to 160 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = tid / LPR, lr = tid % LPR;     // row passes: token row rg of the TV, lane lr of its LPR; threads of rows 0 and 1 also take the two halo rows (QAN)
+    // ---- first batch of requests (pinned order, the wait below counts).  Oldest: the token rows (five slabs each; behind them everything else of the prologue runs
+    // while they are in flight); then the shared vectors by DMA, the scalars, and -- youngest -- the learned-query fragments
+    const int nwg = ntile * nclip, xq = nwg >> 3, xr = nwg & 7, xcd = (int)blockIdx.x & 7;      // XCD-affine logical id (xcd_logical_id) from the preloaded counts
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+    const int b = lid / ntile, t0 = (lid - b * ntile) * TV;
+    const size_t rowbase = (size_t)b * T;
     const int ta = QAN ? t0 - 1 + rg : t0 + rg, tb = t0 + TV - 1 + rg;
     const bool halo = QAN && rg < 2;
     const bool va = ta >= 0 && ta < T, vb = halo && tb < T;
     RowLRaw<LPR, NP> raw_a, raw_b;
     RowLRaw<LPR, 1> raw_r;
-    if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) g0v[i] = g0b[ML::col(hh, min((lane & 3) + 4 * i, mlen - 1))];
     if constexpr (QAN) {
         if (halo) raw_b.request(u_in + (rowbase + min(tb, T - 1)) * D, lr, u_pstride);     // halo rows t0 + TV - 1, t0 + TV: the threads of rows 0 and 1 (wave-uniform: LPR >= 32)
     }
@@ -804,6 +788,25 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     if constexpr (!QAN) {
         if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, lr, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    idf_args_now(lnp_b, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, sa_bias, h2_scale);
+    const int li = lane & 15, kq = lane >> 4;
+    const int mlen = ML::GEN ? mem_len : MEM;
+    const float *Gb = G + (size_t)b * ML::G_H2, *g0b = g0 + b * ML::G0N, *VWTb = VWT + (size_t)b * VW_H2;
+    {   // wave w brings shared vector w (a scalar choice: one DMA instruction per wave)
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        const float *src = ws == 0 ? (lnp_w ? lnp_w : ln1_w) : ws == 1 ? (lnp_w ? lnp_b : ln1_b) : ws == 2 ? ln1_w : ws == 3 ? ln1_b : ws == 4 ? ln2_w : ws == 5 ? ln2_b
+                         : ws == 6 ? bout : (sa_bias ? sa_bias : ln1_b);
+        idf_dma16_s(idf_uniform_ptr(src), (uint32_t)(lane << 4), idf_lds_addr(prm) + (uint32_t)(ws * 1024));
+    }
+    float4 q[2][3], gv[2][NCT], vw2[2][2][2];     // plane fragments: q[plane][tap], gv[plane][column tile] of this wave's K step; vw2[K step][tile][plane] of its two output tiles
+    float wk_n = 0.f, g0v[NSLOT];
+    const float gsc = h2_scale[2 * b], vsc = h2_scale[2 * b + 1];
+    const int hh = wave & 3;                      // head softmax: waves 0..3, wave = head
+    RowL<LPR> ra, rb;
+    if constexpr (QAN) wk_n = wk[min(li, NQ - 1)];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) g0v[i] = g0b[ML::col(hh, min((lane & 3) + 4 * i, mlen - 1))];
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (QAN) {
 #pragma unroll
@@ -818,6 +821,7 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    for (int i = tid; i < 2 * TR * PHS / 8; i += 512) reinterpret_cast<float4 *>(ppl)[i] = zero4();
     IDF_RB_STAMP(9);                                     // every request of the first batch issued
     if constexpr (QAN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // everything older than the six learned-query fragment loads has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -873,12 +877,14 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
                 al[j] = *reinterpret_cast<const h8 *>(xl + (li + j) * HS + koff);
             }
             mma_h2<3>(acc, acc_c, ah, al, q[0], q[1]);
+            IDF_RB_STAMP(13);                                // (probe) logits: operands read, MFMAs issued
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * PTS + (kq * 4 + r) * PTR + li] = acc[j][r] + acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
         }
         fetch_vw();
+        IDF_RB_STAMP(14);                                // (probe) logits: partial tiles stored, VW requested
         __syncthreads();
         IDF_RB_STAMP(2);                                 // logits MFMA
         float c0, c1, c2;
@@ -1000,6 +1006,7 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
             const float4 bh[2] = {vw2[s2][0][0], vw2[s2][1][0]}, bl[2] = {vw2[s2][0][1], vw2[s2][1][1]};
             mma_h2<2>(acc, acc_c, ah, al, bh, bl);
         }
+        IDF_RB_STAMP(15);                                    // (probe) P.VW: MFMAs issued
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = (wave * 2 + c) * 16 + li;
@@ -1864,13 +1871,13 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
             const int dyn8 = rb_h2 && rb8 ? (tv8 == 8 ? rb8_qan_dyn<MS, 8>() : rb8_qan_dyn<MS, 16>()) : -1;
             const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_qan_dyn<MS>() : -1;
             if (dyn8 >= 0 && tv8 == 8) {
-                rowblock8_kernel<true, NSL, MS, 8><<<rb8_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, pstride, nullptr, nullptr, scl, mlen);
+                rowblock8_kernel<true, NSL, MS, 8><<<dim3(rb8_grid.x * B), dim3(512), (size_t)dyn8, s>>>(u_in, T, (int)rb8_grid.x, B, mlen, pstride, nullptr, ar + ly.qc_h2,
+                                   lnp_w, lnp_b, ar + ly.wk, ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, nullptr, scl);
             } else if (dyn8 >= 0) {
-                rowblock8_kernel<true, NSL, MS, 16><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, pstride, nullptr, nullptr, scl, mlen);
+                rowblock8_kernel<true, NSL, MS, 16><<<dim3(rb_grid.x * B), dim3(512), (size_t)dyn8, s>>>(u_in, T, (int)rb_grid.x, B, mlen, pstride, nullptr, ar + ly.qc_h2,
+                                   lnp_w, lnp_b, ar + ly.wk, ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, nullptr, scl);
             } else if (dyn >= 0) {
                 rowblock_kernel<true, true, NSL, true, MS><<<rb_grid, dim3(256), (size_t)dyn, s>>>(u_in, lnp_w, lnp_b, ar + ly.qc_h2, ar + ly.wk,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
@@ -1909,13 +1916,13 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                 const int dyn8 = rb_h2 && rb8 ? (tv8 == 8 ? rb8_std_dyn<MS, 8>() : rb8_std_dyn<MS, 16>()) : -1;
                 const int dyn = rb_h2 && dyn8 < 0 ? rb_h2_std_dyn<MS>() : -1;
                 if (dyn8 >= 0 && tv8 == 8) {
-                    rowblock8_kernel<false, H, MS, 8><<<rb8_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
+                    rowblock8_kernel<false, H, MS, 8><<<dim3(rb8_grid.x * B), dim3(512), (size_t)dyn8, s>>>(k.parts, T, (int)rb8_grid.x, B, mlen, pstride, k.xn, nullptr,
+                                   nullptr, nullptr, nullptr, ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, ar + ly.sa_out_b, scl);
                 } else if (dyn8 >= 0) {
-                    rowblock8_kernel<false, H, MS, 16><<<rb_grid, dim3(512), (size_t)dyn8, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
-                                   ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
-                                   ar + ly.ln_b[1], k.x2, T, pstride, k.xn, ar + ly.sa_out_b, scl, mlen);
+                    rowblock8_kernel<false, H, MS, 16><<<dim3(rb_grid.x * B), dim3(512), (size_t)dyn8, s>>>(k.parts, T, (int)rb_grid.x, B, mlen, pstride, k.xn, nullptr,
+                                   nullptr, nullptr, nullptr, ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],
+                                   ar + ly.ln_b[1], k.x2, ar + ly.sa_out_b, scl);
                 } else if (dyn >= 0) {
                     rowblock_kernel<false, true, H, true, MS><<<rb_grid, dim3(256), (size_t)dyn, s>>>(k.parts, nullptr, nullptr, nullptr, nullptr,
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gh, g0l, VWh, ar + ly.ca_out_b, ar + ly.ln_w[1],

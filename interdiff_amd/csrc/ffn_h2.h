@@ -161,7 +161,7 @@ __device__ __forceinline__ void idf_sload16(const float *p, f4s &a, f4s &b, f4s 
 // MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue, 3 = phase stamps of thread 0 behind the slabs, 4 = no slab stores
 // (tools/ffn_h2_probe.hip only; `if constexpr` keeps every trace of them out of MODE 0).
 template <int TT, int S, int MODE = 0>
-__global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, const float *__restrict__ pack,
+__global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, int nwg, const float *__restrict__ pack,
                                                      const float *__restrict__ b1p, const float *__restrict__ b2,
                                                      float *__restrict__ parts, int order) {
     constexpr int BM = 16 * TT;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     asm volatile("" ::: "v255");                       // the whole register file: see EXCLUSIVE CU below
     float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
     float *ring = smem + BM * 256;                  // (the slice's linear1 bias comes through the scalar cache: with four ring slots the planes and the ring are the whole 160 KiB)
-    idf_args_now(x2, M, pack, b1p, b2, parts, order, gridDim.x);
+    // (all 13 argument dwords -- the grid size among them, instead of gridDim.x from the hidden block -- arrive preloaded in SGPRs: build.py; no argument-segment read before the first DMA)
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     // affine ids (an XCD streams one or two of the five 432-KiB weight streams: 13 instead of 40 slice loads per launch), order 2 = plain ids
     // (rounds 1-3: the five slices of a tile on five XCDs).  One process (profiles/r04_ffn_split_f16_ab.txt): bursts 10.6 / 10.5 / 12.1 us,
     // denoiser forward 212 / 234-238 / 226-230 us, whole samples with correction 0.2363 / 0.2446 / 0.2437 ms per step for orders 0 / 1 / 2.
-    const int nwg = gridDim.x, id = blockIdx.x, nmt = nwg / NSL;
+    const int id = blockIdx.x, nmt = nwg / NSL;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
     // order 0: ffn.h's M-tile-major ids; 1: slice-major over XCD-affine ids; 2: M-tile-major over XCD-affine ids (an XCD holds ALL slices of its M tiles: x2 rows
@@ -471,7 +471,7 @@ inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack
     static idf_excl_cache excl;
     const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), TT == 1 ? "ffn_h2_kernel<16 rows>" : (TT == 2 ? "ffn_h2_kernel<32 rows>" : "ffn_h2_kernel<64 rows>"), NT, excl);
     if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;            // (the kernel has no static LDS: its dynamic request IS the CU's 160 KiB)
-    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, pack, b1p, b2, parts, order);
+    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, (int)(idf_cdiv(M, BM) * NSL), pack, b1p, b2, parts, order);
     return IDF_OK;
 }
 // rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits

@@ -19,7 +19,7 @@ float run(const float *x2, int M, const float *pack, const float *b1, const floa
     constexpr int BM = 16 * TT;
     const dim3 grid((unsigned)(idf_cdiv(M, BM) * NSL));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQUEST));
-    auto go = [&](int i) { hipLaunchKernelGGL((ffn_h2_kernel<TT, S, MODE>), grid, dim3(NT), LDS_REQUEST, 0, x2, M, pack + (size_t)(i % layers) * NSL * SLICE_FLOATS, b1, b2, parts, 0); };
+    auto go = [&](int i) { hipLaunchKernelGGL((ffn_h2_kernel<TT, S, MODE>), grid, dim3(NT), LDS_REQUEST, 0, x2, M, (int)grid.x, pack + (size_t)(i % layers) * NSL * SLICE_FLOATS, b1, b2, parts, 0); };
     for (int i = 0; i < 10; ++i) go(i);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

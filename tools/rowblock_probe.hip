@@ -5,7 +5,7 @@
 // phase over the workgroups of the LAST QaN launch of a forward at B x T.
 #include <hip/hip_runtime.h>
 __device__ long long g_rb_stamps[8192 * 16];
-#define IDF_RB_STAMP(i) do { if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
+#define IDF_RB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ long long g_at_stamps[8192 * 8];
 #define IDF_AT_STAMP(i) do { if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); } while (0)
 __device__ long long g_ah2_stamps[8192 * 8];
@@ -95,6 +95,13 @@ int main(int argc, char **argv) {
             a12 += (double)(st[(size_t)wgi * 16 + 12] - st[(size_t)wgi * 16]);
         }
         printf("    -> past the barrier behind the landing (every wave's rows are there) %.0f, -> wave 0 done with its rows (two LayerNorms: its own + a halo row), before the second barrier %.0f\n", a11 / nwg, a12 / nwg);
+        double a13 = 0, a14 = 0, a15 = 0;
+        for (int wgi = 0; wgi < nwg; ++wgi) {
+            a13 += (double)(st[(size_t)wgi * 16 + 13] - st[(size_t)wgi * 16 + 1]);
+            a14 += (double)(st[(size_t)wgi * 16 + 14] - st[(size_t)wgi * 16 + 1]);
+            a15 += (double)(st[(size_t)wgi * 16 + 15] - st[(size_t)wgi * 16 + 6]);
+        }
+        printf("  inside the logits phase (wave 0): -> operands read, MFMAs issued %.0f, -> partial tiles stored, VW requested %.0f (then the barrier); inside P.VW: -> MFMAs issued %.0f\n", a13 / nwg, a14 / nwg, a15 / nwg);
     }
     {
         const int nat = ((T + 16 * ATTN_RT - 1) / (16 * ATTN_RT)) * 4 * B;

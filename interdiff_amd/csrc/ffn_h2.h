@@ -505,20 +505,19 @@ constexpr int QSLICE_FLOATS = 8 * QSTEP / 4;             // 40960 floats per 160
 constexpr int QBM = 32;
 
 template <int NP>
-__global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, const float *__restrict__ lnw,
-                                                           const float *__restrict__ lnb, int M, const float *__restrict__ pack,
+__global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, int M, int nwg, const float *__restrict__ pack,
+                                                           const float *__restrict__ lnw, const float *__restrict__ lnb, int nsl_grid, int step_B,
                                                            const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
                                                            float *__restrict__ xn_out, int64_t *__restrict__ step_state,
-                                                           int64_t *__restrict__ step_ts, int step_B, int nsl_grid) {
+                                                           int64_t *__restrict__ step_ts) {
+    // (argument order: the first 14 dwords -- what the weight stream and the row requests need -- arrive preloaded in SGPRs: build.py)
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     asm volatile("" ::: "v255");                       // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
-    idf_args_now(A, a_pstride, lnw, lnb, M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl_grid, gridDim.x);
-    if (step_state && blockIdx.x == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
     float *Xs = smem, *ring = smem + QBM * 256, *Sc = ring + 3 * (QSTEP / 4);      // Sc [32]: 2^e of every row
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int mt, sl;
-    idf_ffn::xcd_affine_tile(gridDim.x, blockIdx.x, nsl_grid, mt, sl);
+    idf_ffn::xcd_affine_tile(nwg, blockIdx.x, nsl_grid, mt, sl);
     const int m0 = mt * QBM, n0 = sl * QHS;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * QSLICE_FLOATS);
     const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
@@ -543,6 +542,8 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
         float4 v[QBM / NW];
 #pragma unroll
         for (int i = 0; i < QBM / NW; ++i) v[i] = ld4_sum<NP>(A + (size_t)min(m0 + wave + NW * i, M - 1) * D + lane * 4, a_pstride);
+        idf_args_now(bias, C, ldc, N, xn_out, step_state, step_ts);      // the rest of the argument segment, behind the requests
+        if (step_state && blockIdx.x == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
 #pragma unroll
         for (int i = 0; i < QBM / NW; ++i) {
             const int row = wave + NW * i;
@@ -673,8 +674,8 @@ inline int launch_ln_linear_h2(hipStream_t s, const float *A, size_t a_pstride, 
     const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NT, excl);
     if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
     const int nsl = (int)idf_cdiv(N, QHS);
-    hipLaunchKernelGGL(ln_linear_h2_kernel<NP>, dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, lnw, lnb,
-                       M, pack, bias, C, ldc, N, xn_out, step_state, step_ts, step_B, nsl);
+    hipLaunchKernelGGL(ln_linear_h2_kernel<NP>, dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
+                       (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts);
     return IDF_OK;
 }
 }  // namespace idf_ffn_h2

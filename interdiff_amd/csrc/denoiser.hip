@@ -789,7 +789,11 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
         if (sa_resid) raw_r.request(sa_resid + (rowbase + min(max(ta, 0), T - 1)) * D, lr, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    IDF_RB_STAMP(9);                                     // token rows requested (from the preloaded arguments alone)
     idf_args_now(lnp_b, wk, ln1_w, ln1_b, G, g0, VWT, bout, ln2_w, ln2_b, x2_out, sa_bias, h2_scale);
+#ifdef IDF_RB_STAMP_ARGS
+    IDF_RB_STAMP(14);                                    // (probe variant) the rest of the argument segment has arrived
+#endif
     const int li = lane & 15, kq = lane >> 4;
     const int mlen = ML::GEN ? mem_len : MEM;
     const float *Gb = G + (size_t)b * ML::G_H2, *g0b = g0 + b * ML::G0N, *VWTb = VWT + (size_t)b * VW_H2;
@@ -822,12 +826,26 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < 2 * TR * PHS / 8; i += 512) reinterpret_cast<float4 *>(ppl)[i] = zero4();
-    IDF_RB_STAMP(9);                                     // every request of the first batch issued
+    IDF_RB_STAMP(15);                                    // the rest of the argument segment read, every request of the first batch issued
+    // (A CU's vector-memory path accepts ~64 B per clock for all its waves and a wave waits in its issue slot until its request is taken: the ~100 KB of this batch keep
+    // wave 0 here until ~4.4 k cycles.  Sending the learned-query fragments behind the barrier below instead moved that wait into the LayerNorm pass, same total:
+    // tools/rowblock_probe.hip, profiles/r05_rowblock_probe.txt.  The kernel's ~200 KB of operands per workgroup are ~3.2 k cycles of such issue time.)
     if constexpr (QAN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // everything older than the six learned-query fragment loads has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IDF_RB_STAMP(10);                                    // this wave's share has landed
     __syncthreads();
     IDF_RB_STAMP(11);                                    // every wave's share has landed
+    auto fetch_g = [&]() {                        // [K eighth = wave][column tile][plane][lane][8 halves]
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#ifdef IDF_RB_EXPERIMENT_SKIP_LO      // (timing experiment only, wrong results: how much of the kernel is the operand stream?  tools/rowblock_probe.hip)
+                if (p2 == 1) { gv[1][ct] = gv[0][ct]; continue; }
+#endif
+                gv[p2][ct] = ld4(Gb + ((((wave * NCT + ct) * 2 + p2) * 64) + lane) * 4);
+            }
+    };
     raw_a.reduce(ra);
     if constexpr (QAN) {
         if (halo) raw_b.reduce(rb);
@@ -835,19 +853,18 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     }
     const float *P_lnp_w = prm, *P_lnp_b = prm + 256, *P_ln1_w = prm + 512, *P_ln1_b = prm + 768, *P_ln2_w = prm + 1024, *P_ln2_b = prm + 1280,
                 *P_bout = prm + 1536, *P_sab = prm + 1792;
-    auto fetch_g = [&]() {                        // [K eighth = wave][column tile][plane][lane][8 halves]
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) gv[p2][ct] = ld4(Gb + ((((wave * NCT + ct) * 2 + p2) * 64) + lane) * 4);
-    };
     auto fetch_vw = [&]() {                       // [output column quarter = wave >> 1][K step][column tile 2 (wave & 1) + c][plane][lane][8 halves]
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int p2 = 0; p2 < 2; ++p2) vw2[s2][c][p2] = ld4(VWTb + ((((((wave >> 1) * 2 + s2) * 4 + 2 * (wave & 1) + c) * 2 + p2) * 64) + lane) * 4);
+                for (int p2 = 0; p2 < 2; ++p2) {
+#ifdef IDF_RB_EXPERIMENT_SKIP_LO
+                    if (p2 == 1) { vw2[s2][c][1] = vw2[s2][c][0]; continue; }
+#endif
+                    vw2[s2][c][p2] = ld4(VWTb + ((((((wave >> 1) * 2 + s2) * 4 + 2 * (wave & 1) + c) * 2 + p2) * 64) + lane) * 4);
+                }
     };
 
     if constexpr (QAN) {
@@ -884,7 +901,9 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
                 for (int r = 0; r < 4; ++r) part[(wave * 3 + j) * PTS + (kq * 4 + r) * PTR + li] = acc[j][r] + acc_c[j][r] * idf_ffn_h2::LO_UNSCALE;
         }
         fetch_vw();
+#ifndef IDF_RB_STAMP_ARGS
         IDF_RB_STAMP(14);                                // (probe) logits: partial tiles stored, VW requested
+#endif
         __syncthreads();
         IDF_RB_STAMP(2);                                 // logits MFMA
         float c0, c1, c2;
@@ -1006,7 +1025,6 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
             const float4 bh[2] = {vw2[s2][0][0], vw2[s2][1][0]}, bl[2] = {vw2[s2][0][1], vw2[s2][1][1]};
             mma_h2<2>(acc, acc_c, ah, al, bh, bl);
         }
-        IDF_RB_STAMP(15);                                    // (probe) P.VW: MFMAs issued
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = (wave * 2 + c) * 16 + li;

@@ -66,6 +66,21 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 5; ++i)
         if (interdiff_mdm_forward(&w, memctx, x, ts, B, T, x0, ws, wsb, nullptr) != 0) { printf("forward failed\n"); return 1; }
     CK(hipDeviceSynchronize());
+    const bool replay = argc > 6 && atoi(argv[6]) != 0;       // 7th argument 1: the stamps of a captured forward REPLAYED as a hipGraph (how the product runs it) instead of plain launches
+    if (replay) {
+        hipStream_t cs;
+        hipGraph_t gr;
+        hipGraphExec_t ge;
+        CK(hipStreamCreate(&cs));
+        CK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 2; ++i)
+            if (interdiff_mdm_forward(&w, memctx, x, ts, B, T, x0, ws, wsb, cs) != 0) { printf("forward failed\n"); return 1; }
+        CK(hipStreamEndCapture(cs, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, cs));
+        CK(hipStreamSynchronize(cs));
+        printf("(stamps of a hipGraph replay: two forwards per graph, five replays)\n");
+    }
     const int nwg = ((T + tv - 1) / tv) * B;
     std::vector<long long> st((size_t)nwg * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_rb_stamps), st.size() * 8));
@@ -77,31 +92,21 @@ int main(int argc, char **argv) {
     printf("QaN row block%s (last launch of the forward), B=%d T=%d, %d workgroups; mean cycles per phase:\n", h2 ? (waves4 || h2 != 1 ? ", split-f16 contractions, four waves" : (tv == 8 ? ", split-f16 contractions, EIGHT waves, 8 tokens per workgroup (rowblock8_kernel)" : ", split-f16 contractions, EIGHT waves, 16 tokens per workgroup (rowblock8_kernel)")) : "", B, T, nwg);
     for (int i = 1; i < 9; ++i) { printf("  %-46s %8.0f\n", names[i], acc[i] / nwg); tot += acc[i] / nwg; }
     printf("  total %.0f\n", tot);
-    double a9 = 0, a10 = 0, spread = 0;
-    long long first = st[0], last = st[0];
-    for (int wgi = 0; wgi < nwg; ++wgi) {
-        a9 += (double)(st[(size_t)wgi * 16 + 9] - st[(size_t)wgi * 16]);
-        a10 += (double)(st[(size_t)wgi * 16 + 10] - st[(size_t)wgi * 16]);
-        first = std::min(first, st[(size_t)wgi * 16]);
-        last = std::max(last, st[(size_t)wgi * 16]);
-    }
-    (void)spread;
-    printf("  inside the first phase: entry -> all requests issued %.0f, -> first batch landed (wave 0) %.0f; workgroup entry times spread over %lld cycles\n",
-           a9 / nwg, a10 / nwg, last - first);
-    if (h2 == 1 && !waves4) {
-        double a11 = 0, a12 = 0;
+    if (h2 == 1 && !waves4) {     // rowblock8_kernel: finer stamps of wave 0, all counted from the kernel's first instruction (stamp 0)
+        double a[16] = {0};
+        for (int wgi = 0; wgi < nwg; ++wgi)
+            for (int i = 9; i < 16; ++i) a[i] += (double)(st[(size_t)wgi * 16 + i] - st[(size_t)wgi * 16 + (i == 13 || i == 14 ? 1 : 0)]);
+        printf("  inside the first phase, from the kernel's first instruction (wave 0): token rows requested %.0f, rest of the argument segment read + every request issued %.0f, its rows landed %.0f,\n"
+               "    past the barrier behind the landing (every wave's rows are there) %.0f, wave 0 done with its rows (two LayerNorms side by side: its own + a halo row) %.0f\n",
+               a[9] / nwg, a[15] / nwg, a[10] / nwg, a[11] / nwg, a[12] / nwg);
+        printf("  inside the logits phase (wave 0): operands read + MFMAs issued %.0f, partial tiles stored + VW requested %.0f (then the barrier)\n", a[13] / nwg, a[14] / nwg);
+    } else {
+        double a9 = 0, a10 = 0;
         for (int wgi = 0; wgi < nwg; ++wgi) {
-            a11 += (double)(st[(size_t)wgi * 16 + 11] - st[(size_t)wgi * 16]);
-            a12 += (double)(st[(size_t)wgi * 16 + 12] - st[(size_t)wgi * 16]);
+            a9 += (double)(st[(size_t)wgi * 16 + 9] - st[(size_t)wgi * 16]);
+            a10 += (double)(st[(size_t)wgi * 16 + 10] - st[(size_t)wgi * 16]);
         }
-        printf("    -> past the barrier behind the landing (every wave's rows are there) %.0f, -> wave 0 done with its rows (two LayerNorms: its own + a halo row), before the second barrier %.0f\n", a11 / nwg, a12 / nwg);
-        double a13 = 0, a14 = 0, a15 = 0;
-        for (int wgi = 0; wgi < nwg; ++wgi) {
-            a13 += (double)(st[(size_t)wgi * 16 + 13] - st[(size_t)wgi * 16 + 1]);
-            a14 += (double)(st[(size_t)wgi * 16 + 14] - st[(size_t)wgi * 16 + 1]);
-            a15 += (double)(st[(size_t)wgi * 16 + 15] - st[(size_t)wgi * 16 + 6]);
-        }
-        printf("  inside the logits phase (wave 0): -> operands read, MFMAs issued %.0f, -> partial tiles stored, VW requested %.0f (then the barrier); inside P.VW: -> MFMAs issued %.0f\n", a13 / nwg, a14 / nwg, a15 / nwg);
+        printf("  inside the first phase (four-wave kernel: counted from behind the argument wait): all requests issued %.0f, first batch landed (wave 0) %.0f\n", a9 / nwg, a10 / nwg);
     }
     {
         const int nat = ((T + 16 * ATTN_RT - 1) / (16 * ATTN_RT)) * 4 * B;

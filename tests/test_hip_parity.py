@@ -2,6 +2,7 @@
 oracle on the same seeded inputs and against the golden fixtures recorded from the reference's own source.
 Tolerance: north_star's 1e-4 relative fp32 (max|delta| / max|ref|), tighter where the op allows; bit-exact for
 indices and decisions.  Run with:  python -m pytest tests -m gpu"""
+import os
 import numpy as np
 import pytest
 import torch
@@ -596,6 +597,32 @@ def test_exclusive_cu_claims_are_verified_and_hold(mdm, smpl):
         differing += 0 if (torch.equal(v, v0) and torch.equal(j, j0)) else 1
     fx.record_parity('smpl_stage_beside_split_f16_ffn', runs=8, runs_that_differ=differing)
     assert differing == 0, 'the SMPL stage computed different bits beside the split-f16 feed-forward kernel in %d of 8 runs' % differing
+
+
+def test_coresidency_reproducer_and_the_integrator_rule(tmp_path):
+    """The stand-alone reproducer of the co-residency effect (tools/coresidency_repro.hip; DESIGN.md "exclusive CU") as a test.
+    ASSERTED -- the rule an integrator is given: (i) a victim with NO packed-fp32 instruction (-fno-slp-vectorize) computes the same bits beside every aggressor form;
+    (ii) the controls of the default build (no aggressor, fp32 MFMA + loads, loads alone) are bit-stable.  RECORDED, not asserted (it is the hardware's behaviour, and a
+    later firmware may well end it): how many launches of the packed-fp32 victim differ beside the two f16-MFMA aggressor forms."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    src = os.path.join(os.path.dirname(__file__), '..', 'tools', 'coresidency_repro.hip')
+    out = {}
+    for name, extra in (('default', []), ('noslp', ['-fno-slp-vectorize'])):
+        exe = str(tmp_path / ('repro_' + name))
+        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3'] + extra + [src, '-o', exe], check=True, timeout=300)
+        txt = subprocess.run([exe, '2', '5000', '1024'], check=True, timeout=300, capture_output=True, text=True).stdout
+        rows = dict((m.group(1).strip(), int(m.group(2))) for m in re.finditer(r'^(.*?)\s*: (\d+) of \d+ victim launches differ', txt, re.M))
+        assert len(rows) == 5, txt
+        out[name] = rows
+    fx.record_parity('coresidency_reproducer', launches_per_form=48, **{k: v for k, v in out.items()})
+    assert all(v == 0 for v in out['noslp'].values()), out['noslp']
+    for control in ('no aggressor', 'fp32 MFMA + global loads', 'global loads only'):
+        assert out['default'][control] == 0, out['default']
 
 
 def test_evaluate_batch_and_sample_once(mdm, smpl):

@@ -9,7 +9,7 @@ __device__ long long g_rb_stamps[8192 * 16];
 __device__ long long g_at_stamps[8192 * 8];
 #define IDF_AT_STAMP(i) do { if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); } while (0)
 __device__ long long g_ah2_stamps[8192 * 8];
-#define IDF_AH2_STAMP(i) do { if (threadIdx.x == 0) g_ah2_stamps[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#define IDF_AH2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_ah2_stamps[blockIdx.x * 8 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #include "denoiser.hip"
 #include <algorithm>
 #include <cstdio>

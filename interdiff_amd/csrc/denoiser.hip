@@ -1066,15 +1066,17 @@ constexpr int ATTN_RT = IDF_ATTN_RT;     // 16-query tiles per workgroup of the 
 // RT: 16-query tiles per workgroup (grid.x = ceil(T / (16 RT))).  RT = 1 halves a workgroup's LDS image (73 KB at T = 100), so that two
 // workgroups share a CU and one's loads / softmax run beside the other's MFMA phases.
 template <bool OUTPROJ, int RT>
-__global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T,
+__global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T, int nwg,
                                                         const float *__restrict__ wo_frag, float *__restrict__ slabs, size_t pstride) {
+    // 1-D grid of nwg = ceil(T / QT) * H * B workgroups; all twelve argument dwords arrive preloaded in SGPRs (build.py): no argument-segment read, no gridDim
     extern __shared__ __attribute__((aligned(16))) float smx[];
-    idf_args_now(qkv, ctx, T, wo_frag, slabs, pstride, gridDim.x);
     IDF_AT_STAMP(0);
     const int TP = (T + 15) & ~15, SS = TP + SPAD;       // (TP + 8: the same 2-slots-mod-16 rule for the P.V A-operand reads of the score rows)
     constexpr int QT = 16 * RT;
     float *Ks = smx, *Vs = Ks + TP * ASK, *Qs = Vs + TP * AS, *Ss = Qs + QT * ASK;
-    const int lid = xcd_logical_id(), nqt = gridDim.x, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT, tid = threadIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = (int)blockIdx.x & 7;                   // XCD-affine logical id (xcd_logical_id)
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+    const int nqt = (T + QT - 1) / QT, b = lid / (nqt * H), h = (lid / nqt) % H, q0 = (lid % nqt) * QT, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const size_t rowbase = (size_t)b * T;
     // Operand fetch, all requests of a batch in flight together: clamped (always valid) addresses, no guard around a load -- a guarded
@@ -1519,8 +1521,8 @@ inline size_t attn_lds_bytes(int T, int rt) {
 // self-attention + out-projection partials of one standard layer: the one-shot kernel up to ATTN_MAX_T frames, the K/V-tiled one beyond
 inline void launch_self_attn_outproj(hipStream_t s, const float *qkv, int B, int T, const float *wo_frag, float *parts, size_t pstride) {
     if (T <= ATTN_MAX_T)
-        hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)idf_cdiv(T, 16 * ATTN_RT), H, B), dim3(256), attn_lds_bytes(T, ATTN_RT), s, qkv, nullptr, T,
-                           wo_frag, parts, pstride);
+        hipLaunchKernelGGL((self_attn_kernel<true, ATTN_RT>), dim3((unsigned)(idf_cdiv(T, 16 * ATTN_RT) * H * B)), dim3(256), attn_lds_bytes(T, ATTN_RT), s, qkv, nullptr, T,
+                           (int)(idf_cdiv(T, 16 * ATTN_RT) * H * B), wo_frag, parts, pstride);
     else
         hipLaunchKernelGGL(self_attn_tiled_kernel, dim3((unsigned)idf_cdiv(T, 16), H, B), dim3(256), 0, s, qkv, T, wo_frag, parts, pstride);
 }
@@ -1950,8 +1952,8 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                                    ar + ly.ln_w[0], ar + ly.ln_b[0], Gl, g0l, VWTl, ar + ly.ca_out_b, ar + ly.ln_w[1],
                                    ar + ly.ln_b[1], k.x2, T, 0, pstride, k.xn, ar + ly.sa_out_b, nullptr, mlen);
             } else {                                   // A/B runs: the out-projection as a separate GEMM (tools/kbench.py)
-                hipLaunchKernelGGL((self_attn_kernel<false, 2>), dim3((unsigned)idf_cdiv(T, 32), H, B), dim3(256), attn_lds_bytes(T, 2), s, k.qkv, k.ctx, T,
-                                   nullptr, nullptr, (size_t)0);
+                hipLaunchKernelGGL((self_attn_kernel<false, 2>), dim3((unsigned)(idf_cdiv(T, 32) * H * B)), dim3(256), attn_lds_bytes(T, 2), s, k.qkv, k.ctx, T,
+                                   (int)(idf_cdiv(T, 32) * H * B), nullptr, nullptr, (size_t)0);
                 Args o{};
                 o.A = k.ctx; o.lda = D; o.K = D; o.W = ar + ly.sa_out_w; o.bias = ar + ly.sa_out_b; o.C = u_tmp; o.ldc = D; o.M = N;
                 o.N = D; o.resid = k.xn; o.T = T;

@@ -57,7 +57,10 @@ struct TailArgs {
 };
 
 template <int MODE, bool RAGGED>
-__global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
+__global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const float *__restrict__ u_in, size_t u_pstride, const float *__restrict__ wout, int M, int T, int nwg,
+                                                           int plain_ids, const TailArgs a) {
+    // (the leading scalars repeat what the heads' first requests need -- slab rows, weight fragments, sizes: they arrive preloaded in SGPRs (build.py), the struct behind
+    // them is read from the argument segment while those requests fly)
     constexpr bool HEADS = MODE != 0, EMBED = MODE == 0 || MODE == 3, POST = MODE >= 2;
     asm volatile("" ::: "v255");                         // exclusive CU: 2 waves per SIMD x 256 registers = the register file (+ the dynamic LDS the launcher adds)
     __shared__ __attribute__((aligned(16))) _Float16 rpl[HEADS ? 2 * TRW * RHS : 8];     // [hi | lo'][16][RHS]: LN3 rows
@@ -69,9 +72,9 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
     // XCD-affine row tiles (round 5): workgroup id runs on XCD id % 8; giving an XCD CONSECUTIVE tiles puts the rows of clips {2x, 2x + 1} (B = 16, T = 100) on XCD x
     // like the row block, the attention, the feed-forward and the QKV kernels already do -- the five slabs this kernel sums were written by that XCD, and the u0 / x rows
     // it writes are read by that XCD's QKV workgroups next (any order is correct: every workgroup computes the same tile).
-    const int nwg = gridDim.x, wid = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = wid & 7;
-    const int tile = a.plain_ids ? wid : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
-    const int m0 = tile * TRW, M = a.M, T = a.T;
+    const int wid = blockIdx.x, xq = nwg >> 3, xr = nwg & 7, xcd = wid & 7;
+    const int tile = plain_ids ? wid : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wid >> 3);
+    const int m0 = tile * TRW;
     const int rown = (wave & 3) * 4 + kq;                 // row passes (waves 0..3): one 16-lane group per token row
     const bool rowpass = wave < 4;
 
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
         const int ntw = wave == 0 ? 2 : 1;
         auto tile_of = [&](int j) { return j == 0 ? wave : NTO - 1; };
         Row16Raw<IDF_FFN_SLICES> raw;
-        if (rowpass) raw.request(a.u_in + (size_t)min(m0 + rown, M - 1) * D, li, a.pstride);
+        if (rowpass) raw.request(u_in + (size_t)min(m0 + rown, M - 1) * D, li, u_pstride);
         idf_gemm::PostOperands<1, 1> po[NTW];
         if constexpr (POST) {
 #pragma unroll
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const TailArgs a) {
 #pragma unroll
                 for (int s = 0; s < KSH; ++s)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) wf[j][s][pl] = idf_gemm::ld4(a.wout + (size_t)(((tile_of(j) * KSH + s) * 2 + pl) * 64 + lane) * 4);
+                    for (int pl = 0; pl < 2; ++pl) wf[j][s][pl] = idf_gemm::ld4(wout + (size_t)(((tile_of(j) * KSH + s) * 2 + pl) * 64 + lane) * 4);
             }
         if (rowpass) {
             Row16 r;
@@ -254,7 +257,8 @@ inline int launch_tail_one(hipStream_t s, const TailArgs *ta) {
     const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&step_tail_h2_kernel<MODE, RAGGED>), names[MODE], NTH, excl);
     if (!ta) return dyn;
     if (dyn < 0) return IDF_NOT_EXCLUSIVE;
-    hipLaunchKernelGGL((step_tail_h2_kernel<MODE, RAGGED>), dim3((unsigned)idf_cdiv(ta->M, TRW)), dim3(NTH), (size_t)dyn, s, *ta);
+    hipLaunchKernelGGL((step_tail_h2_kernel<MODE, RAGGED>), dim3((unsigned)idf_cdiv(ta->M, TRW)), dim3(NTH), (size_t)dyn, s, ta->u_in, ta->pstride, ta->wout, ta->M, ta->T,
+                       (int)idf_cdiv(ta->M, TRW), ta->plain_ids, *ta);
     return IDF_OK;
 }
 inline int launch_tail_sel(hipStream_t s, int mode, bool ragged, const TailArgs *ta) {

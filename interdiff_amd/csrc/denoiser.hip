@@ -754,7 +754,10 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
     static_assert(TV == 16 || TV == 8, "tokens per workgroup");
     constexpr int NCT = ML::NCT, NSLOT = ML::NSLOT, NW8 = 8, NPT = NCT > 3 ? NCT : 3;
     constexpr int LPR = 512 / TV;                 // lanes per token row in the row passes
-    constexpr int PTR = 17, PTS = 16 * PTR;       // K-split partial tiles: row stride 17 floats (the head softmax reads a tile column-wise: 16 would be a 4-way bank conflict)
+    constexpr int PTR = 20, PTS = 16 * PTR;       // K-split partial tiles: row stride 20 floats.  The MFMA result layout stores row 4 kq + r, column li per lane: 4 rows = 80 floats = 16 banks
+                                                  // further, so the four kq groups of a store cover 64 different banks (17 put them 4 banks apart: up to 4 lanes per bank, ~0.6 k conflict
+                                                  // cycles per workgroup = most of the kernel's SQ_LDS_BANK_CONFLICT); the head softmax's column-wise reads (token = lane >> 2: 20 tq mod 64 are
+                                                  // the sixteen multiples of 4) and the tap softmax's row reads stay conflict-free
     constexpr int XS = QAN ? (TR + 2) * RS : 0;
     constexpr int HS = D + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16), PHS = 64 + (IDF_LDS_STRIDE_SET == 4 ? 8 : 16);     // plane strides: conflict-free fragment reads (rowblock_kernel)
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * (TR + 2) * HS];       // [hi | lo'][TR+2][HS]: LN_prev rows for the logits, then x1 for the scores (TV + 2 rows are written)

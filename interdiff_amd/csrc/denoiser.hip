@@ -1609,7 +1609,26 @@ int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, 
     return IDF_OK;
 }
 
+
+// ---- The seven kernels of a plain denoising step at the shipped shapes, instantiated HERE, next to each other (three inside this namespace, four right behind it).  Explicit
+// instantiations are emitted where they stand, so the seven end up CONTIGUOUS in the code object (57 KB); implicit ones land wherever the compiler gets to them -- scattered over
+// this file's 1.1 MB of code, where 16-39 % of their cache lines shared an instruction-cache set with more lines than it has ways (64 KB per CU pair; a step cycles through all
+// seven kernels, 22 launches at a time: with LRU such a set misses on every pass).  Contiguous code maps onto the cache without a collision.
+// (Which instantiations: mdm_forward_impl_t at B = 16, T = 100, memory length 10.)
+template __global__ void self_attn_kernel<true, ATTN_RT>(const float *, float *, int, int, const float *, float *, size_t);
+template __global__ void rowblock8_kernel<false, H, MEM, 8>(const float *, int, int, int, int, size_t, const float *, const float *, const float *, const float *, const float *, const float *,
+                                                            const float *, const float *, const float *, const float *, const float *, const float *, const float *, float *, const float *,
+                                                            const float *);
+template __global__ void rowblock8_kernel<true, NSL, MEM, 8>(const float *, int, int, int, int, size_t, const float *, const float *, const float *, const float *, const float *, const float *,
+                                                             const float *, const float *, const float *, const float *, const float *, const float *, const float *, float *, const float *,
+                                                             const float *);
 }  // namespace
+template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0>(const float *, int, int, const float *, const float *, const float *, float *, int);
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
+                                                            int64_t *, int64_t *);
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int,
+                                                                         float *, int64_t *, int64_t *);
+template __global__ void idf_tail_h2::step_tail_h2_kernel<3, false>(const float *, size_t, const float *, int, int, int, int, const idf_tail_h2::TailArgs);
 
 extern "C" int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts,
                                  void *stream) {

@@ -1028,12 +1028,21 @@ __global__ __launch_bounds__(512) void rowblock8_kernel(const float *__restrict_
             const float4 bh[2] = {vw2[s2][0][0], vw2[s2][1][0]}, bl[2] = {vw2[s2][0][1], vw2[s2][1][1]};
             mma_h2<2>(acc, acc_c, ah, al, bh, bl);
         }
+        if (TV == 16 || kq * 4 < TV) {            // (8 tokens: rows 0..7 = the lanes of kq 0, 1.  ONE branch around all eight updates: a guard per element made eight serial LDS round trips)
+            float xo[2][4], bo[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = (wave * 2 + c) * 16 + li;
+            for (int c = 0; c < 2; ++c) {
+                const int col = (wave * 2 + c) * 16 + li;
+                bo[c] = P_bout[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (TV == 16 || kq * 4 + r < TV) x1s[(kq * 4 + r) * RS + col] += (acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc + P_bout[col];       // VW[b] was divided by vsc
+                for (int r = 0; r < 4; ++r) xo[c][r] = x1s[(kq * 4 + r) * RS + col];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = (wave * 2 + c) * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x1s[(kq * 4 + r) * RS + col] = xo[c][r] + ((acc[c][r] + acc_c[c][r] * idf_ffn_h2::LO_UNSCALE) * vsc + bo[c]);       // VW[b] was divided by vsc
+            }
         }
     }
     __syncthreads();

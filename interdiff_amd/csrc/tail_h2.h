@@ -111,17 +111,24 @@ __global__ __launch_bounds__(NTH) void step_tail_h2_kernel(const float *__restri
         f32x4 am[NTW], ac[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) am[j] = ac[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // every A fragment first (16 reads in flight together), then one MFMA chain per tile under ONE branch: with the guard inside the K loop every step was its own
+        // basic block -- eight serial LDS round trips in front of the matrix pipe.  Same products in the same order per accumulator.
+        h8 ah[KSH], al[KSH];
 #pragma unroll
         for (int s = 0; s < KSH; ++s) {
-            const h8 ah = *reinterpret_cast<const h8 *>(rpl + li * RHS + 32 * s + 8 * kq), al = *reinterpret_cast<const h8 *>(rpl + (TRW + li) * RHS + 32 * s + 8 * kq);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                if (j < ntw) {
-                    IDF_H2_MFMA(am[j], ah, __builtin_bit_cast(h8, wf[j][s][0]));
-                    IDF_H2_MFMA(ac[j], ah, __builtin_bit_cast(h8, wf[j][s][1]));
-                    IDF_H2_MFMA(ac[j], al, __builtin_bit_cast(h8, wf[j][s][0]));
-                }
+            ah[s] = *reinterpret_cast<const h8 *>(rpl + li * RHS + 32 * s + 8 * kq);
+            al[s] = *reinterpret_cast<const h8 *>(rpl + (TRW + li) * RHS + 32 * s + 8 * kq);
         }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+            if (j < ntw) {
+#pragma unroll
+                for (int s = 0; s < KSH; ++s) {
+                    IDF_H2_MFMA(am[j], ah[s], __builtin_bit_cast(h8, wf[j][s][0]));
+                    IDF_H2_MFMA(ac[j], ah[s], __builtin_bit_cast(h8, wf[j][s][1]));
+                    IDF_H2_MFMA(ac[j], al[s], __builtin_bit_cast(h8, wf[j][s][0]));
+                }
+            }
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
             if (j < ntw) {

@@ -553,7 +553,7 @@ def main():
     line = dict(metric='denoising frame-steps/sec (denoising-steps/sec x B x T frames)', value=STEPS * Btot * T / wall,
                 unit='frame-steps/s', n_gpus=world, steps=n_timed, steps_requested=K, warmup=args.warmup, ms_per_step=1e3 * wall / STEPS,
                 higher_is_better=True, scaling='weak', vs_baseline=None,
-                dtype='f32 (feed-forward block, QKV projection, row-block contractions and the two token GEMMs: every fp32 operand as two f16 planes, 3 f16 MFMAs per product, fp32 accumulate; self-attention, SMPL and everything else fp32 MFMA / VALU)' if split else 'f32',
+                dtype='f32 (every contraction of the denoiser -- feed-forward block, QKV projection, self-attention, row-block contractions and the two token GEMMs: every fp32 operand as two f16 planes, 3 f16 MFMAs per product, fp32 accumulate; SMPL and everything else fp32 MFMA / VALU)' if split else 'f32',
                 data='synthetic', steps_per_sec=STEPS / wall,
                 ms_per_step_samples=dict(median=1e3 * wall / STEPS, min=1e3 * min(sample_s) / STEPS, max=1e3 * max(sample_s) / STEPS,
                                          all=[round(1e3 * w_ / STEPS, 5) for w_ in sample_s], n=n_samples,

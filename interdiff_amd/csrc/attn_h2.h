@@ -1,6 +1,7 @@
-// NOT ON THE DEFAULT ROUTE (tune[IDF_TUNE_MISC] = 5 selects it): correct (all parity tests pass with it; a denoiser forward is 3.2e-7 from the fp64 answer
-// with it, 4.6e-7 without) but 1.5 % slower over whole samples than the fp32 kernel it would replace -- 11.1 / 10.0 us against 10.2 / 9.8 in situ
-// (profiles/r04_attn_split_f16_ab.txt): owning the CU costs the overlap of two co-resident workgroups, which was worth more than the matrix time saved.
+// THE DEFAULT self-attention of the split arithmetic since round 5 (tune[IDF_TUNE_MISC] = 6 selects the fp32 kernel of denoiser.hip instead).  Round 4 built it and
+// left it off the route: owning the CU costs the overlap of two co-resident workgroups, and with V staged as fp32 and transposed through LDS it was 1.5 % slower over whole
+// samples (profiles/r04_attn_split_f16_ab.txt).  With V kept row-major and read by ds_read_b64_tr_b16 -- no staging, no transposition, two barriers fewer: 17.4 k -> 15.2 k
+// cycles per workgroup -- it is 1.2 % FASTER than the fp32 kernel (profiles/r05_attn_split_f16_ab.txt); a denoiser forward is 3.2e-7 from the fp64 answer with it, 4.6e-7 without.
 //
 // Temporal self-attention of the two standard layers with its head's slice of the out-projection, on the f16 matrix pipe (round 4):
 //
@@ -15,7 +16,7 @@
 //    (exact; an f16 pair then keeps 22 bits of every element down to 2^-27 of the largest) and the fp32 results are multiplied back -- S by 2^(eq + ek) / 8,
 //    the out-projection by 2^ev (the context is a convex combination of V rows: it inherits V's scale and range).  Probabilities are split as they are.
 //  * W_o arrives as pre-split plane fragments [head][16 column tiles][2 K steps][2 planes][64 lanes][8 halves] (mdm.py sa_out_fragments_h2).
-// LDS (dynamic, sized by T; T <= 208): K planes [TP][72] x 2 | V^T planes [64][TPP + 8] x 2 | S fp32 [32][TP + 4] | Q planes [32][72] x 2; the probability
+// LDS (dynamic, sized by T; T <= 192): K planes [TP][72] x 2 | V planes [TPP][72] x 2, row-major | S fp32 [32][TP + 4] | Q planes [32][72] x 2; the probability
 // planes [32][TPP + 8] x 2 overwrite K once S is complete, the context planes overwrite Q.  TP = T up to 16, TPP = T up to 32 (K steps over the keys).
 #pragma once
 #include <float.h>
@@ -32,14 +33,31 @@ namespace idf_attn_h2 {
 using idf_ffn_h2::h8;
 constexpr int D = IDF_MDM_D, H = IDF_MDM_HEADS, HD = D / H, QT = 32, NTH = 512, NWV = NTH / 64;
 constexpr int KHS = HD + 8;                              // row stride (halves) of the Q / K / context planes
-constexpr int MAX_T = 208, NIT = (MAX_T * 16 + NTH - 1) / NTH;      // float4 sweeps of a K / V tile per thread: 7
+constexpr int VRS = HD + 8;                              // row stride (halves) of the V planes (row-major [key][dim]: the P V operand is read with the transposing LDS read)
+constexpr int MAX_T = 192, NIT = (MAX_T * 16 + NTH - 1) / NTH;      // float4 sweeps of a K / V tile per thread: 6 (the planes of a longer clip do not fit the CU's LDS: the fp32 kernel takes it)
+constexpr int NIT0 = 4;                                  // sweeps that cover T <= 128: requested unconditionally; the rest sit behind ONE workgroup-uniform branch
 constexpr int WO_H2_FLOATS = H * 16 * 2 * 2 * 64 * 4;      // 32768
 
 // halves of the region that holds the K planes and later the probability planes
 __host__ __device__ inline int k_region_halves(int TP, int TPP) { return 2 * TP * KHS > 2 * QT * (TPP + 8) ? 2 * TP * KHS : 2 * QT * (TPP + 8); }
 inline size_t lds_bytes(int T) {
     const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31;
-    return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * HD * (TPP + 8) * 2 + (size_t)QT * (TP + 4) * 4 + (size_t)2 * QT * KHS * 2 + 64;
+    return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * TPP * VRS * 2 + (size_t)QT * (TP + 4) * 4 + (size_t)2 * QT * KHS * 2 + 64;
+}
+
+// The P V operand of one K step from the row-major V planes: four transposing LDS reads (ds_read_b64_tr_b16, four halves each: keys k0 .. k0 + 3 and k0 + 4 .. k0 + 7 of the
+// lane's column, hi plane and lo plane) and ONE wait.  `hi` / `lo`: the lane's 8-byte-aligned chunk address in either plane (see the call site); the second read of a plane
+// is the immediate offset of four rows.  (The wait is inside: the compiler does not count an asm's LDS operations, and nothing of this asm is in flight when it ends.)
+__device__ __forceinline__ void tr_read_v(const _Float16 *hi, const _Float16 *lo, h8 &bh, h8 &bl) {
+    typedef __attribute__((address_space(3))) const _Float16 lds_h;
+    uint64_t h0, h1, l0, l1;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\tds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+                 : "v"((uint32_t)(uintptr_t)(lds_h *)hi), "v"((uint32_t)(uintptr_t)(lds_h *)lo), "i"(4 * VRS * 2)
+                 : "memory");
+    struct { uint64_t a, b; } ph = {h0, h1}, pl = {l0, l1};
+    bh = __builtin_bit_cast(h8, ph);
+    bl = __builtin_bit_cast(h8, pl);
 }
 
 // power of two that brings amax into [2^13, 2^14): returns the multiplier 2^-e and, through `up`, 2^e (1 for an all-zero or non-finite tile)
@@ -50,6 +68,7 @@ __device__ __forceinline__ float pow2_scale(float amax, float &up) {
     return __builtin_bit_cast(float, (uint32_t)((127 - e) << 23));
 }
 
+template <int PLACED = 0>      // (a template only so that denoiser.hip can instantiate it explicitly, next to the other kernels of a step: code placement)
 __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restrict__ qkv, int T, int nwg, const float *__restrict__ wo_h2,
                                                            float *__restrict__ slabs, size_t pstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -58,8 +77,8 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     // (all ten argument dwords, the grid size among them, arrive preloaded in SGPRs: build.py)
     const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31, VTS = TPP + 8, SS = TP + 4;
     _Float16 *kh = reinterpret_cast<_Float16 *>(smraw), *kl = kh + TP * KHS;                 // K planes [TP][KHS]
-    _Float16 *vth = kh + k_region_halves(TP, TPP), *vtl = vth + HD * VTS;                    // V^T planes [64][VTS]
-    float *Ss = reinterpret_cast<float *>(vtl + HD * VTS);                                   // S [32][SS]
+    _Float16 *vh = kh + k_region_halves(TP, TPP), *vl = vh + TPP * VRS;                      // V planes [TPP][VRS], row-major (rows T .. TPP - 1 zero)
+    float *Ss = reinterpret_cast<float *>(vl + TPP * VRS);                                   // S [32][SS]
     _Float16 *qh = reinterpret_cast<_Float16 *>(Ss + QT * SS), *ql = qh + QT * KHS;          // Q planes [32][KHS], later the context planes
     _Float16 *ph = kh, *pl = kh + QT * VTS;                                                  // probability planes [32][VTS] over K (the region is sized for the larger of the two)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -74,11 +93,23 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     const float4 qv = *reinterpret_cast<const float4 *>(qkv + (rowbase + min(q0 + qr, T - 1)) * (3 * D) + h * HD + c4);
     float4 kreg[NIT], vreg[NIT];
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) {
+    for (int u = 0; u < NIT0; ++u) {
         const int j = min(qr + 32 * u, T - 1);
         const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
         kreg[u] = *reinterpret_cast<const float4 *>(src + D);
         vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
+    }
+    if (TP > 32 * NIT0) {                                // (clips longer than 128 frames; at T = 100 these sweeps were three more rounds of clamped -- repeated -- requests)
+#pragma unroll
+        for (int u = NIT0; u < NIT; ++u) {
+            const int j = min(qr + 32 * u, T - 1);
+            const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
+            kreg[u] = *reinterpret_cast<const float4 *>(src + D);
+            vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
+        }
+    } else {
+#pragma unroll
+        for (int u = NIT0; u < NIT; ++u) kreg[u] = vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 wo[2][2][2];                                  // out-projection fragments of this wave's two column tiles: [tile][K step][plane]
 #pragma unroll
@@ -108,32 +139,11 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     float uq, uk, uv;
     const float dq = pow2_scale(aq, uq), dk = pow2_scale(ak, uk), dv = pow2_scale(av, uv);
 
-    // ---- planes: Q and K row-major [row][dim], V transposed [dim][key] (it is the B operand of P V: a lane's 8 halves run along the keys).
-    // The transposition goes through LDS as fp32 (staged in the K region, which K's planes take afterwards): a first version wrote V^T straight from the registers
-    // with 56 two-byte stores per thread into four banks -- 6 k of the launch's 18.6 k cycles (tools/rowblock_probe.hip).
+    // ---- planes: Q, K and V row-major [row][dim], each thread splits the chunks it fetched -- no staging, no transposition: the P V contraction reads its V operand
+    // with gfx950's transposing LDS read (ds_read_b64_tr_b16, below).  (A first version staged V as fp32, transposed it with eight strided scalar reads per octet of
+    // keys and needed two more barriers: 6.7 k of the launch's 17.4 k cycles went into this phase, tools/rowblock_probe.hip.)
     {
-        constexpr int VFS = HD + 4;                      // row stride (floats) of the staged V tile: [TP][VFS] floats <= the K region for every T
-        float *Vf = reinterpret_cast<float *>(kh);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int j = qr + 32 * u;
-            if (32 * u < TP && j < TP)                   // (first condition workgroup-uniform)
-                *reinterpret_cast<float4 *>(Vf + j * VFS + c4) = j < T ? make_float4(vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv) : z;
-        }
-        __syncthreads();
-        for (int g = tid; g < HD * (TPP / 8); g += NTH) {            // (dim, octet of keys): lanes run along the dims, so the strided reads hit 64 different banks
-            const int d = g & (HD - 1), j0 = (g / HD) * 8;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = j0 + e < TP ? Vf[(j0 + e) * VFS + d] : 0.f;       // keys TP .. TPP - 1 are zero: they meet zero probabilities
-            uint2 h0, l0, h1, l1;
-            idf_ffn_h2::split4_pk(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
-            idf_ffn_h2::split4_pk(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
-            *reinterpret_cast<uint4 *>(vth + d * VTS + j0) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            *reinterpret_cast<uint4 *>(vtl + d * VTS + j0) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        }
-        __syncthreads();                                 // the staged tile is consumed: its region becomes the K planes
         uint2 hi, lo;
         idf_ffn_h2::split4_pk(q0 + qr < T ? make_float4(qv.x * dq, qv.y * dq, qv.z * dq, qv.w * dq) : z, hi, lo);
         *reinterpret_cast<uint2 *>(qh + qr * KHS + c4) = hi;
@@ -141,10 +151,15 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             const int j = qr + 32 * u;
-            if (32 * u < TP && j < TP) {
-                idf_ffn_h2::split4_pk(j < T ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
-                *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
-                *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
+            if (32 * u < TPP && j < TPP) {               // (first condition workgroup-uniform)
+                if (j < TP) {
+                    idf_ffn_h2::split4_pk(j < T ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
+                    *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
+                    *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
+                }
+                idf_ffn_h2::split4_pk(j < T ? make_float4(vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv) : z, hi, lo);      // keys T .. TPP - 1: zero rows (they meet zero probabilities)
+                *reinterpret_cast<uint2 *>(vh + j * VRS + c4) = hi;
+                *reinterpret_cast<uint2 *>(vl + j * VRS + c4) = lo;
             }
         }
     }
@@ -177,36 +192,59 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     __syncthreads();
     IDF_AH2_STAMP(3);                                    // S
 
-    // ---- row softmax: one 16-lane group per query row (32 groups = 32 rows); lane l16 owns columns l16, 16 + l16, ...; probabilities leave as planes over K
+    // ---- row softmax: one 16-lane group per query row (32 groups = 32 rows); lane l16 owns columns l16, 16 + l16, ...; probabilities leave as planes over K.
+    // The first NC0 = 8 columns per lane cover T <= 128 and run unconditionally; the columns of longer clips sit behind ONE workgroup-uniform branch per pass
+    // (same operations in the same order: max, then the sum over ascending columns).
     {
-        constexpr int NC = ((MAX_T + 31) & ~31) / 16;    // 14 columns per lane cover TPP of the longest clip
+        constexpr int NC = ((MAX_T + 31) & ~31) / 16, NC0 = 8;      // 12 columns per lane cover TPP of the longest clip
         const int row = wave * 4 + kq;
         const float *srow = Ss + row * SS;
+        const bool tail = TP > 16 * NC0;
         float v[NC], mx = -FLT_MAX;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < NC0; ++c) {
             const int j = 16 * c + li;
             v[c] = srow[min(j, TP - 1)];
             v[c] = j < T ? v[c] : -FLT_MAX;
             mx = fmaxf(mx, v[c]);
         }
+        if (tail) {
+#pragma unroll
+            for (int c = NC0; c < NC; ++c) {
+                const int j = 16 * c + li;
+                v[c] = srow[min(j, TP - 1)];
+                v[c] = j < T ? v[c] : -FLT_MAX;
+                mx = fmaxf(mx, v[c]);
+            }
+        }
         mx = row16_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < NC0; ++c) {
             v[c] = 16 * c + li < T ? __expf(v[c] - mx) : 0.f;
             sum += v[c];
         }
-        const float inv = __builtin_amdgcn_rcpf(row16_sum(sum));
+        if (tail) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int j = 16 * c + li;
-            if (j < TPP) {                               // columns T .. TPP - 1 are written as zeros: they are part of the last K step
-                _Float16 a, cc;
-                idf_ffn_h2::split1_nf(v[c] * inv, a, cc);
-                ph[row * VTS + j] = a;
-                pl[row * VTS + j] = cc;
+            for (int c = NC0; c < NC; ++c) {
+                v[c] = 16 * c + li < T ? __expf(v[c] - mx) : 0.f;
+                sum += v[c];
             }
+        }
+        const float inv = __builtin_amdgcn_rcpf(row16_sum(sum));
+        auto put = [&](int c) {                          // columns T .. TPP - 1 are written as zeros: they are part of the last K step
+            _Float16 a, cc;
+            idf_ffn_h2::split1_nf(v[c] * inv, a, cc);
+            ph[row * VTS + 16 * c + li] = a;
+            pl[row * VTS + 16 * c + li] = cc;
+        };
+#pragma unroll
+        for (int c = 0; c < NC0; ++c)
+            if (16 * c < TPP) put(c);                    // (workgroup-uniform: TPP is a multiple of 32)
+        if (tail) {
+#pragma unroll
+            for (int c = NC0; c < NC; ++c)
+                if (16 * c < TPP) put(c);
         }
     }
     __syncthreads();
@@ -219,7 +257,12 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
         for (int s = 0; s < TPP / 32; ++s) {
             const int ko = 32 * s + 8 * kq;
             const h8 ah = *reinterpret_cast<const h8 *>(ph + (rt * 16 + li) * VTS + ko), al = *reinterpret_cast<const h8 *>(pl + (rt * 16 + li) * VTS + ko);
-            const h8 bh = *reinterpret_cast<const h8 *>(vth + (dt * 16 + li) * VTS + ko), bl = *reinterpret_cast<const h8 *>(vtl + (dt * 16 + li) * VTS + ko);
+            // B operand: lane (li = head-dim column, kq) needs V[32 s + 8 kq .. + 7][16 dt + li] -- eight KEYS of one column of the row-major image.  ds_read_b64_tr_b16: the 16 lanes of
+            // a group each name four contiguous halves, lane c the chunk (key k0 + (c >> 2), dims 16 dt + 4 (c & 3) ..), and lane i receives element i & 3 of the chunks (i >> 2) + 4 j,
+            // j = 0..3 = keys k0 .. k0 + 3 of column 16 dt + i (tools/tr_read_probe.hip); two reads (k0 = 32 s + 8 kq, + 4) make the fragment
+            const int vo = (ko + (li >> 2)) * VRS + dt * 16 + 4 * (li & 3);
+            h8 bh, bl;
+            tr_read_v(vh + vo, vl + vo, bh, bl);
             IDF_H2_MFMA(am, ah, bh);
             IDF_H2_MFMA(ac, ah, bl);
             IDF_H2_MFMA(ac, al, bh);
@@ -274,10 +317,10 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
 
 inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride) {
     static idf_excl_cache excl;
-    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel<0>), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
     if (dyn < 0) return IDF_NOT_EXCLUSIVE;
     if (T > MAX_T || (int)lds_bytes(T) > dyn) return IDF_E_INVAL;
-    hipLaunchKernelGGL(self_attn_h2_kernel, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, (int)(idf_cdiv(T, QT) * H * B), wo_h2, slabs, pstride);
+    hipLaunchKernelGGL(self_attn_h2_kernel<0>, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, (int)(idf_cdiv(T, QT) * H * B), wo_h2, slabs, pstride);
     return IDF_OK;
 }
 

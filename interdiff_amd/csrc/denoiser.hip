@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
     IDF_AT_STAMP(4);                                     // P V (+ store)
     if constexpr (OUTPROJ) {
         __syncthreads();
+        IDF_AT_STAMP(7);                                 // (probe) context tile in LDS, every wave there
         f32x4 o[4 * RT];
 #pragma unroll
         for (int i = 0; i < 4 * RT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1259,6 +1260,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
             }
             mma_rounds<4 * RT>(o, a, bb);
         }
+        IDF_AT_STAMP(6);                                 // (probe) out-projection MFMAs issued
         float *slab = slabs + (size_t)h * pstride;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1619,12 +1621,11 @@ int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, 
 }
 
 
-// ---- The seven kernels of a plain denoising step at the shipped shapes, instantiated HERE, next to each other (three inside this namespace, four right behind it).  Explicit
+// ---- The seven kernels of a plain denoising step at the shipped shapes, instantiated HERE, next to each other (two inside this namespace, five right behind it).  Explicit
 // instantiations are emitted where they stand, so the seven end up CONTIGUOUS in the code object (57 KB); implicit ones land wherever the compiler gets to them -- scattered over
 // this file's 1.1 MB of code, where 16-39 % of their cache lines shared an instruction-cache set with more lines than it has ways (64 KB per CU pair; a step cycles through all
 // seven kernels, 22 launches at a time: with LRU such a set misses on every pass).  Contiguous code maps onto the cache without a collision.
 // (Which instantiations: mdm_forward_impl_t at B = 16, T = 100, memory length 10.)
-template __global__ void self_attn_kernel<true, ATTN_RT>(const float *, float *, int, int, const float *, float *, size_t);
 template __global__ void rowblock8_kernel<false, H, MEM, 8>(const float *, int, int, int, int, size_t, const float *, const float *, const float *, const float *, const float *, const float *,
                                                             const float *, const float *, const float *, const float *, const float *, const float *, const float *, float *, const float *,
                                                             const float *);
@@ -1632,6 +1633,7 @@ template __global__ void rowblock8_kernel<true, NSL, MEM, 8>(const float *, int,
                                                              const float *, const float *, const float *, const float *, const float *, const float *, const float *, float *, const float *,
                                                              const float *);
 }  // namespace
+template __global__ void idf_attn_h2::self_attn_h2_kernel<0>(const float *, int, int, const float *, float *, size_t);
 template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0>(const float *, int, int, const float *, const float *, const float *, float *, int);
 template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
                                                             int64_t *, int64_t *);
@@ -1957,7 +1959,10 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                 // u1 = xn + ctx.Wo^T + bo with the product taken per head inside the attention kernel: H partial slabs in the FFN's
                 // slab buffer (its previous contents were consumed by the QKV kernel), summed with xn + bo by the row block
                 int rc_ah2 = IDF_NOT_EXCLUSIVE;
-                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] == 5 && T <= ATTN_MAX_T) {      // NOT the default: the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) measured 1.5 % slower over whole samples than the fp32 kernel with two workgroups per CU (profiles/r04_attn_split_f16_ab.txt); MISC = 5 selects it
+                // the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) is the default since round 5 (row-major V planes read with the transposing LDS read:
+                // -1.2 % per step against the fp32 kernel, profiles/r05_attn_split_f16_ab.txt); tune[IDF_TUNE_MISC] == 6 keeps the fp32 kernel for A/B; clips longer than its LDS
+                // budget (T > 192), the exact arithmetic and a device where it does not get its CU take the fp32 kernel
+                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] != 6 && T <= idf_attn_h2::MAX_T) {
                     rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride);
                     if (rc_ah2 != IDF_OK && rc_ah2 != IDF_NOT_EXCLUSIVE) return rc_ah2;
                 }
@@ -2090,7 +2095,7 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<4, 2, 0>), "ffn_h2_kernel<64 rows>", NT, c[2]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel<0>), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
     }
     rb_h2_qan_dyn<MEM>();
     rb_h2_std_dyn<MEM>();

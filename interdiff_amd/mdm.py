@@ -646,11 +646,13 @@ class MDM:
                      rowblock='split' if (rb_split and ly.rb_h2_ok and (not ly.is_qan or (ly.qc_h2 and l > 0))) else 'exact')
             if not ly.is_qan:
                 d['qkv'] = 'split' if (split and ly.sa_in_pack_h2) else 'exact'
-                d['self_attention'] = 'exact'
+                # csrc/denoiser.hip: the split-f16 attention kernel unless tune misc == 6 (A/B) or its fragments were not packed; clips longer than 192 frames and a device where
+                # the kernel does not get its CU take the fp32 kernel at launch time (not known here)
+                d['self_attention'] = 'split' if (split and ly.sa_out_frag_h2 and w.tune[_lib.TUNE['misc']] != 6) else 'exact'
             layers.append(d)
         tail = 'split' if (split and w.out_w_h2 and w.in_w_h2 and w.C == 144 and w.tail_h2_ok) else 'exact'
         return dict(ffn_math=self.ffn_math, rowblock_math=self.rowblock_math, layers=layers, embedding_and_heads=tail,
-                    all_split=all(d['ffn'] == 'split' and d['rowblock'] == 'split' and d.get('qkv', 'split') == 'split' for d in layers) and tail == 'split')
+                    all_split=all(d['ffn'] == 'split' and d['rowblock'] == 'split' and d.get('qkv', 'split') == 'split' and d.get('self_attention', 'split') == 'split' for d in layers) and tail == 'split')
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):
         """``memctx`` / ``ws``: caller-owned folded memory and workspace, as in ``forward_step`` (then ``y`` is not consulted).

@@ -112,25 +112,27 @@ def test_mdm_forward_split_f16_vs_exact_and_fp64(lib):
         assert err['exact'] <= 1e-5, (B, T, err)
 
 
-def test_mdm_forward_with_the_split_f16_attention_kernel(lib):
-    """csrc/attn_h2.h (not on the default route: measured slower, tune[IDF_TUNE_MISC] = 5 selects it) against the oracle in float64 at the bench shape, the
-    longest clip, the reference's default clip length and one shorter than a key tile: as close to fp64 as the default route (within 2x)."""
+def test_mdm_forward_with_either_self_attention_kernel(lib):
+    """The split-f16 self-attention (csrc/attn_h2.h: the default of the split arithmetic since round 5) and the fp32 kernel it replaced (tune[IDF_TUNE_MISC] = 6; also what a
+    clip longer than 192 frames takes) against the oracle in float64 at the bench shape, the longest clip of either kernel, the reference's default clip length and clips shorter
+    than a key tile: the split-f16 kernel is as close to fp64 as the fp32 one (within 2x)."""
     from interdiff_amd import _lib
     from interdiff_amd.mdm import MDM
     sd = fx.mdm_weights()
     sd64 = {k: torch.as_tensor(v).double() for k, v in sd.items()}
     m = MDM(sd, device=DEV)
-    for B, T in ((16, 100), (1, 208), (3, 35), (2, 13), (2, 1)):
+    for B, T in ((16, 100), (1, 208), (1, 192), (2, 129), (3, 35), (2, 13), (2, 1)):
         x, ts, cond = fx.mdm_inputs(B, T)
         ref = oden.mdm_forward(sd64, x.double(), ts, cond.double())
         err = {}
-        for name, misc in (('default', 0), ('split_attention', 5)):
+        for name, misc in (('fp32_attention', 6), ('split_attention', 0)):
             m.w.tune[_lib.TUNE['misc']] = misc
             got = m(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)}).cpu().double()
             err[name] = float((got - ref).abs().max() / ref.abs().max())
         m.w.tune[_lib.TUNE['misc']] = 0
         fx.record_parity('mdm_forward_split_attention_vs_fp64_B%d_T%d' % (B, T), **err)
-        assert err['split_attention'] <= max(2 * err['default'], 2e-6), (B, T, err)
+        assert err['split_attention'] <= max(2 * err['fp32_attention'], 2e-6), (B, T, err)
+        assert err['fp32_attention'] <= 2e-6, (B, T, err)
 
 
 def test_mdm_no_rotary_switch(lib):

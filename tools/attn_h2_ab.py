@@ -1,5 +1,5 @@
 """fp32 vs split-f16 self-attention kernel (csrc/denoiser.hip self_attn_kernel vs csrc/attn_h2.h) under the split arithmetic: denoiser forward and whole
-samples, alternating in one process on one box (not product code).  Output -> profiles/r04_attn_split_f16_ab.txt."""
+samples, alternating in one process on one box (not product code).  Output -> profiles/r04_attn_split_f16_ab.txt (round 4: V transposed through LDS), profiles/r05_attn_split_f16_ab.txt (round 5: transposing reads)."""
 import json
 import os
 import sys
@@ -20,7 +20,7 @@ def main():
     model, corr, bt, y, _ = bench.build_world(dev, 0)
     diff = create_gaussian_diffusion('cosine', bench.STEPS)
     for rep in range(3):
-        for name, misc in (('fp32 attention', 0), ('split-f16 attention', 5)):
+        for name, misc in (('fp32 attention', 6), ('split-f16 attention', 0)):       # (round 5: the split-f16 kernel is the default; 6 selects the fp32 kernel)
             model.w.tune[_lib.TUNE['misc']] = misc
             model.__dict__.pop('_graph_cache', None)
             out = dict(attention=name, forward_us=round(bench.time_forward_graph(model, bt, y, dev), 2))

@@ -93,7 +93,7 @@ def roofline(b):
         out.append('| f16-MFMA kernels that do NOT own their CU | %s of %d |' % (ex.get('kernels_not_exclusive'), len(ex.get('table') or [])))
     ar = b.get('arithmetic_by_layer') or {}
     if ar:
-        out.append('| arithmetic by layer | %s |' % ('every contraction of every layer split-f16 (self-attention exact fp32 by choice)' if ar.get('all_split') else
+        out.append('| arithmetic by layer | %s |' % ('every contraction of every layer split-f16, self-attention included' if ar.get('all_split') else
                                                    '; '.join('L%d %s' % (d['layer'], '/'.join('%s=%s' % (k, v) for k, v in d.items() if k not in ('layer', 'kind'))) for d in ar.get('layers', []))))
     return '\n'.join(out)
 

@@ -7,7 +7,7 @@
 __device__ long long g_rb_stamps[8192 * 16];
 #define IDF_RB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_rb_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ long long g_at_stamps[8192 * 8];
-#define IDF_AT_STAMP(i) do { if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); } while (0)
+#define IDF_AT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_at_stamps[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ long long g_ah2_stamps[8192 * 8];
 #define IDF_AH2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_ah2_stamps[blockIdx.x * 8 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #include "denoiser.hip"
@@ -119,6 +119,9 @@ int main(int argc, char **argv) {
         printf("self-attention (last launch), %d workgroups; mean cycles per phase:\n", nat);
         for (int i = 1; i < 6; ++i) { printf("  %-46s %8.0f\n", an[i], aa[i] / nat); at += aa[i] / nat; }
         printf("  total %.0f\n", at);
+        double b7 = 0, b6 = 0;
+        for (int w = 0; w < nat; ++w) { b7 += (double)(sa[(size_t)w * 8 + 7] - sa[(size_t)w * 8 + 4]); b6 += (double)(sa[(size_t)w * 8 + 6] - sa[(size_t)w * 8 + 4]); }
+        printf("  inside the last phase: context tile in LDS + barrier %.0f, out-projection MFMAs issued %.0f, then the 16 partial-slab stores per lane\n", b7 / nat, b6 / nat);
     }
     if (h2 == 2) {
         const int nw = ((T + 31) / 32) * 4 * B;

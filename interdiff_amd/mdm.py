@@ -589,7 +589,8 @@ class MDM:
         of 32 rows x 5 slices = 255 workgroups, ONE round on 256 CUs -- the kernel owns its CUs (csrc/ffn_h2.h "exclusive CU"), so a second chain can
         no longer slip its small kernels beside it, and up to one round a single chain is ahead (same process, whole samples with correction,
         tools/chains_ab.py: 12 clips 0.2171 vs 0.2252, 16 clips 0.2300 vs 0.2372 ms per step; beyond one round two chains win big: 17 clips 0.2455 vs
-        0.3135, 20: 0.2545 vs 0.3310, 24: 0.2875 vs 0.3412, 32: 0.3362 vs 0.3495)."""
+        0.3135, 20: 0.2545 vs 0.3310, 24: 0.2875 vs 0.3412, 32: 0.3362 vs 0.3495; re-measured on round 5's final build, where the row block and the
+        self-attention own their CUs too: 24 clips 0.290 vs 0.321, 32 clips 0.318 vs 0.323 -- two chains still ahead beyond one round)."""
         if self.ffn_math != 'split':
             return self.FFN16_MAX_ROWS
         if getattr(self, '_n_cu', None) is None:      # one round of 32-row x 5-slice workgroups on THIS device's CUs (256 on MI355X: 1632 rows)

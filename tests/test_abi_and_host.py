@@ -587,3 +587,32 @@ def test_documents_quote_the_measurement_files():
     for doc in ('DESIGN.md', 'BASELINE.md', 'README.md'):
         txt = open(os.path.join(ROOT, doc)).read()
         assert txt.count('<!-- BEGIN GENERATED') == txt.count('<!-- END GENERATED') >= 2, doc
+
+
+def test_transposing_lds_read_address_map_of_the_attention_kernel():
+    """csrc/attn_h2.h reads the P.V operand out of ROW-MAJOR V planes with gfx950's ds_read_b64_tr_b16.  What the instruction returns was measured
+    (tools/tr_read_probe.hip): inside a 16-lane group, lane c names four contiguous halves (its "chunk"), and lane i receives element i & 3 of the chunks
+    (i >> 2) + 4 j, j = 0..3.  This test restates that mapping in numpy and checks that the kernel's address formula -- lane (li, kq) of K step s and head-dim tile dt
+    names the chunk at key 32 s + 8 kq + 4 h + (li >> 2), dims 16 dt + 4 (li & 3) ..+3, h = 0, 1 -- hands every lane the MFMA B fragment it must hold:
+    V[32 s + 8 kq + 0..7][16 dt + li]."""
+    VRS, T = 72, 128
+    rng = np.random.RandomState(0)
+    V = rng.randint(0, 1 << 15, size=(T, 64)).astype(np.int64)
+    lds = np.zeros(T * VRS, np.int64)
+    for k in range(T):
+        lds[k * VRS:k * VRS + 64] = V[k]
+
+    def tr_read(addr):                      # addr[16]: element index each lane of the group names -> out[16][4]
+        chunks = np.stack([lds[a:a + 4] for a in addr])                  # [lane c][4 halves]
+        return np.array([[chunks[(i >> 2) + 4 * j][i & 3] for j in range(4)] for i in range(16)])
+    for s in range(T // 32):
+        for dt in range(4):
+            for kq in range(4):
+                ko = 32 * s + 8 * kq
+                frag = np.zeros((16, 8), np.int64)
+                for h in range(2):
+                    addr = [(ko + 4 * h + (li >> 2)) * VRS + dt * 16 + 4 * (li & 3) for li in range(16)]
+                    assert all(a % 4 == 0 for a in addr)                 # 8-byte aligned: a misaligned transposing read returns the aligned address's data
+                    frag[:, 4 * h:4 * h + 4] = tr_read(addr)
+                want = np.stack([V[ko:ko + 8, dt * 16 + li] for li in range(16)])
+                assert np.array_equal(frag, want), (s, dt, kq)

@@ -144,6 +144,10 @@ typedef struct {
                                   its three contractions as split-f16 products; 0 = always exact fp32 */
     int64_t sa_out_frag_h2;    /* std only: 0, or sa_out_w as two f16 planes in the split-f16 attention kernel's fragment order [head][16 output column tiles][2 K steps][2 planes]
                                   [64 lanes][8 halves] (mdm.py sa_out_fragments_h2; csrc/attn_h2.h) */
+    int64_t qkv_bounds_ok;     /* std only: 1 when eight floats stand right behind the sa_in_pack_h2 stream (arena offset sa_in_pack_h2 + 5 x 40960): max over the q, k, v rows
+                                  of sa_in_w of their L1 norm (x 1.001), max |sa_in_b| of the q, k, v rows, two spare (mdm.py qkv_bounds).  With them the QKV kernel may write
+                                  its output as the self-attention's f16 plane pairs -- |q_c| <= 2^e_row ||W_c||_1 + |b_c| is the per-row power of two it divides by --
+                                  instead of fp32 rows (csrc/ffn_h2.h ln_linear_h2_kernel<.., PLANES>); 0: fp32 rows, the attention splits them itself */
 } idf_mdm_layer;
 
 typedef struct {

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('INTERDIFF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')      # (the override: A/B builds of the SAME library under build_ab/, tools/ only)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -31,7 +31,7 @@ class MdmLayer(C.Structure):
                 ('ca_q_w', i64), ('ca_q_b', i64), ('ca_kv_w', i64), ('ca_kv_b', i64),
                 ('ca_out_w', i64), ('ca_out_b', i64),
                 ('ff1_w', i64), ('ff1_b', i64), ('ff2_w', i64), ('ff2_b', i64), ('ffn_pack', i64), ('ffn_b1p', i64), ('sa_in_pack', i64), ('sa_out_frag', i64),
-                ('ln_w', i64 * 3), ('ln_b', i64 * 3), ('ffn_pack_h2', i64), ('sa_in_pack_h2', i64), ('qc_h2', i64), ('rb_h2_ok', i64), ('sa_out_frag_h2', i64)]
+                ('ln_w', i64 * 3), ('ln_b', i64 * 3), ('ffn_pack_h2', i64), ('sa_in_pack_h2', i64), ('qc_h2', i64), ('rb_h2_ok', i64), ('sa_out_frag_h2', i64), ('qkv_bounds_ok', i64)]
 
 
 class MdmWeights(C.Structure):

@@ -68,12 +68,17 @@ __device__ __forceinline__ float pow2_scale(float amax, float &up) {
     return __builtin_bit_cast(float, (uint32_t)((127 - e) << 23));
 }
 
-template <int PLACED = 0>      // (a template only so that denoiser.hip can instantiate it explicitly, next to the other kernels of a step: code placement)
+// PLANES_IN: `qkv` holds the plane pairs the QKV kernel wrote (ffn_h2.h ln_linear_h2_kernel<.., PLANES>: per token row and (q / k / v, head) group [hi 64 halves | lo' 64 halves])
+// and `scales` [N][4] the power of two each row's q / k / v were divided by -- nothing is split here, the planes go from memory to LDS as they are; S is multiplied back per
+// (query row, key), a probability takes its key's V scale relative to the largest of the clip (<= 1) before it is split, the largest scales the output.  Otherwise `qkv` is the fp32
+// [N][768] matrix and the kernel splits Q, K, V itself under one power of two per tile (the route of a QKV projection that ran as fp32).
+template <int PLACED = 0, bool PLANES_IN = false>      // (PLACED: a template so that denoiser.hip can instantiate the kernel explicitly, next to the other kernels of a step: code placement)
 __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restrict__ qkv, int T, int nwg, const float *__restrict__ wo_h2,
-                                                           float *__restrict__ slabs, size_t pstride) {
+                                                           float *__restrict__ slabs, size_t pstride, const float *__restrict__ scales) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     asm volatile("" ::: "v255");                         // exclusive CU: 2 waves per SIMD x 256 registers (+ the launcher's 160 KiB of LDS)
     __shared__ float red[3][NWV];
+    __shared__ float sqs[PLANES_IN ? QT : 1], sks[PLANES_IN ? MAX_T : 1], svs[PLANES_IN ? MAX_T + 32 : 1];      // 2^e of the query rows / keys (K, V) of this (clip, head)
     // (all ten argument dwords, the grid size among them, arrive preloaded in SGPRs: build.py)
     const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31, VTS = TPP + 8, SS = TP + 4;
     _Float16 *kh = reinterpret_cast<_Float16 *>(smraw), *kl = kh + TP * KHS;                 // K planes [TP][KHS]
@@ -88,29 +93,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
     const size_t rowbase = (size_t)b * T;
 
     IDF_AH2_STAMP(0);
-    // ---- operand fetch: everything requested at once with clamped addresses (no guard around a load)
-    const int qr = tid >> 4, c4 = (tid & 15) * 4;        // thread (row, 4-float chunk) of a [rows][64] tile
-    const float4 qv = *reinterpret_cast<const float4 *>(qkv + (rowbase + min(q0 + qr, T - 1)) * (3 * D) + h * HD + c4);
-    float4 kreg[NIT], vreg[NIT];
-#pragma unroll
-    for (int u = 0; u < NIT0; ++u) {
-        const int j = min(qr + 32 * u, T - 1);
-        const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
-        kreg[u] = *reinterpret_cast<const float4 *>(src + D);
-        vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
-    }
-    if (TP > 32 * NIT0) {                                // (clips longer than 128 frames; at T = 100 these sweeps were three more rounds of clamped -- repeated -- requests)
-#pragma unroll
-        for (int u = NIT0; u < NIT; ++u) {
-            const int j = min(qr + 32 * u, T - 1);
-            const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
-            kreg[u] = *reinterpret_cast<const float4 *>(src + D);
-            vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
-        }
-    } else {
-#pragma unroll
-        for (int u = NIT0; u < NIT; ++u) kreg[u] = vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    float uq = 1.f, uk = 1.f, uv = 1.f;                  // (tile scales of the fp32-input route)
     float4 wo[2][2][2];                                  // out-projection fragments of this wave's two column tiles: [tile][K step][plane]
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -120,46 +103,115 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
             for (int p = 0; p < 2; ++p)
                 wo[c][s][p] = *reinterpret_cast<const float4 *>(wo_h2 + (size_t)(((((h * 16 + 2 * wave + c) * 2 + s) * 2 + p) * 64) + lane) * 4);
 
-    // ---- the three tile scales
-    auto amax4 = [](const float4 v) { return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))); };
-    float aq = q0 + qr < T ? amax4(qv) : 0.f, ak = 0.f, av = 0.f;
-#pragma unroll
-    for (int u = 0; u < NIT; ++u)
-        if (qr + 32 * u < T) {
-            ak = fmaxf(ak, amax4(kreg[u]));
-            av = fmaxf(av, amax4(vreg[u]));
-        }
-    IDF_AH2_STAMP(1);                                    // operands landed (the amax code above consumed them)
-    aq = wave_max(aq); ak = wave_max(ak); av = wave_max(av);
-    if (lane == 0) { red[0][wave] = aq; red[1][wave] = ak; red[2][wave] = av; }
-    __syncthreads();
-    aq = ak = av = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) { aq = fmaxf(aq, red[0][w]); ak = fmaxf(ak, red[1][w]); av = fmaxf(av, red[2][w]); }
-    float uq, uk, uv;
-    const float dq = pow2_scale(aq, uq), dk = pow2_scale(ak, uk), dv = pow2_scale(av, uv);
-
-    // ---- planes: Q, K and V row-major [row][dim], each thread splits the chunks it fetched -- no staging, no transposition: the P V contraction reads its V operand
-    // with gfx950's transposing LDS read (ds_read_b64_tr_b16, below).  (A first version staged V as fp32, transposed it with eight strided scalar reads per octet of
-    // keys and needed two more barriers: 6.7 k of the launch's 17.4 k cycles went into this phase, tools/rowblock_probe.hip.)
-    {
+    if constexpr (PLANES_IN) {
+        // ---- planes from memory to LDS: thread (row qr of a 32-row sweep, 16-byte chunk c of the row's 256 bytes: c < 8 the hi plane, else the lo' plane)
+        const int qr = tid >> 4, c = tid & 15;
+        const size_t coff = (size_t)c * 4;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 hi, lo;
-        idf_ffn_h2::split4_pk(q0 + qr < T ? make_float4(qv.x * dq, qv.y * dq, qv.z * dq, qv.w * dq) : z, hi, lo);
-        *reinterpret_cast<uint2 *>(qh + qr * KHS + c4) = hi;
-        *reinterpret_cast<uint2 *>(ql + qr * KHS + c4) = lo;
+        const float4 qv = *reinterpret_cast<const float4 *>(qkv + ((rowbase + min(q0 + qr, T - 1)) * 12 + h) * 64 + coff);
+        float4 kreg[NIT], vreg[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT0; ++u) {
+            const size_t rw = (rowbase + min(qr + 32 * u, T - 1)) * 12;
+            kreg[u] = *reinterpret_cast<const float4 *>(qkv + (rw + 4 + h) * 64 + coff);
+            vreg[u] = *reinterpret_cast<const float4 *>(qkv + (rw + 8 + h) * 64 + coff);
+        }
+        if (TP > 32 * NIT0) {
+#pragma unroll
+            for (int u = NIT0; u < NIT; ++u) {
+                const size_t rw = (rowbase + min(qr + 32 * u, T - 1)) * 12;
+                kreg[u] = *reinterpret_cast<const float4 *>(qkv + (rw + 4 + h) * 64 + coff);
+                vreg[u] = *reinterpret_cast<const float4 *>(qkv + (rw + 8 + h) * 64 + coff);
+            }
+        } else {
+#pragma unroll
+            for (int u = NIT0; u < NIT; ++u) kreg[u] = vreg[u] = z;
+        }
+        float4 sc4 = z;
+        if (tid < TPP) sc4 = *reinterpret_cast<const float4 *>(scales + (rowbase + min(tid, T - 1)) * 4);
+        const float sq1 = tid < QT ? scales[(rowbase + min(q0 + tid, T - 1)) * 4] : 0.f;
+        IDF_AH2_STAMP(1);
+        // (component-wise selects and integer plane offsets: a `cond ? float4 : float4` or a `cond ? ptr : ptr` here made the compiler park both candidates in scratch
+        // memory and index them -- 32 scratch instructions and 7 us per launch)
+        auto keep = [](bool on, const float4 v) { return make_float4(on ? v.x : 0.f, on ? v.y : 0.f, on ? v.z : 0.f, on ? v.w : 0.f); };
+        const int po = (c & 7) * 8;                      // halves into the row of either plane
+        const bool lo = c >= 8;
+        *reinterpret_cast<float4 *>(qh + (lo ? QT * KHS : 0) + qr * KHS + po) = keep(q0 + qr < T, qv);
+        const int kplane = lo ? TP * KHS : 0, vplane = lo ? TPP * VRS : 0;
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             const int j = qr + 32 * u;
             if (32 * u < TPP && j < TPP) {               // (first condition workgroup-uniform)
-                if (j < TP) {
-                    idf_ffn_h2::split4_pk(j < T ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
-                    *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
-                    *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
+                if (j < TP) *reinterpret_cast<float4 *>(kh + kplane + j * KHS + po) = keep(j < T, kreg[u]);
+                *reinterpret_cast<float4 *>(vh + vplane + j * VRS + po) = keep(j < T, vreg[u]);      // keys T .. TPP - 1: zero rows (they meet zero probabilities)
+            }
+        }
+        if (tid < TPP) { sks[tid] = tid < T ? sc4.y : 1.f; svs[tid] = tid < T ? sc4.z : 0.f; }
+        if (tid < QT) sqs[tid] = sq1;
+    } else {
+        // ---- operand fetch: everything requested at once with clamped addresses (no guard around a load)
+        const int qr = tid >> 4, c4 = (tid & 15) * 4;        // thread (row, 4-float chunk) of a [rows][64] tile
+        const float4 qv = *reinterpret_cast<const float4 *>(qkv + (rowbase + min(q0 + qr, T - 1)) * (3 * D) + h * HD + c4);
+        float4 kreg[NIT], vreg[NIT];
+    #pragma unroll
+        for (int u = 0; u < NIT0; ++u) {
+            const int j = min(qr + 32 * u, T - 1);
+            const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
+            kreg[u] = *reinterpret_cast<const float4 *>(src + D);
+            vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
+        }
+        if (TP > 32 * NIT0) {                                // (clips longer than 128 frames; at T = 100 these sweeps were three more rounds of clamped -- repeated -- requests)
+    #pragma unroll
+            for (int u = NIT0; u < NIT; ++u) {
+                const int j = min(qr + 32 * u, T - 1);
+                const float *src = qkv + (rowbase + j) * (3 * D) + h * HD + c4;
+                kreg[u] = *reinterpret_cast<const float4 *>(src + D);
+                vreg[u] = *reinterpret_cast<const float4 *>(src + 2 * D);
+            }
+        } else {
+    #pragma unroll
+            for (int u = NIT0; u < NIT; ++u) kreg[u] = vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // ---- the three tile scales
+        auto amax4 = [](const float4 v) { return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))); };
+        float aq = q0 + qr < T ? amax4(qv) : 0.f, ak = 0.f, av = 0.f;
+    #pragma unroll
+        for (int u = 0; u < NIT; ++u)
+            if (qr + 32 * u < T) {
+                ak = fmaxf(ak, amax4(kreg[u]));
+                av = fmaxf(av, amax4(vreg[u]));
+            }
+        IDF_AH2_STAMP(1);                                    // operands landed (the amax code above consumed them)
+        aq = wave_max(aq); ak = wave_max(ak); av = wave_max(av);
+        if (lane == 0) { red[0][wave] = aq; red[1][wave] = ak; red[2][wave] = av; }
+        __syncthreads();
+        aq = ak = av = 0.f;
+    #pragma unroll
+        for (int w = 0; w < NWV; ++w) { aq = fmaxf(aq, red[0][w]); ak = fmaxf(ak, red[1][w]); av = fmaxf(av, red[2][w]); }
+        const float dq = pow2_scale(aq, uq), dk = pow2_scale(ak, uk), dv = pow2_scale(av, uv);
+
+        // ---- planes: Q, K and V row-major [row][dim], each thread splits the chunks it fetched -- no staging, no transposition: the P V contraction reads its V operand
+        // with gfx950's transposing LDS read (ds_read_b64_tr_b16, below).  (A first version staged V as fp32, transposed it with eight strided scalar reads per octet of
+        // keys and needed two more barriers: 6.7 k of the launch's 17.4 k cycles went into this phase, tools/rowblock_probe.hip.)
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            idf_ffn_h2::split4_pk(q0 + qr < T ? make_float4(qv.x * dq, qv.y * dq, qv.z * dq, qv.w * dq) : z, hi, lo);
+            *reinterpret_cast<uint2 *>(qh + qr * KHS + c4) = hi;
+            *reinterpret_cast<uint2 *>(ql + qr * KHS + c4) = lo;
+    #pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int j = qr + 32 * u;
+                if (32 * u < TPP && j < TPP) {               // (first condition workgroup-uniform)
+                    if (j < TP) {
+                        idf_ffn_h2::split4_pk(j < T ? make_float4(kreg[u].x * dk, kreg[u].y * dk, kreg[u].z * dk, kreg[u].w * dk) : z, hi, lo);
+                        *reinterpret_cast<uint2 *>(kh + j * KHS + c4) = hi;
+                        *reinterpret_cast<uint2 *>(kl + j * KHS + c4) = lo;
+                    }
+                    idf_ffn_h2::split4_pk(j < T ? make_float4(vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv) : z, hi, lo);      // keys T .. TPP - 1: zero rows (they meet zero probabilities)
+                    *reinterpret_cast<uint2 *>(vh + j * VRS + c4) = hi;
+                    *reinterpret_cast<uint2 *>(vl + j * VRS + c4) = lo;
                 }
-                idf_ffn_h2::split4_pk(j < T ? make_float4(vreg[u].x * dv, vreg[u].y * dv, vreg[u].z * dv, vreg[u].w * dv) : z, hi, lo);      // keys T .. TPP - 1: zero rows (they meet zero probabilities)
-                *reinterpret_cast<uint2 *>(vh + j * VRS + c4) = hi;
-                *reinterpret_cast<uint2 *>(vl + j * VRS + c4) = lo;
             }
         }
     }
@@ -187,7 +239,10 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = (am[rt][r] + ac[rt][r] * idf_ffn_h2::LO_UNSCALE) * sscale;
+            for (int r = 0; r < 4; ++r) {
+                const float sc = PLANES_IN ? sqs[rt * 16 + kq * 4 + r] * (sks[ct * 16 + li] * 0.125f) : sscale;
+                Ss[(rt * 16 + kq * 4 + r) * SS + ct * 16 + li] = (am[rt][r] + ac[rt][r] * idf_ffn_h2::LO_UNSCALE) * sc;
+            }
     }
     __syncthreads();
     IDF_AH2_STAMP(3);                                    // S
@@ -201,12 +256,14 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
         const float *srow = Ss + row * SS;
         const bool tail = TP > 16 * NC0;
         float v[NC], mx = -FLT_MAX;
+        float svl[PLANES_IN ? NC : 1], svm = 0.f;        // PLANES_IN: 2^e of the V rows of this lane's columns (0 past the clip), and their maximum
 #pragma unroll
         for (int c = 0; c < NC0; ++c) {
             const int j = 16 * c + li;
             v[c] = srow[min(j, TP - 1)];
             v[c] = j < T ? v[c] : -FLT_MAX;
             mx = fmaxf(mx, v[c]);
+            if constexpr (PLANES_IN) { svl[c] = svs[min(j, TPP - 1)]; svm = fmaxf(svm, svl[c]); }
         }
         if (tail) {
 #pragma unroll
@@ -215,6 +272,7 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
                 v[c] = srow[min(j, TP - 1)];
                 v[c] = j < T ? v[c] : -FLT_MAX;
                 mx = fmaxf(mx, v[c]);
+                if constexpr (PLANES_IN) { svl[c] = svs[min(j, TPP - 1)]; svm = fmaxf(svm, svl[c]); }
             }
         }
         mx = row16_max(mx);
@@ -232,9 +290,15 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
             }
         }
         const float inv = __builtin_amdgcn_rcpf(row16_sum(sum));
+        float rsvm = 1.f;
+        if constexpr (PLANES_IN) {                       // a probability carries its key's V scale relative to the clip's largest (powers of two: exact, <= 1)
+            svm = row16_max(svm);
+            rsvm = __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(uint32_t, svm));
+            if (tid == 0) red[0][0] = svm;               // (every row of every workgroup of the (clip, head) finds the same maximum)
+        }
         auto put = [&](int c) {                          // columns T .. TPP - 1 are written as zeros: they are part of the last K step
             _Float16 a, cc;
-            idf_ffn_h2::split1_nf(v[c] * inv, a, cc);
+            idf_ffn_h2::split1_nf(PLANES_IN ? v[c] * inv * (svl[c] * rsvm) : v[c] * inv, a, cc);
             ph[row * VTS + 16 * c + li] = a;
             pl[row * VTS + 16 * c + li] = cc;
         };
@@ -308,19 +372,26 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
                 if (t < T) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
-                        idf_store4_wt(slab + (rowbase + t) * D + (2 * wave + c) * 16 + li, (om[rt][c][r] + oc[rt][c][r] * idf_ffn_h2::LO_UNSCALE) * uv);
+                        idf_store4_wt(slab + (rowbase + t) * D + (2 * wave + c) * 16 + li, (om[rt][c][r] + oc[rt][c][r] * idf_ffn_h2::LO_UNSCALE) * (PLANES_IN ? red[0][0] : uv));
                 }
             }
     }
     IDF_AH2_STAMP(6);                                    // out-projection + stores issued
 }
 
-inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride) {
-    static idf_excl_cache excl;
-    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel<0>), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
+// qkv: fp32 [N][768], scales null -- or the QKV kernel's plane pairs with their per-row scales [N][4] (see the kernel).  qkv null: availability query (the launch-time check of the
+// kernel that WOULD run, nothing launched): the caller decides the QKV projection's output form before it launches that.
+inline int launch_self_attn_h2(hipStream_t s, const float *qkv, int B, int T, const float *wo_h2, float *slabs, size_t pstride, const float *scales = nullptr, bool planes = false) {
+    static idf_excl_cache excl, excl_p;
+    const bool pl = planes || scales != nullptr;
+    const int dyn = pl ? idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel<0, true>), "self_attn_h2_kernel<planes in>", NTH, excl_p)
+                       : idf_exclusive_cu(reinterpret_cast<const void *>(&self_attn_h2_kernel<0, false>), "self_attn_h2_kernel", NTH, excl);      // the whole CU's LDS minus the kernel's static words (exclusive CU)
     if (dyn < 0) return IDF_NOT_EXCLUSIVE;
     if (T > MAX_T || (int)lds_bytes(T) > dyn) return IDF_E_INVAL;
-    hipLaunchKernelGGL(self_attn_h2_kernel<0>, dim3((unsigned)(idf_cdiv(T, QT) * H * B)), dim3(NTH), (size_t)dyn, s, qkv, T, (int)(idf_cdiv(T, QT) * H * B), wo_h2, slabs, pstride);
+    if (!qkv) return IDF_OK;
+    const int nwg = (int)(idf_cdiv(T, QT) * H * B);
+    if (pl) hipLaunchKernelGGL((self_attn_h2_kernel<0, true>), dim3((unsigned)nwg), dim3(NTH), (size_t)dyn, s, qkv, T, nwg, wo_h2, slabs, pstride, scales);
+    else hipLaunchKernelGGL((self_attn_h2_kernel<0, false>), dim3((unsigned)nwg), dim3(NTH), (size_t)dyn, s, qkv, T, nwg, wo_h2, slabs, pstride, (const float *)nullptr);
     return IDF_OK;
 }
 

@@ -1605,8 +1605,16 @@ void run_heads_post(int cfg, hipStream_t s, const Args &g, int np) {
 // QKV projection: the LayerNorm+linear kernel of ffn.h (tune 0) or, for A/B runs, one of the generic GEMM configurations
 // step_state != null (layer 0 of interdiff_mdm_forward_step): one thread of the launch does the step's sampler bookkeeping (philox.h)
 // pack_h2 != null: the split-f16 form (ffn_h2.h ln_linear_h2_kernel: tune[IDF_TUNE_FFN_MATH] == 1 and the layer's sa_in_pack_h2 is set)
+// planes / scales != null (with pack_h2): the output leaves as the self-attention's f16 plane pairs + per-row scales instead of fp32 rows (ffn_h2.h ln_linear_h2_kernel<.., PLANES>);
+// the caller has checked (qkv_planes_ok) that this kernel and the attention kernel that reads the planes both run here -- there is no fp32 fallback behind a planes launch
 int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, int64_t *step_state = nullptr, int64_t *step_ts = nullptr,
-            int step_B = 0, const float *pack_h2 = nullptr) {
+            int step_B = 0, const float *pack_h2 = nullptr, float *planes = nullptr, float *scales = nullptr) {
+    if (planes) {
+        if (!pack_h2) return IDF_E_INVAL;
+        const int rc = np == NSL ? idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B, planes, scales)
+                                 : idf_ffn_h2::launch_ln_linear_h2<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B, planes, scales);
+        return rc == IDF_NOT_EXCLUSIVE ? IDF_E_LAUNCH : rc;
+    }
     if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return IDF_OK; }
     if (pack_h2) {
         const int rc = np == NSL ? idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B)
@@ -1621,6 +1629,14 @@ int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, 
 }
 
 
+// May the QKV projection of a standard layer hand the self-attention PLANES (np = slabs of its input, T = clip length)?  Both kernels of the pair must get their CUs here.
+bool qkv_planes_ok(int np, int B, int T) {
+    float dummy = 0.f;
+    const int rq = np == NSL ? idf_ffn_h2::launch_ln_linear_h2<NSL>(nullptr, nullptr, 0, nullptr, nullptr, 0, 3 * D, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, &dummy, &dummy)
+                             : idf_ffn_h2::launch_ln_linear_h2<1>(nullptr, nullptr, 0, nullptr, nullptr, 0, 3 * D, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, &dummy, &dummy);
+    return rq == IDF_OK && idf_attn_h2::launch_self_attn_h2(nullptr, nullptr, B, T, nullptr, nullptr, 0, nullptr, true) == IDF_OK;
+}
+
 // ---- The seven kernels of a plain denoising step at the shipped shapes, instantiated HERE, next to each other (two inside this namespace, five right behind it).  Explicit
 // instantiations are emitted where they stand, so the seven end up CONTIGUOUS in the code object (57 KB); implicit ones land wherever the compiler gets to them -- scattered over
 // this file's 1.1 MB of code, where 16-39 % of their cache lines shared an instruction-cache set with more lines than it has ways (64 KB per CU pair; a step cycles through all
@@ -1633,12 +1649,12 @@ template __global__ void rowblock8_kernel<true, NSL, MEM, 8>(const float *, int,
                                                              const float *, const float *, const float *, const float *, const float *, const float *, const float *, float *, const float *,
                                                              const float *);
 }  // namespace
-template __global__ void idf_attn_h2::self_attn_h2_kernel<0>(const float *, int, int, const float *, float *, size_t);
+template __global__ void idf_attn_h2::self_attn_h2_kernel<0, true>(const float *, int, int, const float *, float *, size_t, const float *);
 template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0>(const float *, int, int, const float *, const float *, const float *, float *, int);
-template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
-                                                            int64_t *, int64_t *);
-template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int,
-                                                                         float *, int64_t *, int64_t *);
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
+                                                                  int64_t *, int64_t *, float *, float *);
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int,
+                                                                               int, float *, int64_t *, int64_t *, float *, float *);
 template __global__ void idf_tail_h2::step_tail_h2_kernel<3, false>(const float *, size_t, const float *, int, int, int, int, const idf_tail_h2::TailArgs);
 
 extern "C" int interdiff_mdm_ffn(const idf_mdm_weights *w, int32_t layer, int32_t encoder, const float *x2, int32_t M, float *parts,
@@ -1950,9 +1966,13 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
             g.C = k.qkv; g.ldc = 3 * D; g.M = N; g.N = 3 * D; g.xn_out = k.xn; g.T = T; g.a_pstride = pstride;
             idf_prof_mark(IDF_K_GEMM_QKV, s);
             const float *qkv_h2 = (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_in_pack_h2) ? ar + ly.sa_in_pack_h2 : nullptr;
+            // Round 5: when the split-f16 self-attention follows, the projection writes the attention's f16 plane pairs (+ per-row scales, in the unused context buffer) instead of
+            // fp32 rows -- the four query tiles of a (clip, head) then fetch planes instead of each splitting K and V again.  tune[IDF_TUNE_MISC] == 9 keeps fp32 rows (A/B).
+            const bool attn_h2 = tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] != 6 && T <= idf_attn_h2::MAX_T && tune[IDF_TUNE_GEMM_OUTPROJ] == 0;
+            const bool planes = attn_h2 && qkv_h2 && ly.qkv_bounds_ok != 0 && tune[IDF_TUNE_MISC] != 9 && (tune[IDF_TUNE_GEMM_QKV] == 0 || (post.x && l == 0)) && qkv_planes_ok(u_np, B, T);
             int rcq;
-            if (post.x && l == 0) rcq = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B, qkv_h2);
-            else rcq = run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0, qkv_h2);
+            if (post.x && l == 0) rcq = run_qkv(0, s, g, ar + ly.sa_in_pack, u_np, post.state, post.ts, B, qkv_h2, planes ? k.qkv : nullptr, planes ? k.ctx : nullptr);
+            else rcq = run_qkv(tune[IDF_TUNE_GEMM_QKV], s, g, ar + ly.sa_in_pack, u_np, nullptr, nullptr, 0, qkv_h2, planes ? k.qkv : nullptr, planes ? k.ctx : nullptr);
             if (rcq != IDF_OK) return rcq;
             idf_prof_mark(IDF_K_SELF_ATTN, s);
             if (tune[IDF_TUNE_GEMM_OUTPROJ] == 0) {
@@ -1962,9 +1982,9 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                 // the split-f16 form (attn_h2.h: 32 queries per workgroup, one workgroup per CU) is the default since round 5 (row-major V planes read with the transposing LDS read:
                 // -1.2 % per step against the fp32 kernel, profiles/r05_attn_split_f16_ab.txt); tune[IDF_TUNE_MISC] == 6 keeps the fp32 kernel for A/B; clips longer than its LDS
                 // budget (T > 192), the exact arithmetic and a device where it does not get its CU take the fp32 kernel
-                if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.sa_out_frag_h2 != 0 && tune[IDF_TUNE_MISC] != 6 && T <= idf_attn_h2::MAX_T) {
-                    rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride);
-                    if (rc_ah2 != IDF_OK && rc_ah2 != IDF_NOT_EXCLUSIVE) return rc_ah2;
+                if (attn_h2) {
+                    rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride, planes ? k.ctx : nullptr);
+                    if (rc_ah2 != IDF_OK && (rc_ah2 != IDF_NOT_EXCLUSIVE || planes)) return rc_ah2 == IDF_NOT_EXCLUSIVE ? IDF_E_LAUNCH : rc_ah2;
                 }
                 if (rc_ah2 == IDF_NOT_EXCLUSIVE) launch_self_attn_outproj(s, k.qkv, B, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
@@ -2093,10 +2113,12 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<1, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<16 rows>", NT, c[0]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<32 rows>", NT, c[1]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<4, 2, 0>), "ffn_h2_kernel<64 rows>", NT, c[2]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel<0>), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1, false>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES, false>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel<0, false>), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
     }
+    qkv_planes_ok(1, 1, 16);
+    qkv_planes_ok(NSL, 1, 16);
     rb_h2_qan_dyn<MEM>();
     rb_h2_std_dyn<MEM>();
     rb_h2_qan_dyn<MEMX>();

@@ -504,12 +504,17 @@ constexpr int QSTEP = QCT * 2 * 1024;                    // bytes of a K step: 2
 constexpr int QSLICE_FLOATS = 8 * QSTEP / 4;             // 40960 floats per 160-column slice
 constexpr int QBM = 32;
 
-template <int NP>
+// PLANES (the QKV projection in front of the split-f16 self-attention, attn_h2.h): the output leaves as the f16 plane pair the attention contracts -- per token row and 64-column
+// group (q / k / v x head) [hi 64 halves | lo' 64 halves] at planes_out + (row * 12 + group) * 128 halves -- instead of fp32 rows, so that the four query tiles of a (clip, head)
+// fetch planes instead of each splitting K and V again.  The power of two a row is divided by needs no look at the OUTPUT: the kernel already divides every INPUT row by its own
+// 2^e (Sc[row]; |x'| < 1), so |v_c| <= 2^e ||W_c||_1 + |b_c| -- a bound every slice of the launch computes identically from three static L1 norms and three bias maxima per layer
+// (the six floats behind the packed stream: mdm.py qkv_bounds).  scales_out[row][4] = the three 2^(E - 15) the attention multiplies back (q, k, v; written by slice 0).
+template <int NP, bool PLANES = false>
 __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, int M, int nwg, const float *__restrict__ pack,
                                                            const float *__restrict__ lnw, const float *__restrict__ lnb, int nsl_grid, int step_B,
                                                            const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
                                                            float *__restrict__ xn_out, int64_t *__restrict__ step_state,
-                                                           int64_t *__restrict__ step_ts) {
+                                                           int64_t *__restrict__ step_ts, float *__restrict__ planes_out, float *__restrict__ scales_out) {
     // (argument order: the first 14 dwords -- what the weight stream and the row requests need -- arrive preloaded in SGPRs: build.py)
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     asm volatile("" ::: "v255");                       // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
@@ -536,6 +541,12 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
     };
     issue_step(0);
     issue_step(1);
+    float bnd6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // PLANES: {||W||_1 max of the q, k, v rows; max |b| of q, k, v}, behind the stream; requested now, used in the epilogue
+    if constexpr (PLANES) {
+        const float *bnd = pack + (size_t)nsl_grid * QSLICE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bnd6[i] = bnd[i];
+    }
     {   // rows: slab sum, LayerNorm (null lnw: layer 0 takes the embedding as it is), residual copy, row scale, split into the plane image
         const float4 gw = lnw ? *reinterpret_cast<const float4 *>(lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 gb = lnw ? *reinterpret_cast<const float4 *>(lnb + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -659,23 +670,60 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
         }
     }
     __syncthreads();
+    if constexpr (PLANES) {
+        const float wq = bnd6[0], wk = bnd6[1], wv = bnd6[2], bq = bnd6[3], bk = bnd6[4], bvv = bnd6[5];
+        auto down = [](float bound, float &up) {                         // bound < 2^E: multiplier 2^(15 - E) (|v| 2^(15 - E) < 2^15) and, through `up`, 2^(E - 15)
+            const int E = (int)((__builtin_bit_cast(uint32_t, fmaxf(bound, 1e-30f)) >> 23) & 0xff) - 126;
+            up = __builtin_bit_cast(float, (uint32_t)((127 + E - 15) << 23));
+            return __builtin_bit_cast(float, (uint32_t)((127 + 15 - E) << 23));
+        };
 #pragma unroll
-    for (int it = 0; it < (QBM * (QHS / 4) + NT - 1) / NT; ++it) {
-        const int idx = tid + it * NT, row = idx / (QHS / 4), c4 = (idx - row * (QHS / 4)) << 2, gr = m0 + row;
-        if (idx < QBM * (QHS / 4) && gr < M && n0 + c4 < N) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, *reinterpret_cast<const float4 *>(Cs + row * QCS + c4));
+        for (int it = 0; it < (QBM * (QHS / 8) + NT - 1) / NT; ++it) {
+            const int idx = tid + it * NT, row = idx / (QHS / 8), c8 = (idx - row * (QHS / 8)) << 3, gr = m0 + row, gc = n0 + c8;
+            if (idx < QBM * (QHS / 8) && gr < M && gc < N) {
+                const int t = gc >> 8, grp = gc >> 6, o = gc & 63;
+                const float e2 = Sc[row];
+                float uq, uk, uv;
+                const float dq = down(e2 * wq + bq, uq), dk = down(e2 * wk + bk, uk), dv = down(e2 * wv + bvv, uv);
+                const float dn = t == 0 ? dq : (t == 1 ? dk : dv);
+                const float4 v0 = *reinterpret_cast<const float4 *>(Cs + row * QCS + c8), v1 = *reinterpret_cast<const float4 *>(Cs + row * QCS + c8 + 4);
+                uint2 h0, l0, h1, l1;
+                split4_pk(make_float4(v0.x * dn, v0.y * dn, v0.z * dn, v0.w * dn), h0, l0);
+                split4_pk(make_float4(v1.x * dn, v1.y * dn, v1.z * dn, v1.w * dn), h1, l1);
+                float *dst = planes_out + ((size_t)gr * 12 + grp) * 64 + (o >> 1);      // (float words: 128 halves per (row, group); hi plane first)
+                idf_store16_wt(dst, __builtin_bit_cast(float4, make_uint4(h0.x, h0.y, h1.x, h1.y)));
+                idf_store16_wt(dst + 32, __builtin_bit_cast(float4, make_uint4(l0.x, l0.y, l1.x, l1.y)));
+                if (sl == 0 && c8 == 0) idf_store16_wt(scales_out + (size_t)gr * 4, make_float4(uq, uk, uv, 0.f));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < (QBM * (QHS / 4) + NT - 1) / NT; ++it) {
+            const int idx = tid + it * NT, row = idx / (QHS / 4), c4 = (idx - row * (QHS / 4)) << 2, gr = m0 + row;
+            if (idx < QBM * (QHS / 4) && gr < M && n0 + c4 < N) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, *reinterpret_cast<const float4 *>(Cs + row * QCS + c4));
+        }
     }
 }
 
 template <int NP>
 inline int launch_ln_linear_h2(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
                                const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
-                               int64_t *step_ts = nullptr, int step_B = 0) {
-    static idf_excl_cache excl;
-    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NT, excl);
+                               int64_t *step_ts = nullptr, int step_B = 0, float *planes_out = nullptr, float *scales_out = nullptr) {
+    static idf_excl_cache excl, excl_p;
+    if (planes_out) {                                  // the plane-pair output of the QKV projection (N = 768, the bounds behind the stream): see the kernel
+        const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, true>), NP == 1 ? "ln_linear_h2_kernel<1 slab, planes out>" : "ln_linear_h2_kernel<5 slabs, planes out>", NT, excl_p);
+        if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
+        if (!A) return IDF_OK;                         // (availability query: nothing to launch)
+        const int nsl = (int)idf_cdiv(N, QHS);
+        hipLaunchKernelGGL((ln_linear_h2_kernel<NP, true>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
+                           (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts, planes_out, scales_out);
+        return IDF_OK;
+    }
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, false>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NT, excl);
     if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
     const int nsl = (int)idf_cdiv(N, QHS);
-    hipLaunchKernelGGL(ln_linear_h2_kernel<NP>, dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
-                       (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts);
+    hipLaunchKernelGGL((ln_linear_h2_kernel<NP, false>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
+                       (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts, (float *)nullptr, (float *)nullptr);
     return IDF_OK;
 }
 }  // namespace idf_ffn_h2

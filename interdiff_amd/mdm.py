@@ -255,6 +255,16 @@ def pack_linear160_h2(w):
     return out.view(np.float32)
 
 
+def qkv_bounds(w, b):
+    """in_proj weight [768,256] and bias [768] -> the eight floats the split-f16 QKV kernel finds right behind its weight stream when it writes the self-attention's f16 planes
+    (csrc/ffn_h2.h ln_linear_h2_kernel<.., PLANES>): max L1 norm of the q / k / v rows (x 1.001: the kernel's own rounding), max |bias| of the q / k / v rows, two spare.
+    The kernel divides every input row by its own power of two (|x'| < 1), so |out_c| <= 2^e_row ||W_c||_1 + |b_c|."""
+    w, b = np.asarray(w, np.float64), np.asarray(b, np.float64)
+    l1 = np.abs(w).sum(1)
+    out = [l1[t * D:(t + 1) * D].max() * 1.001 for t in range(3)] + [np.abs(b[t * D:(t + 1) * D]).max() for t in range(3)] + [0.0, 0.0]
+    return np.asarray(out, np.float32)
+
+
 def sa_out_fragments(w):
     """out_proj.weight [256 out, 256 in] -> MFMA B-operand fragment order of the attention kernel's out-projection tail
     (csrc/denoiser.hip self_attn_kernel<true>): [head][wave = output column quarter][k-group of 16][column tile][lane = kq*16+li][4],
@@ -354,7 +364,12 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             ly.rb_h2_ok = 1 if ln_h2_range_ok((g(p + 'norm1.weight'), g(p + 'norm1.bias'))) else 0
             ly.sa_in_w = ar.add(g(p + 'self_attn.in_proj_weight'))
             ly.sa_in_pack = ar.add(pack_linear160(g(p + 'self_attn.in_proj_weight')))
-            ly.sa_in_pack_h2 = ar.add(pack_linear160_h2(g(p + 'self_attn.in_proj_weight'))) if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT else 0
+            if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT:      # the stream with the output bounds right behind it (include/interdiff_hip.h qkv_bounds_ok)
+                bnd = qkv_bounds(g(p + 'self_attn.in_proj_weight'), g(p + 'self_attn.in_proj_bias'))
+                ly.sa_in_pack_h2 = ar.add(np.concatenate([pack_linear160_h2(g(p + 'self_attn.in_proj_weight')), bnd]))
+                ly.qkv_bounds_ok = 1 if np.isfinite(bnd).all() and float(bnd[:3].max()) * 2.0 ** 60 < 3e38 else 0
+            else:
+                ly.sa_in_pack_h2, ly.qkv_bounds_ok = 0, 0
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
             ly.sa_out_w = ar.add(g(p + 'self_attn.out_proj.weight'))
             ly.sa_out_frag = ar.add(sa_out_fragments(g(p + 'self_attn.out_proj.weight')))

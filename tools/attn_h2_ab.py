@@ -20,7 +20,10 @@ def main():
     model, corr, bt, y, _ = bench.build_world(dev, 0)
     diff = create_gaussian_diffusion('cosine', bench.STEPS)
     for rep in range(3):
-        for name, misc in (('fp32 attention', 6), ('split-f16 attention', 0)):       # (round 5: the split-f16 kernel is the default; 6 selects the fp32 kernel)
+        settings = (('fp32 attention', 6), ('split-f16 attention', 0))       # (round 5: the split-f16 kernel is the default; 6 selects the fp32 kernel)
+        if os.environ.get('ATTN_AB') == 'planes':                           # the QKV kernel's output form in front of the split-f16 attention: fp32 rows (9) vs plane pairs (default)
+            settings = (('split-f16 attention, fp32 rows from the QKV kernel', 9), ('split-f16 attention, plane pairs from the QKV kernel', 0))
+        for name, misc in settings:
             model.w.tune[_lib.TUNE['misc']] = misc
             model.__dict__.pop('_graph_cache', None)
             out = dict(attention=name, forward_us=round(bench.time_forward_graph(model, bt, y, dev), 2))

@@ -616,3 +616,32 @@ def test_transposing_lds_read_address_map_of_the_attention_kernel():
                     frag[:, 4 * h:4 * h + 4] = tr_read(addr)
                 want = np.stack([V[ko:ko + 8, dt * 16 + li] for li in range(16)])
                 assert np.array_equal(frag, want), (s, dt, kq)
+
+
+def test_qkv_plane_bounds_hold_and_keep_the_split_in_range():
+    """The QKV kernel writes the self-attention's f16 planes under a per-row power of two derived WITHOUT looking at the output (csrc/ffn_h2.h ln_linear_h2_kernel<.., PLANES>):
+    every input row is divided by 2^e (|x'| < 1), so |out_c| <= 2^e ||W_c||_1 + |b_c|; mdm.py qkv_bounds supplies max ||W_c||_1 and max |b_c| per q / k / v block.  Restated
+    here in numpy on rows of very different magnitude: the bound holds for every output, the scaled outputs stay below 2^15 (f16 range), and the split (hi + lo' 2^-11) of the
+    scaled outputs reproduces them to 2^-21 of the row's bound."""
+    from interdiff_amd.mdm import qkv_bounds, split_f16
+    rng = np.random.RandomState(5)
+    W = (rng.randn(768, 256) * 0.08).astype(np.float32)
+    b = (rng.randn(768) * 0.3).astype(np.float32)
+    bnd = qkv_bounds(W, b)
+    assert bnd.shape == (8,) and bnd.dtype == np.float32
+    x = (rng.randn(40, 256) * np.exp(rng.uniform(-12, 12, size=(40, 1)))).astype(np.float32)
+    x[7] = 0.0
+    out = x.astype(np.float64) @ W.astype(np.float64).T + b
+    for r in range(x.shape[0]):
+        amax = np.abs(x[r]).max()
+        e = int(np.frexp(amax)[1]) if amax > 0 else 0              # |x| 2^-e in [0.5, 1)
+        for t in range(3):
+            bound = np.float32(np.float32(2.0 ** e) * bnd[t] + bnd[3 + t])
+            o = out[r, 256 * t:256 * (t + 1)]
+            assert np.abs(o).max() <= bound, (r, t)
+            E = int(np.frexp(max(float(bound), 1e-30))[1])           # bound < 2^E (frexp: bound = m 2^E, m in [0.5, 1))
+            scaled = (o * 2.0 ** (15 - E)).astype(np.float32)
+            assert np.abs(scaled).max() < 2.0 ** 15
+            hi, lo = split_f16(scaled)
+            back = hi.astype(np.float64) + lo.astype(np.float64) * 2.0 ** -11
+            assert np.abs(back - scaled).max() <= 2.0 ** 15 * 2.0 ** -21

@@ -69,8 +69,8 @@ void probe(int M) {
 
 int main(int argc, char **argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 1600;
-    probe<2, 3>(M);
-    probe<1, 3>(M / 2);
+    probe<2, 4>(M);
+    probe<1, 4>(M / 2);
     probe<4, 2>(2 * M);
     return 0;
 }

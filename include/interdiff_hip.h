@@ -323,6 +323,10 @@ int interdiff_mdm_step_chaining(const idf_mdm_weights *w);
  * process-stable, so every route of one process computes the same bits).  This entry forces the check for every such kernel on the current device,
  * writes one text line per kernel into buf (<= cap bytes, NUL-terminated) and returns how many do NOT pass (0 on MI355X), or a negative IDF_E_*. */
 int interdiff_exclusive_cu_report(char *buf, int32_t cap);
+/* DEBUG, tests only (round 6): from now on every f16-MFMA kernel whose name -- as the report above prints it -- contains one of the comma-separated `patterns` is
+ * treated as NOT owning its CU, so its launcher takes the fp32 kernel: the fallbacks can be executed on a device where every claim holds.  NULL / "" clears the
+ * list.  Process-wide state (the only such switch in the library; empty unless a test sets it); callers drop captured graphs, which bake the kernel choice in. */
+int interdiff_debug_deny_exclusive(const char *patterns);
 
 /* ------------------------------------------------------------------------------------
  * Correction predictor   replaces ObjProjector.sample (model/correction_smpl.py:79-138,

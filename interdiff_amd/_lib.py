@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('INTERDIFF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libinterdiff_hip.so')      # (the override: A/B builds of the SAME library under build_ab/, tools/ only)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -127,6 +127,7 @@ _SIGS = {
     'interdiff_debug_joint_map_vjp': (C.c_int, [vp, vp, vp, i32]),
     'interdiff_debug_lds_sentinel': (C.c_int, [vp, i32, i32, vp]),
     'interdiff_exclusive_cu_report': (C.c_int, [C.c_char_p, i32]),
+    'interdiff_debug_deny_exclusive': (C.c_int, [C.c_char_p]),
     'interdiff_debug_f16_aggressor': (C.c_int, [vp, sz, vp, i32, i32, i32, vp]),
     'interdiff_profile_begin': (C.c_int, [i32]),
     'interdiff_profile_end': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -170,6 +171,12 @@ def exclusive_cu_report():
     if bad < 0:
         check(bad, 'exclusive_cu_report')
     return buf.value.decode(), bad
+
+
+def debug_deny_exclusive(patterns=''):
+    """DEBUG (tests): treat every f16-MFMA kernel whose report name contains one of the comma-separated ``patterns`` as not owning its CU from now on (its launcher
+    then takes the fp32 kernel); '' clears the list.  Process-wide -- callers drop their captured graphs (they bake the kernel choice in)."""
+    check(load().interdiff_debug_deny_exclusive(patterns.encode() if patterns else None), 'debug_deny_exclusive')
 
 
 def exported_symbols():

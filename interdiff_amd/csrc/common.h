@@ -49,7 +49,7 @@ static inline int idf_opt_in_lds(const void *fn, int bytes, std::atomic<uint64_t
 // and never to IDF_E_LAUNCH.  Every verdict is kept in a table that interdiff_exclusive_cu_report() prints (tests, bench.py).
 struct idf_excl_entry {
     const char *name;
-    int threads, num_regs, static_lds, dyn_lds, blocks_per_cu, ok, dev;
+    int threads, num_regs, static_lds, dyn_lds, blocks_per_cu, ok, dev, denied;
 };
 // one table per process (C++17 inline variables: every translation unit, and every probe build that includes a kernel file whole, sees the same one); not on
 // any hot path: touched once per (kernel, device)
@@ -68,25 +68,55 @@ inline int idf_excl_report(char *buf, int cap) {        // the table as text; re
     for (const idf_excl_entry &e : g_idf_excl) {
         bad += e.ok ? 0 : 1;
         const int w = snprintf(buf + n, (size_t)(cap - n), "%-52s dev %d  threads %3d  regs %3d  lds %6d + %6d  workgroups_per_cu %d  %s\n", e.name, e.dev, e.threads, e.num_regs,
-                               e.static_lds, e.dyn_lds, e.blocks_per_cu, e.ok ? "exclusive" : "NOT exclusive -> fp32 kernel");
+                               e.static_lds, e.dyn_lds, e.blocks_per_cu, e.ok ? "exclusive" : (e.denied ? "DENIED (debug deny list) -> fp32 kernel" : "NOT exclusive -> fp32 kernel"));
         if (w < 0 || w >= cap - n) break;
         n += w;
     }
     return bad;
 }
+// DEBUG deny list (round 6; interdiff_debug_deny_exclusive, tests only -- empty in the product): kernels whose name contains one of the comma-separated patterns are treated as if
+// they did not get their CU, so that the fp32 fallbacks behind every split-f16 launcher can be EXECUTED on a device where every claim holds (MI355X: all of them).  Setting the list
+// bumps a generation counter; a launcher's cached verdict of an older generation is dropped and asked again.
+inline std::string g_idf_excl_deny;                     // guarded by g_idf_excl_mu
+inline std::atomic<uint64_t> g_idf_excl_gen{1};
+inline void idf_excl_set_deny(const char *patterns) {
+    std::lock_guard<std::mutex> lk(g_idf_excl_mu);
+    g_idf_excl_deny = patterns ? patterns : "";
+    g_idf_excl.clear();
+    g_idf_excl_gen.fetch_add(1, std::memory_order_acq_rel);
+}
+inline bool idf_excl_denied(const char *name) {
+    std::lock_guard<std::mutex> lk(g_idf_excl_mu);
+    if (g_idf_excl_deny.empty()) return false;
+    const std::string nm(name);
+    size_t a = 0;
+    while (a <= g_idf_excl_deny.size()) {
+        size_t b = g_idf_excl_deny.find(',', a);
+        if (b == std::string::npos) b = g_idf_excl_deny.size();
+        if (b > a && nm.find(g_idf_excl_deny.substr(a, b - a)) != std::string::npos) return true;
+        a = b + 1;
+    }
+    return false;
+}
 struct idf_excl_cache {
-    std::atomic<uint64_t> yes{0}, no{0};
+    std::atomic<uint64_t> yes{0}, no{0}, gen{0};
     std::atomic<int> dyn{-1};
 };
 constexpr int IDF_CU_LDS_BYTES = 160 * 1024;
-constexpr int IDF_NOT_EXCLUSIVE = 1;                    // internal (positive) return of the split-f16 launchers: "take the fp32 kernel"
+constexpr int IDF_NOT_EXCLUSIVE = 1;                    // internal (positive) return of the split-f16 launchers: "take the fp32 kernel"; never leaves the library (idf_public_rc)
+static inline int idf_public_rc(int rc) { return rc == IDF_NOT_EXCLUSIVE ? IDF_E_LAUNCH : rc; }      // at a public entry point: a launcher that had no fp32 fallback left
 static inline int idf_exclusive_cu(const void *fn, const char *name, int threads, idf_excl_cache &c) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    const uint64_t bit = 1ull << (dev & 63);
+    const uint64_t bit = 1ull << (dev & 63), gen = g_idf_excl_gen.load(std::memory_order_acquire);
+    if (c.gen.load(std::memory_order_acquire) != gen) {  // (a new deny list: forget what was cached under the old one; racing threads both reset, both ask again)
+        c.yes.store(0, std::memory_order_release);
+        c.no.store(0, std::memory_order_release);
+        c.gen.store(gen, std::memory_order_release);
+    }
     if (c.yes.load(std::memory_order_acquire) & bit) return c.dyn.load(std::memory_order_acquire);
     if (c.no.load(std::memory_order_acquire) & bit) return -1;
-    idf_excl_entry e{name, threads, -1, -1, -1, -1, 0, dev};
+    idf_excl_entry e{name, threads, -1, -1, -1, -1, 0, dev, 0};
     hipFuncAttributes at;
     if (hipFuncGetAttributes(&at, fn) == hipSuccess) {
         e.num_regs = at.numRegs;
@@ -97,6 +127,7 @@ static inline int idf_exclusive_cu(const void *fn, const char *name, int threads
             e.ok = e.blocks_per_cu == 1 && e.num_regs >= 256 ? 1 : 0;
     }
     (void)hipGetLastError();                             // a refused attribute must not surface as the next launch's error
+    if (e.ok && idf_excl_denied(name)) { e.ok = 0; e.denied = 1; }
     idf_excl_record(e);
     if (e.ok) {
         c.dyn.store(e.dyn_lds, std::memory_order_release);
@@ -104,8 +135,9 @@ static inline int idf_exclusive_cu(const void *fn, const char *name, int threads
         return e.dyn_lds;
     }
     c.no.fetch_or(bit, std::memory_order_release);
-    fprintf(stderr, "interdiff_hip: %s does not get its CU to itself on device %d (regs %d, LDS %d + %d, %d workgroups per CU): the fp32-MFMA kernel runs instead\n",
-            name, dev, e.num_regs, e.static_lds, e.dyn_lds, e.blocks_per_cu);
+    if (e.denied) fprintf(stderr, "interdiff_hip: %s is on the DEBUG deny list: the fp32-MFMA kernel runs instead\n", name);
+    else fprintf(stderr, "interdiff_hip: %s does not get its CU to itself on device %d (regs %d, LDS %d + %d, %d workgroups per CU): the fp32-MFMA kernel runs instead\n",
+                 name, dev, e.num_regs, e.static_lds, e.dyn_lds, e.blocks_per_cu);
     return -1;
 }
 

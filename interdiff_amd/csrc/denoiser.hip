@@ -1613,7 +1613,7 @@ int run_qkv(int tuned, hipStream_t s, const Args &g, const float *pack, int np, 
         if (!pack_h2) return IDF_E_INVAL;
         const int rc = np == NSL ? idf_ffn_h2::launch_ln_linear_h2<NSL>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B, planes, scales)
                                  : idf_ffn_h2::launch_ln_linear_h2<1>(s, g.A, g.a_pstride, g.lnw, g.lnb, g.M, g.N, pack_h2, g.bias, g.C, g.ldc, g.xn_out, step_state, step_ts, step_B, planes, scales);
-        return rc == IDF_NOT_EXCLUSIVE ? IDF_E_LAUNCH : rc;
+        return idf_public_rc(rc);
     }
     if (tuned && !step_state) { run_gemm_ln<E_BIAS>(tuned, s, g, np); return IDF_OK; }
     if (pack_h2) {
@@ -1897,7 +1897,7 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
         ta.u0 = k.uA; ta.M = N; ta.T = T; ta.x_tok = x; ta.plain_ids = tune[IDF_TUNE_MISC] == 7 ? 1 : 0;
         if (!(post.x && (flags & IDF_STEP_EMBED_READY))) {
             idf_prof_mark(IDF_K_EMBED, s);
-            if (const int rc = idf_tail_h2::launch_tail(s, 0, ta); rc != IDF_OK) return rc;
+            if (const int rc = idf_tail_h2::launch_tail(s, 0, ta); rc != IDF_OK) return idf_public_rc(rc);      // (tail_exclusive_ok was asked first: IDF_NOT_EXCLUSIVE cannot come back, and never leaves the library if it does)
         }
     } else
     {   // u0 = [x_body | x_obj].W_in^T + b_in + temb[ts] + pe   (tokens gathered from x[b][c][t])
@@ -1984,7 +1984,7 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
                 // budget (T > 192), the exact arithmetic and a device where it does not get its CU take the fp32 kernel
                 if (attn_h2) {
                     rc_ah2 = idf_attn_h2::launch_self_attn_h2(s, k.qkv, B, T, ar + ly.sa_out_frag_h2, k.parts, pstride, planes ? k.ctx : nullptr);
-                    if (rc_ah2 != IDF_OK && (rc_ah2 != IDF_NOT_EXCLUSIVE || planes)) return rc_ah2 == IDF_NOT_EXCLUSIVE ? IDF_E_LAUNCH : rc_ah2;
+                    if (rc_ah2 != IDF_OK && (rc_ah2 != IDF_NOT_EXCLUSIVE || planes)) return idf_public_rc(rc_ah2);
                 }
                 if (rc_ah2 == IDF_NOT_EXCLUSIVE) launch_self_attn_outproj(s, k.qkv, B, T, ar + ly.sa_out_frag, k.parts, pstride);
                 idf_prof_mark(IDF_K_ROWBLOCK_STD, s);
@@ -2038,7 +2038,7 @@ int mdm_forward_impl_t(const idf_mdm_weights *w, const float *memctx, const floa
             ta.post.post_x = post.x; ta.post.post_gt = post.gt; ta.post.post_mask = post.mask; ta.post.post_table = post.table; ta.post.post_state = post.state;
             mode = (flags & IDF_STEP_EMBED_NEXT) ? 3 : 2;
         }
-        if (const int rc = idf_tail_h2::launch_tail(s, mode, ta); rc != IDF_OK) return rc;
+        if (const int rc = idf_tail_h2::launch_tail(s, mode, ta); rc != IDF_OK) return idf_public_rc(rc);
     } else
     {   // heads: x0[b][c][t] = LN3_last(u).Wout^T + b
         Args g{};
@@ -2100,6 +2100,13 @@ extern "C" int interdiff_mdm_forward_step_ex(const idf_mdm_weights *w, const flo
 extern "C" int interdiff_mdm_step_chaining(const idf_mdm_weights *w) {
     return w && w->tune[IDF_TUNE_FFN_MATH] != 0 && w->out_w_h2 != 0 && w->in_w_h2 != 0 && w->C == idf_tail_h2::CW && w->tail_h2_ok != 0 &&
                    idf_tail_h2::tail_exclusive_ok(false) && idf_tail_h2::tail_exclusive_ok(true) ? 1 : 0;
+}
+
+// DEBUG (tests only): kernels whose name -- as interdiff_exclusive_cu_report prints it -- contains one of the comma-separated patterns are treated as NOT getting their CU from now on,
+// so that the fp32 kernel behind every split-f16 launcher can be executed on a device where all claims hold; null / "" clears the list.  Process-wide; not for product use.
+extern "C" int interdiff_debug_deny_exclusive(const char *patterns) {
+    idf_excl_set_deny(patterns);
+    return IDF_OK;
 }
 
 // Verdicts of the exclusive-CU check (common.h idf_exclusive_cu) for EVERY kernel of the library that issues the f16 MFMA, on the current device: forces

@@ -167,7 +167,7 @@ extern "C" int interdiff_randn(float *out, int64_t n, uint64_t seed, uint64_t st
     return interdiff_randn_at(out, n, seed, step_index, 0, stream);
 }
 
-#define IDF_ABI_VERSION 15
+#define IDF_ABI_VERSION 16
 #define IDF_STR_(x) #x
 #define IDF_STR(x) IDF_STR_(x)
 extern "C" int interdiff_abi_version(void) { return IDF_ABI_VERSION; }

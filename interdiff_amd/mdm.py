@@ -647,27 +647,41 @@ class MDM:
         if self.w.tune[_lib.TUNE['misc']] in (0, 8):            # (other values of the A/B switch are left to whoever set them)
             self.w.tune[_lib.TUNE['misc']] = 8 if getattr(self, 'rowblock_waves', 8) == 4 else 0
 
-    def arithmetic_report(self):
+    def arithmetic_report(self, device_verdicts=True):
         """Which arithmetic every contraction of a denoiser forward takes under the current ``ffn_math`` / ``rowblock_math`` selection, layer by
         layer -- the same conditions csrc/denoiser.hip applies (a layer whose f16 range proof failed at pack time stays on the exact fp32-MFMA kernel;
-        nothing else reports that).  'split' = split-f16 (two f16 planes per fp32 operand, three f16 MFMAs per product), 'exact' = fp32 MFMA."""
+        nothing else reports that).  'split' = split-f16 (two f16 planes per fp32 operand, three f16 MFMAs per product), 'exact' = fp32 MFMA.
+        ``device_verdicts`` (on a GPU): the launch-time side of the choice is folded in -- a split-f16 kernel that does not get its CU to itself on this device
+        (csrc/common.h idf_exclusive_cu; or sits on the debug deny list) runs as its fp32 counterpart, and the contraction is reported 'exact' with the
+        kernel named under ``not_exclusive``: a silent downgrade shows up here and in bench.py's line."""
         split = self.ffn_math == 'split'
         rb_split = split and self.rowblock_math == 'split'
         w = self.w
+        failing = []
+        if device_verdicts and self.device.type == 'cuda':
+            text, _ = _lib.exclusive_cu_report()
+            failing = [ln.split('  dev ')[0].strip() for ln in text.splitlines() if ln.strip() and not ln.rstrip().endswith('  exclusive')]
+        bad = lambda *tags: any(all(t in name for t in tags) for name in failing)
+        tile = {1: '32 rows', 2: '16 rows', 3: '64 rows'}.get(int(w.tune[_lib.TUNE['ffn']]), '')
         layers = []
         for l in range(LAYERS):
             ly = w.layer[l]
+            kind = 'QaN' if ly.is_qan else 'std'
             d = dict(layer=l, kind='qan' if ly.is_qan else 'std',
-                     ffn='split' if (split and ly.ffn_pack_h2) else 'exact',
-                     rowblock='split' if (rb_split and ly.rb_h2_ok and (not ly.is_qan or (ly.qc_h2 and l > 0))) else 'exact')
+                     ffn='split' if (split and ly.ffn_pack_h2 and not bad('ffn_h2_kernel', tile)) else 'exact',
+                     # the eight-wave row block, else round 4's four-wave split kernel, else fp32: 'exact' only when both split forms of this kind are refused
+                     rowblock='split' if (rb_split and ly.rb_h2_ok and (not ly.is_qan or (ly.qc_h2 and l > 0)) and not (bad('rowblock8_kernel<' + kind) and bad('rowblock_kernel<' + kind))) else 'exact')
             if not ly.is_qan:
-                d['qkv'] = 'split' if (split and ly.sa_in_pack_h2) else 'exact'
-                # csrc/denoiser.hip: the split-f16 attention kernel unless tune misc == 6 (A/B) or its fragments were not packed; clips longer than 192 frames and a device where
-                # the kernel does not get its CU take the fp32 kernel at launch time (not known here)
-                d['self_attention'] = 'split' if (split and ly.sa_out_frag_h2 and w.tune[_lib.TUNE['misc']] != 6) else 'exact'
+                slabs = '1 slab' if l == 0 else '5 slabs'
+                attn_packed = bool(split and ly.sa_out_frag_h2 and w.tune[_lib.TUNE['misc']] != 6)
+                planes = bool(attn_packed and ly.sa_in_pack_h2 and ly.qkv_bounds_ok and w.tune[_lib.TUNE['misc']] != 9 and not bad('ln_linear_h2_kernel<' + slabs + ', planes out>') and not bad('self_attn_h2_kernel<planes in>'))
+                d['qkv'] = 'split' if (split and ly.sa_in_pack_h2 and (planes or not any(n == 'ln_linear_h2_kernel<%s>' % slabs for n in failing))) else 'exact'
+                # csrc/denoiser.hip: the split-f16 attention kernel unless tune misc == 6 (A/B) or its fragments were not packed; clips longer than 192 frames take the fp32 kernel at launch time (not known here)
+                d['self_attention'] = 'split' if (attn_packed and (planes or 'self_attn_h2_kernel' not in failing)) else 'exact'
+                d['qkv_hands_over_planes'] = planes
             layers.append(d)
-        tail = 'split' if (split and w.out_w_h2 and w.in_w_h2 and w.C == 144 and w.tail_h2_ok) else 'exact'
-        return dict(ffn_math=self.ffn_math, rowblock_math=self.rowblock_math, layers=layers, embedding_and_heads=tail,
+        tail = 'split' if (split and w.out_w_h2 and w.in_w_h2 and w.C == 144 and w.tail_h2_ok and not bad('step_tail_h2_kernel')) else 'exact'
+        return dict(ffn_math=self.ffn_math, rowblock_math=self.rowblock_math, layers=layers, embedding_and_heads=tail, not_exclusive=failing,
                     all_split=all(d['ffn'] == 'split' and d['rowblock'] == 'split' and d.get('qkv', 'split') == 'split' and d.get('self_attention', 'split') == 'split' for d in layers) and tail == 'split')
 
     def forward(self, x, timesteps, y=None, out=None, memctx=None, ws=None, batch_rows=None):

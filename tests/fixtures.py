@@ -192,11 +192,11 @@ def corr32_inputs():
     return x, model_kwargs_y(bt, T)
 
 
-PARITY_LOG = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r05.json')
+PARITY_LOG = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r06.json')
 
 
 def record_parity(name, **values):
-    """Measured errors of the chain / end-to-end parity tests -> gpurun_out/parity_r05.json (merged back from the GPU box; the
+    """Measured errors of the chain / end-to-end parity tests -> gpurun_out/parity_r06.json (merged back from the GPU box; the
     copy that is judged lives in profiles/).  Never fails a test."""
     import json
     try:

@@ -601,6 +601,100 @@ def test_exclusive_cu_claims_are_verified_and_hold(mdm, smpl):
     assert differing == 0, 'the SMPL stage computed different bits beside the split-f16 feed-forward kernel in %d of 8 runs' % differing
 
 
+DENY_CASES = [
+    # (deny patterns, contraction the report must call 'exact' [key, layer or None], what the pattern takes away)
+    ('ffn_h2_kernel', ('ffn', 3), 'the fused feed-forward block -> ffn.h fp32 kernel (csrc/denoiser.hip idf_launch_layer_ffn)'),
+    ('ln_linear_h2_kernel', ('qkv', 0), 'both QKV projections, planes route included -> ffn.h ln_linear_kernel; the attention then splits fp32 rows itself'),
+    ('planes out', ('qkv_hands_over_planes', 0), 'only the plane-pair output of the projection -> fp32 rows out of the split projection, split attention'),
+    ('self_attn_h2_kernel<planes in>', ('qkv_hands_over_planes', 7), 'only the planes-in attention -> fp32 rows out of the projection, attention splits them itself'),
+    ('self_attn_h2_kernel', ('self_attention', 7), 'every split-f16 attention (the planes route with it) -> fp32 self-attention with the out-projection in its tail'),
+    ('rowblock8_kernel', None, 'the eight-wave row block -> round 4\'s four-wave split kernel (still split-f16)'),
+    ('rowblock', ('rowblock', 2), 'both split row blocks -> fp32 row block'),
+    ('step_tail_h2_kernel', ('embedding_and_heads', None), 'the step tail -> fp32 embedding GEMM and heads GEMM (gemm.h), unchained steps'),
+    ('ffn_h2_kernel,ln_linear_h2_kernel,self_attn_h2_kernel,rowblock,step_tail_h2_kernel', ('ffn', 0), 'everything: the whole forward on fp32 kernels although the split arithmetic is selected'),
+]
+
+
+@pytest.mark.parametrize('case', range(len(DENY_CASES)))
+def test_fp32_fallback_behind_every_split_f16_launcher(lib, case):
+    """VERDICT r05 'what is weak' 1: the fp32 kernels behind the split-f16 launchers (csrc/common.h idf_exclusive_cu -> IDF_NOT_EXCLUSIVE) never ran on the only device the
+    tests run on, where every kernel gets its CU.  The debug deny list (interdiff_debug_deny_exclusive) refuses kernels by name; each case denies one family, checks that
+    ``MDM.arithmetic_report()`` names the downgrade, and runs (i) a forward at the bench clip length and a ragged one against oracle/denoiser.py at 1e-4 and (ii) a 30-step
+    chained plain-step window (graph route) against the eager route bit for bit and against the oracle's p_sample_loop at 1e-4 -- in the MIXED arithmetic that results."""
+    from interdiff_amd import _lib
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    patterns, expect, _ = DENY_CASES[case]
+    sd = fx.mdm_weights()
+    try:
+        _lib.debug_deny_exclusive(patterns)
+        model = MDM(sd, device=DEV)
+        assert model.ffn_math == 'split'
+        x, ts, cond = fx.mdm_inputs(4, 100)
+        got = model(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)})            # (launches first: the verdict table fills as launchers ask)
+        rep = model.arithmetic_report()
+        assert rep['not_exclusive'], rep
+        assert all(any(p in n for p in patterns.split(',')) for n in rep['not_exclusive']), rep['not_exclusive']
+        if expect is None:
+            assert rep['all_split'], rep                                           # the four-wave split row block took over: still split-f16 everywhere
+        else:
+            key, layer = expect
+            val = rep[key] if layer is None else rep['layers'][layer][key]
+            assert val in ('exact', False), (key, layer, val, rep)
+            assert not rep['all_split'] or key == 'qkv_hands_over_planes', rep
+        e1 = close(got, oden.mdm_forward(sd, x, ts, cond), 1e-4, 'forward, denied: ' + patterns)
+        x2, ts2, cond2 = fx.mdm_inputs(3, 37)
+        e2 = close(model(x2.to(DEV), ts2.to(DEV), y={'cond': cond2.to(DEV)}), oden.mdm_forward(sd, x2, ts2, cond2), 1e-4, 'ragged forward, denied: ' + patterns)
+        # a window of plain steps: graph route (chained steps where the tail still runs) == eager route fed the same Philox stream, and both vs the oracle
+        diff = create_gaussian_diffusion('cosine', 1000)
+        bt, y = fx.timed_inputs(2)
+        yd, x_t = dev(y), bt['noise'].to(DEV)
+        n, seed = 30, 99
+        g = diff.p_sample_loop(model, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': yd}, seed=seed, n_steps=n, first_t=fx.TIMED_FIRST_T)
+        draw = _philox_step(lib, seed)
+        stream = [draw(it, x_t) for it in range(n)]
+        ea = diff.p_sample_loop(model, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': yd}, step_noise=torch.stack(stream), n_steps=n, first_t=fx.TIMED_FIRST_T)
+        assert torch.equal(g, ea), ('graph route != eager route, denied: ' + patterns, float((g - ea).abs().max()))
+        ref = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond']), tuple(x_t.shape), odf.make_schedule(1000),
+                                bt['noise'].clone(), lambda i, xx: stream[i].cpu(), {'y': y}, n_steps=n, first_t=fx.TIMED_FIRST_T)
+        e3 = close(g, ref, 1e-4, '30 plain steps, denied: ' + patterns)
+        fx.record_parity('fallback_denied_%d' % case, denied=patterns, forward=e1, ragged_forward=e2, window_30_steps=e3, not_exclusive=rep['not_exclusive'])
+    finally:
+        _lib.debug_deny_exclusive('')
+    txt, bad = _lib.exclusive_cu_report()
+    assert bad == 0, txt                                                           # the list is cleared: every kernel owns its CU again
+
+
+def test_one_layer_failing_its_f16_range_proof_runs_mixed(lib):
+    """A model where ONE layer's feed-forward block and ANOTHER layer's row block fail their pack-time f16 range proofs (huge LayerNorm gains: mdm.py ffn_h2_range_ok /
+    ln_h2_range_ok) keeps those two on the exact fp32 kernels and everything else split-f16: the 50-step chain in that mixed arithmetic against the oracle at 1e-4,
+    graph route == eager route bit for bit (only all-split and all-exact were gated end to end before round 6)."""
+    from interdiff_amd.mdm import MDM
+    from interdiff_amd.diffusion import create_gaussian_diffusion
+    sd = {k: torch.as_tensor(v).clone() for k, v in fx.mdm_weights().items()}
+    sd['decoder.layers.3.norm2.weight'] *= 6000.0          # layer 3's feed-forward input bound 16 max|gamma| + max|beta| leaves the f16 range
+    sd['decoder.layers.5.norm1.weight'] *= 6000.0          # layer 5's row-block operand (its own norm1 output) does too
+    model = MDM(sd, device=DEV)
+    rep = model.arithmetic_report()
+    assert rep['layers'][3]['ffn'] == 'exact' and rep['layers'][5]['rowblock'] == 'exact' and not rep['all_split'], rep
+    assert sum(d['ffn'] == 'split' for d in rep['layers']) == 7 and sum(d['rowblock'] == 'split' for d in rep['layers']) >= 6, rep
+    x, ts, cond = fx.mdm_inputs(4, 100)
+    e1 = close(model(x.to(DEV), ts.to(DEV), y={'cond': cond.to(DEV)}), oden.mdm_forward(sd, x, ts, cond), 1e-4, 'mixed-arithmetic forward')
+    diff = create_gaussian_diffusion('cosine', 1000)
+    bt, y = fx.timed_inputs(2)
+    yd, x_t = dev(y), bt['noise'].to(DEV)
+    n, seed = 50, 1234
+    g = diff.p_sample_loop(model, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': yd}, seed=seed, n_steps=n, first_t=fx.TIMED_FIRST_T)
+    draw = _philox_step(lib, seed)
+    stream = [draw(it, x_t) for it in range(n)]
+    ea = diff.p_sample_loop(model, tuple(x_t.shape), noise=x_t, clip_denoised=False, model_kwargs={'y': yd}, step_noise=torch.stack(stream), n_steps=n, first_t=fx.TIMED_FIRST_T)
+    assert torch.equal(g, ea), float((g - ea).abs().max())
+    ref = odf.p_sample_loop(lambda x, t, y: oden.mdm_forward(sd, x, t, y['cond']), tuple(x_t.shape), odf.make_schedule(1000),
+                            bt['noise'].clone(), lambda i, xx: stream[i].cpu(), {'y': y}, n_steps=n, first_t=fx.TIMED_FIRST_T)
+    e2 = close(g, ref, 1e-4, '50 plain steps in mixed arithmetic vs oracle')
+    fx.record_parity('mixed_arithmetic_one_layer_exact', forward=e1, window_50_steps=e2)
+
+
 def test_coresidency_reproducer_and_the_integrator_rule(tmp_path):
     """The stand-alone reproducer of the co-residency effect (tools/coresidency_repro.hip; DESIGN.md "exclusive CU") as a test.
     ASSERTED -- the rule an integrator is given: (i) a victim with NO packed-fp32 instruction (-fno-slp-vectorize) computes the same bits beside every aggressor form;

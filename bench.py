@@ -598,39 +598,41 @@ def main():
             # f16 FLOP it ISSUES (zero-padded hidden units / K steps included: they occupy the pipe like the rest) -- not the fp32-equivalent work, which
             # would be priced against a pipe this kernel no longer uses.
             issued = ffn_issued_f16_flop(rows, 32)
-            ach = issued / (us * 1e-6) / 1e12
-            peak = PEAK_F16_MFMA_TFLOPS
-            frac_of = lambda rows_, tile_, us_: ffn_issued_f16_flop(rows_, tile_) / (us_ * 1e-6) / 1e12 / PEAK_F16_MFMA_TFLOPS
+            eq = flops / (us * 1e-6) / 1e12                  # ALGORITHMIC fp32-grade FLOP per second (SURVEY.md 8(d) x rows / measured duration)
+            peak = PEAK_F16_MFMA_TFLOPS / 3                  # the roof an fp32-grade product has on the pipe the kernel issues on: f16 dense peak / 3 products
+            ach = eq
+            iss = issued / (us * 1e-6) / 1e12                # secondary: f16 FLOP the kernel ISSUES (3 products + zero padding of hidden slices / K steps) vs the f16 dense peak
+            frac_of = lambda rows_, tile_, us_: FFN_FLOP_PER_TOKEN * rows_ / (us_ * 1e-6) / 1e12 / peak
             r_ = tj.get('rocprofv3_in_situ_us')
             if r_:
-                recorded = dict(us_per_launch=r_, achieved=issued / (r_ * 1e-6) / 1e12, frac=issued / (r_ * 1e-6) / 1e12 / peak, recorded_not_measured=True, source=ROCPROF_STATS)
+                recorded = dict(us_per_launch=r_, achieved=flops / (r_ * 1e-6) / 1e12, frac=flops / (r_ * 1e-6) / 1e12 / peak, recorded_not_measured=True, source=ROCPROF_STATS)
             stream_bytes = 5 * 442368                        # packed weight stream of one layer (what every XCD pulls through its L2 once per launch)
-            eq = flops / (us * 1e-6) / 1e12
             line['roofline'] = dict(
                 bound='mfma', kernel=dom, kernel_id=DOMINANT_KERNEL_ID, achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
-                traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best, issued_f16_flop_per_launch=issued, issued_f16_mfma_per_launch=issued // 16384,
+                traffic=traffic, us_per_launch=us, us_per_launch_best=dom_best,
                 algorithmic_flop_per_launch=flops, rocprofv3_in_situ=recorded,
-                peak_note='the kernel issues v_mfma_f32_16x16x32_f16 -- three per fp32-grade product (csrc/ffn_h2.h) -- so achieved = f16 FLOP ISSUED per launch (324 000 MFMAs x 16 384 at '
-                          'M = 1600, zero padding included) / measured duration and peak = the f16 dense MFMA peak (MI355X_MICROARCH.md).  frac is also the share of the launch during which '
-                          'the matrix pipes issue (an MFMA of this shape holds its SIMD 16 cycles: 324 000 x 16 / 1024 SIMDs = 5.06 k cycles = 2.1 us)',
-                mfma_busy_share=dict(analytic=ach / peak, recorded_pmc=tj.get('mfma_busy_share'), target_of_round_5=0.25,
+                peak_note='achieved = the block\'s ALGORITHMIC fp32 FLOP per launch (2 x 2*M*256*1024 = 1 048 576 per token x M rows, SURVEY.md 8(d)) / measured duration; peak = the roof an fp32-grade '
+                          'product has on the pipe this kernel issues on: it multiplies as three v_mfma_f32_16x16x32_f16 per product (csrc/ffn_h2.h), so f16 dense peak 2500 / 3 = 833 TFLOP/s '
+                          '(MI355X_MICROARCH.md).  Same number as 3 x algorithmic FLOP / f16 peak.  Rounds 1-4 divided the same algorithmic FLOP by the fp32-input MFMA peak (157 TFLOP/s), a pipe the '
+                          'kernel no longer uses; round 5\'s top-level figure counted the ISSUED f16 FLOP (zero padding included), which is now `issued_f16` below -- redundant MFMAs must not raise frac',
+                issued_f16=dict(flop_per_launch=issued, mfma_per_launch=issued // 16384, achieved_tflops=iss, frac_of_f16_dense_peak=iss / PEAK_F16_MFMA_TFLOPS,
+                                note='f16 FLOP the kernel issues per launch: (13 hidden tiles x 8 K steps + 16 output tiles x 7 K steps) x 2 token tiles x 3 products x 16 384 x 250 workgroups, zero padding '
+                                     '(1024 -> 5 x 208 hidden units, K 208 -> 224) included; = the share of the launch during which the matrix pipes issue'),
+                mfma_busy_share=dict(analytic=iss / PEAK_F16_MFMA_TFLOPS, recorded_pmc=tj.get('mfma_busy_share'),
                                      note='SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x launch cycles); analytic = issued MFMAs x 16 cycles over the same denominator'),
                 binding_resource=dict(what='the LDS-DMA weight stream (every workgroup pulls its slice\'s 432 KiB from its XCD\'s L2 at the ~50 B/clk a CU reaches) plus fixed phases outside the K loops '
                                            '(row fetch + split, GELU + split, staging, the 8-MB slab store burst): DESIGN.md 4.2 phase stamps',
                                       weight_stream_bytes_per_workgroup=stream_bytes // 5, weight_stream_bytes_per_layer=stream_bytes,
                                       weight_stream_gb_per_s_per_cu=(stream_bytes // 5) / (us * 1e-6) / 1e9,
                                       l2_fed_dma_ceiling_gb_per_s_per_cu=50 * 2.4, note='ceiling: tools/dma_ceiling.hip (profiles/r02_dma_ceiling.txt), ~50 B/clk/CU at 2.4 GHz'),
-                fp32_equivalent=dict(achieved_tflops=eq, f32_mfma_peak_tflops=PEAK_F32_MFMA_TFLOPS, split_f16_roof_tflops=PEAK_F16_MFMA_TFLOPS / 3,
-                                     frac_of_split_f16_roof=eq / (PEAK_F16_MFMA_TFLOPS / 3),
-                                     note='the block\'s ALGORITHMIC fp32 FLOP (2 x 2*M*256*1024) / duration, priced against the roof an fp32-grade product has on the f16 pipe '
-                                          '(f16 dense peak / 3 products).  The fp32-input MFMA peak is listed for orientation only: the arithmetic left that pipe, so a ratio to it is not a roofline fraction'),
+                fp32_input_mfma_peak_tflops=PEAK_F32_MFMA_TFLOPS,      # (orientation only: the arithmetic left that pipe, a ratio to it is not a roofline fraction)
                 exact_fp32_kernel=dict(us_per_launch=exact_us, bound='mfma', achieved=flops / (exact_us * 1e-6) / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                                        frac=flops / (exact_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, denoiser_forward_us=exact_fwd_us,
                                        kernel='idf_ffn::ffn_fused_kernel (v_mfma_f32_16x16x4_f32; csrc/ffn.h), selectable with MDM.ffn_math = "exact" / INTERDIFF_FFN_MATH=exact',
                                        note='same measurement recipe, same process; this kernel DOES issue the fp32-input MFMA, so its roof is that peak') if exact_us else None,
                 one_layer_burst=dict(us_per_launch=burst_us, us_per_launch_best=burst_best, frac=frac_of(rows, 32, burst_us),
                                      note='back-to-back launches on ONE layer (weights stay in the L2s): optimistic; secondary'),
-                two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=2 * ffn_issued_f16_flop(rows // 2, 32) / (pair_us * 1e-6) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                two_chain_form=dict(us_per_pair=pair_us, us_per_pair_best_burst=pair_best, frac=flops / (pair_us * 1e-6) / 1e12 / peak,
                                     note='NOT the route of this shape (one chain up to one round of workgroups, MDM.one_chain_max_rows); kept for comparison: '
                                          'the same layer as two concurrent launches at M=%d on two graph branches' % (rows // 2)),
                 small_batch_16_row_tile=dict(rows=800, us_per_launch=small_us, us_per_launch_best=small_best, frac=frac_of(800, 16, small_us),
@@ -689,7 +691,18 @@ def main():
     if cpu:
         if 'no_correction' in extra:                         # GPU / CPU on the denoiser alone, next to the blended ratio
             cpu['plain_only']['gpu_over_cpu'] = extra['no_correction']['value'] / cpu['plain_only']['value']
+            cpu['headline_gpu_over_cpu'] = dict(value=cpu['plain_only']['gpu_over_cpu'], of='plain denoising steps (the denoiser alone): the quotable figure -- 71 % of the blended CPU time is the '
+                                                'oracle\'s own brute-force nearest-neighbour search in the 11 correction calls')
         cpu['gpu_over_cpu_blended'] = line['value'] / cpu['value']
+        try:                                                 # RECORDED in the build container (tools/cpu_reference_vs_port.py; /root/reference cannot travel to this box): is the port slower than the source it restates?
+            pr = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cpu_reference_vs_port.json')))
+            cpu['port_vs_reference'] = dict(plain_step=pr['port_vs_reference']['plain_step'], correction_call=pr['port_vs_reference']['correction_call'], threads=pr['threads'],
+                                            reference_plain_step_s=pr['plain_step_s']['reference'], port_plain_step_s=pr['plain_step_s']['port'], recorded_not_measured=True,
+                                            source='profiles/r06_cpu_reference_vs_port.json',
+                                            note='seconds of the oracle / seconds of the reference\'s own source on the same cores, same inputs (8 threads, build container): ~1.0 -- the port neither '
+                                                 'flatters nor penalises the CPU side; a GPU/CPU ratio against the reference itself = the ratio above / this number')
+        except Exception as e:
+            cpu['port_vs_reference'] = dict(error=repr(e))
         line['cpu_baseline'] = cpu
     sys.stdout.flush()
     C.CDLL(None).fflush(None)                          # whatever C stdio still holds goes to stderr, not behind the JSON

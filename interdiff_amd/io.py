@@ -22,11 +22,20 @@ def _torch_load_weights(path, map_location, trust_pickle):
     ``argparse.Namespace``, which is allow-listed for this one call (it is data: attribute names -> values).  Anything else a file wants to
     unpickle is code execution by whoever wrote the file, and is refused unless the caller says the file is trusted."""
     import argparse
-    try:
+    import pickle
+    import contextlib
+    try:                                              # torch >= 2.5: a scoped allow-list; 2.4: a process-wide one; older: plain weights_only=True (a Namespace in the file is then refused)
         from torch.serialization import safe_globals
-        with safe_globals([argparse.Namespace]):
+        allow = safe_globals([argparse.Namespace])
+    except ImportError:
+        allow = contextlib.nullcontext()
+        add = getattr(torch.serialization, 'add_safe_globals', None)
+        if add is not None:
+            add([argparse.Namespace])
+    try:
+        with allow:
             return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception as e:
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError) as e:      # what an unpickler refusing a global raises; OSError (no such file, ...) propagates as it is
         if not trust_pickle:
             raise ValueError('%s does not load with weights_only=True (%s: %s); pass trust_pickle=True only for a file whose origin you trust -- '
                              'a pickle runs code' % (path, type(e).__name__, str(e).splitlines()[0] if str(e) else '')) from e

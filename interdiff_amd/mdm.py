@@ -265,6 +265,22 @@ def qkv_bounds(w, b):
     return np.asarray(out, np.float32)
 
 
+QKV_BOUND_SLACK_MAX = 16.0      # a (type, head) group may sit at most this factor below the bound all heads of its type are divided by (4 of a plane pair's 22 bits)
+
+
+def qkv_bounds_usable(w, b, bnd):
+    """Whether the per-TYPE bounds of ``qkv_bounds`` are good enough to scale every head's planes by: finite, far from overflow, and no (type, head) group
+    whose own bound lies more than QKV_BOUND_SLACK_MAX below its type's (one outlier row or head would push every other head's planes down by that slack and
+    cost their small elements range: ADVICE r05).  Such a layer keeps fp32 rows out of the projection and the attention splits them by the measured
+    amax per (clip, head) tile, as before round 5."""
+    w, b, bnd = np.asarray(w, np.float64), np.asarray(b, np.float64), np.asarray(bnd, np.float64)
+    if not np.isfinite(bnd).all() or float(bnd[:3].max()) * 2.0 ** 60 >= 3e38:
+        return False
+    l1 = np.abs(w).sum(1).reshape(3, HEADS, D // HEADS).max(2) * 1.001 + np.abs(b).reshape(3, HEADS, D // HEADS).max(2)      # [type][head]: the bound a head would get on its own (unit row scale)
+    whole = bnd[:3] + bnd[3:6]
+    return bool((whole[:, None] <= QKV_BOUND_SLACK_MAX * np.maximum(l1, 1e-30)).all())
+
+
 def sa_out_fragments(w):
     """out_proj.weight [256 out, 256 in] -> MFMA B-operand fragment order of the attention kernel's out-projection tail
     (csrc/denoiser.hip self_attn_kernel<true>): [head][wave = output column quarter][k-group of 16][column tile][lane = kq*16+li][4],
@@ -367,7 +383,7 @@ def pack_mdm_weights(sd, device, n_steps=1000, max_T=512, rotary=ROTARY_DEFAULT)
             if np.abs(g(p + 'self_attn.in_proj_weight')).max() < H2_LIMIT:      # the stream with the output bounds right behind it (include/interdiff_hip.h qkv_bounds_ok)
                 bnd = qkv_bounds(g(p + 'self_attn.in_proj_weight'), g(p + 'self_attn.in_proj_bias'))
                 ly.sa_in_pack_h2 = ar.add(np.concatenate([pack_linear160_h2(g(p + 'self_attn.in_proj_weight')), bnd]))
-                ly.qkv_bounds_ok = 1 if np.isfinite(bnd).all() and float(bnd[:3].max()) * 2.0 ** 60 < 3e38 else 0
+                ly.qkv_bounds_ok = 1 if qkv_bounds_usable(g(p + 'self_attn.in_proj_weight'), g(p + 'self_attn.in_proj_bias'), bnd) else 0
             else:
                 ly.sa_in_pack_h2, ly.qkv_bounds_ok = 0, 0
             ly.sa_in_b = ar.add(g(p + 'self_attn.in_proj_bias'))
@@ -455,6 +471,7 @@ class MDM:
         self.w, self.arena = pack_mdm_weights(state_dict, self.device, n_steps=n_steps, rotary=rotary)
         self._mem_key, self._mem_cond, self._memctx, self._ws = None, None, None, None
         self._ws_shape, self._ws_pool, self._memctx_pool = None, {}, {}
+        self._memlen_of = {}                      # folded-memory buffer address -> (memory length, floats): the length travels with the buffer (_bind_memory)
         self.ffn_rows = 0                           # 0: feed-forward tile by batch size (_pick_ffn_tile); 16 / 32: forced
         # arithmetic of the feed-forward block: 'split' = split-f16 MFMA (csrc/ffn_h2.h: two f16 planes per fp32 operand, three f16 MFMAs per
         # product, fp32 accumulate -- fp32-grade results, layers whose range proof failed at pack time stay exact); 'exact' = fp32 MFMA (csrc/ffn.h)
@@ -543,15 +560,17 @@ class MDM:
         B = cond.shape[1]
         given = cond
         cond = cond.contiguous()
-        self.w.mem_len = cond.shape[0]              # the handle's memory length: every forward on this memory reads it (10: compact layout; else the generic one)
-        need = self.lib.interdiff_mdm_memctx_floats_for(B, cond.shape[0])
+        L = cond.shape[0]
+        need = self.lib.interdiff_mdm_memctx_floats_for(B, L)
         if into is not None:
             if into.numel() != need or into.dtype != torch.float32 or not into.is_contiguous():
-                raise ValueError('into must be %d contiguous floats' % need)
+                raise ValueError('into must be %d contiguous floats' % need)          # (nothing of the handle has changed yet)
             ws = self._workspace(B, 16)
+            self.w.mem_len = L                      # read by the C call below; every later forward sets it from the buffer it is handed (_bind_memory)
             _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                              _lib.dptr(into), _lib.dptr(ws), ws.numel(), _lib.stream()),
                        'mdm_prepare_memory')
+            self._memlen_of[into.data_ptr()] = (L, need)
             return into
         # one buffer per (batch size, memory length), reused for every sample and never released: its address may be baked into a captured hipGraph
         pool_key = B if cond.shape[0] == MEM else (B, cond.shape[0])
@@ -560,9 +579,11 @@ class MDM:
             memctx = torch.empty(need, dtype=torch.float32, device=self.device)
             self._memctx_pool[pool_key] = memctx
         ws = self._workspace(B, 16)
+        self.w.mem_len = L
         _lib.check(self.lib.interdiff_mdm_prepare_memory(C.byref(self.w), _lib.dptr(cond, torch.float32), B,
                                                          _lib.dptr(memctx), _lib.dptr(ws), ws.numel(), _lib.stream()),
                    'mdm_prepare_memory')
+        self._memlen_of[memctx.data_ptr()] = (L, need)
         # forward() recognises "same memory as last time" by (address, version, shape) of the tensor it is handed; the tensor itself
         # is kept alive here so that the allocator cannot hand its address to a DIFFERENT cond of the same shape (the outputs of
         # _get_embeddings are written through raw pointers, so their version counter never moves)
@@ -570,6 +591,20 @@ class MDM:
         self._mem_cond = given
         self._memctx = memctx
         return memctx
+
+    def _bind_memory(self, memctx, B):
+        """Set the handle's memory length from the folded buffer a forward is about to read -- the length is a property of the BUFFER (recorded next to it by
+        ``prepare_memory``), not of whichever ``prepare_memory`` call came last: a cached model buffer of length 10 stays length 10 after a length-15 fold ``into=`` a
+        caller's buffer.  A buffer this model did not fold is identified by its size (the layouts of different lengths differ in size)."""
+        rec = self._memlen_of.get(memctx.data_ptr())
+        if rec is None or rec[1] != memctx.numel():
+            fits = [L for L in range(1, MEM_MAX + 1) if self.lib.interdiff_mdm_memctx_floats_for(B, L) == memctx.numel()]
+            if len(fits) != 1:
+                raise ValueError('memctx was folded for another batch size or memory length')
+            rec = (fits[0], memctx.numel())
+        if self.lib.interdiff_mdm_memctx_floats_for(B, rec[0]) != memctx.numel():
+            raise ValueError('memctx was folded for another batch size or memory length')
+        self.w.mem_len = rec[0]
 
     def _get_embeddings(self, body_pose, body_trans, obj_angles, obj_trans, obj_points, past_len=10, batch_clips=None):
         """``MDM._get_embeddings`` (model/diffusion_smpl.py:195-223) on tensors instead of the dataset's dict-of-lists:
@@ -696,8 +731,7 @@ class MDM:
             if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
                 self.prepare_memory(cond)
             memctx = self._memctx
-        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats_for(B, self.mem_len):
-            raise ValueError('memctx was folded for another batch size or memory length')
+        self._bind_memory(memctx, B)
         if one != 1 or Cc != self.w.C:
             raise ValueError('x must be [B,1,%d,T]' % self.w.C)
         x = x.contiguous()
@@ -741,8 +775,7 @@ class MDM:
             if self._mem_key != (cond.data_ptr(), cond._version, tuple(cond.shape)):
                 self.prepare_memory(cond)
             memctx = self._memctx
-        elif memctx.numel() != self.lib.interdiff_mdm_memctx_floats_for(B, self.mem_len):
-            raise ValueError('memctx was folded for another batch size or memory length')
+        self._bind_memory(memctx, B)
         if ws is None:
             ws = self._workspace(B, T)
         flags = (_lib.STEP_EMBED_READY if embed_ready else 0) | (_lib.STEP_EMBED_NEXT if embed_next else 0)

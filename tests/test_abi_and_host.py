@@ -645,3 +645,13 @@ def test_qkv_plane_bounds_hold_and_keep_the_split_in_range():
             hi, lo = split_f16(scaled)
             back = hi.astype(np.float64) + lo.astype(np.float64) * 2.0 ** -11
             assert np.abs(back - scaled).max() <= 2.0 ** 15 * 2.0 ** -21
+    # the per-TYPE bound is only taken when no (type, head) group sits far below it (mdm.py qkv_bounds_usable): one outlier head -> the layer keeps fp32 rows (qkv_bounds_ok = 0)
+    from interdiff_amd.mdm import qkv_bounds_usable
+    assert qkv_bounds_usable(W, b, bnd)
+    W2 = W.copy()
+    W2[256 + 64 * 2:256 + 64 * 3] *= 200.0                          # head 2 of the key block: every other head's k planes would be scaled ~200x too low
+    assert not qkv_bounds_usable(W2, b, qkv_bounds(W2, b))
+    W3 = W.copy()
+    W3[5] *= 8.0                                                   # one outlier row inside a head: 8x is within the slack that is tolerated (3 of 22 bits)
+    assert qkv_bounds_usable(W3, b, qkv_bounds(W3, b))
+    assert not qkv_bounds_usable(W * np.float32(1e25), b, qkv_bounds(W * np.float32(1e25), b))      # far from overflow, as before

@@ -1346,6 +1346,36 @@ def test_denoiser_any_memory_length_and_long_clips(lib, M, B, T):
 
 
 @pytest.mark.gpu
+def test_memory_length_travels_with_the_folded_buffer(lib):
+    """the memory length used to be mutable state of the shared weights handle, set by whichever ``prepare_memory`` came last.  The sequence
+    forward(cond of length 10) -> prepare_memory(cond of length 15, into=caller's buffer) -> forward(the SAME length-10 cond: cache hit, no re-fold) then read the
+    compact length-10 buffer with the generic length-15 offsets.  The length now travels with the buffer (MDM._bind_memory): the third call must reproduce the first
+    bit for bit, the caller's buffer must still serve a length-15 forward, and a refused ``into`` must leave the handle alone."""
+    from interdiff_amd.mdm import MDM
+    sd = fx.mdm_weights()
+    m = MDM(sd, device=DEV)
+    B, T = 3, 35
+    rs = np.random.RandomState(88)
+    x = torch.from_numpy(rs.standard_normal((B, 1, 144, T)).astype(np.float32)).to(DEV)
+    ts = torch.from_numpy(rs.randint(0, 1000, size=B).astype(np.int64)).to(DEV)
+    c10 = torch.from_numpy(rs.standard_normal((10, B, 256)).astype(np.float32)).to(DEV)
+    c15 = torch.from_numpy(rs.standard_normal((15, B, 256)).astype(np.float32)).to(DEV)
+    first = m(x, ts, y={'cond': c10}).clone()
+    buf = torch.empty(m.memctx_floats(B, 15), dtype=torch.float32, device=DEV)
+    m.prepare_memory(c15, into=buf)
+    again = m(x, ts, y={'cond': c10})
+    assert torch.equal(first, again)
+    assert m.mem_len == 10
+    got15 = m(x, ts, memctx=buf)
+    close(got15, oden.mdm_forward(sd, x.cpu(), ts.cpu(), c15.cpu()), 1e-4, 'caller-owned length-15 memory')
+    assert m.mem_len == 15
+    assert torch.equal(first, m(x, ts, y={'cond': c10}))
+    with pytest.raises(ValueError):
+        m.prepare_memory(c15, into=torch.empty(7, dtype=torch.float32, device=DEV))
+    assert m.mem_len == 10 and torch.equal(first, m(x, ts, y={'cond': c10}))
+
+
+@pytest.mark.gpu
 def test_sampler_with_a_longer_memory_and_a_long_clip(lib, smpl):
     """The lifted limits through the SAMPLER: 30 plain steps + inpainting at memory length 15 (T = 35, the reference's clip length with --past_len 15) on the graph
     route against the CPU oracle's p_sample_loop fed the materialised Philox stream (1e-4), graph route == eager route bit for bit; the same at T = 240 (K/V-tiled

@@ -373,6 +373,7 @@ typedef struct {
      * that the face normal at the vertex is (a - v) x (b - v).  Results (indices included) never depend on the order. */
     const int32_t *vorder, *faces_scan, *markers_scan, *adj_pair_scan;
     const int32_t *adj_pair;   /* nullable [nnz][2]: adj_pair_scan's pairs as ORIGINAL vertex ids (kernels that read vertices from HBM) */
+    const int32_t *vrank;      /* nullable [V]: vertex -> scan position, the inverse of vorder (round 6): the contact scan then reads a frame's vertices in their own order (coalesced) and scatters them into LDS; NULL = gather through vorder, same results */
 } idf_correction_ctx;
 
 size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T);

@@ -59,7 +59,7 @@ class CorrectionCtx(C.Structure):
     _fields_ = [('smpl', C.POINTER(SmplModel)), ('objproj', C.POINTER(ObjProj)),
                 ('faces', vp), ('adj_ptr', vp), ('adj_face', vp), ('adj_corner', vp), ('markers_idx', vp),
                 ('n_markers', i32), ('n_points', i32), ('past_len', i32), ('tune', i32),
-                ('vorder', vp), ('faces_scan', vp), ('markers_scan', vp), ('adj_pair_scan', vp), ('adj_pair', vp)]
+                ('vorder', vp), ('faces_scan', vp), ('markers_scan', vp), ('adj_pair_scan', vp), ('adj_pair', vp), ('vrank', vp)]
 
 
 class OptCtx(C.Structure):

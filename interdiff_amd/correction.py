@@ -43,6 +43,7 @@ class HipCorrection:
             self.markers_scan = self.topo.scan_positions(markers, self.device)
             ctx.vorder, ctx.faces_scan, ctx.markers_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.markers_scan.data_ptr()
             ctx.adj_pair_scan = self.topo.adj_pair_scan.data_ptr()
+            ctx.vrank = self.topo.vrank.data_ptr()
         self.ctx = ctx
         self._ws = {}
         self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call

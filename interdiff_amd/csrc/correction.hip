@@ -179,6 +179,8 @@ __global__ __launch_bounds__(1024) void corr_point_order_kernel(const float *__r
 // of face id -> corner -> three vertex ids), the signed distance, the marker distances.  The per-point loss goes to LDS by scan
 // position and is reduced in a fixed tree: deterministic whatever wave scored the point.
 constexpr int MAXM = 128;
+// sqrtf(d2) < 0.02f  <=>  d2 < MARK_D2: the smallest float whose (correctly rounded) square root is >= 0.02f -- 0x39d1b716, one ulp below 0.02f * 0.02f
+constexpr float MARK_D2 = 0.00039999996079131961f;
 constexpr int CB = 16;                 // vertices per culling / index-bookkeeping block
 constexpr int SB = 8;                  // blocks per super-block (128 vertices): its box is tested first, 8 block tests are skipped at once
 constexpr int SEED_STRIDE = 4;         // the seed looks at the first record of every 4th block
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                                                           const int32_t *__restrict__ adj_corner,
                                                           const int32_t *__restrict__ adj_pair /* nullable [nnz][2]: per incident face the scan positions (a, b): normal += (a - v) x (b - v) */,
                                                           const int32_t *__restrict__ vorder /* nullable [V]: scan position -> vertex */,
+                                                          const int32_t *__restrict__ vrank /* nullable [V]: vertex -> scan position (the inverse): the frame's vertices are then read in their own order */,
                                                           const int32_t *__restrict__ markers_pos /* scan positions */, int M, int B,
                                                           float *__restrict__ markers_out, float *__restrict__ loss_sum,
                                                           float *__restrict__ min_dist, int32_t *__restrict__ label,
@@ -270,13 +273,69 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         ++n_phase;
     };
     phase_done();
-    for (int v = tid; v < L.V4; v += CT) {
-        float x = 3e18f, y = 3e18f, z = 3e18f;                              // past the end: far away
-        if (v < V) {
-            const int o = vorder ? vorder[v] : v;
-            x = vf[3 * o]; y = vf[3 * o + 1]; z = vf[3 * o + 2];
+    // (requested first, consumed behind the record gather: the object transform of the frame and this thread's marker position)
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tr[3] = {0.f, 0.f, 0.f};
+    if constexpr (!OPT) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
+    }
+    const int my_marker_pos = (!OPT && tid < M) ? markers_pos[tid] : 0;
+    // records -> LDS, four scan positions per thread and trip: all four permutation loads fly together, then all twelve coordinate loads (a gather from the skinning
+    // kernel's output through two dependent round trips per TRIP instead of per position: 21 k -> ~8 k cycles of a ~350 k-cycle workgroup, tools/contact_probe.py).  The spare
+    // words of a record pair carry the ORIGINAL vertex ids of its two records: the resolve step below reads them from LDS instead of gathering vorder[] per candidate.
+    if (vorder && vrank) {
+        // with the inverse permutation: vertices in THEIR order (a wave's 12-byte loads cover 768 contiguous bytes instead of 64 cache lines -- the gather below is bound by
+        // line requests: 19 k cycles per workgroup), scattered into LDS by scan position
+        for (int i0 = tid; i0 < V; i0 += 4 * CT) {
+            typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
+            int pos[4];
+            f3v pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(i0 + k * CT, V - 1);
+                pos[k] = vrank[i];
+                pv[k] = *reinterpret_cast<const f3v *>(vf + 3 * i);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k * CT < V) {
+                    lds_rec_store(vs, pos[k], pv[k].x, pv[k].y, pv[k].z);
+                    reinterpret_cast<int *>(vs + 2 * (pos[k] >> 1) + 1)[2 + (pos[k] & 1)] = i0 + k * CT;
+                }
+            }
         }
-        lds_rec_store(vs, v, x, y, z);
+        for (int v = V + tid; v < L.V4; v += CT) {                         // past the end: far away, no vertex
+            lds_rec_store(vs, v, 3e18f, 3e18f, 3e18f);
+            reinterpret_cast<int *>(vs + 2 * (v >> 1) + 1)[2 + (v & 1)] = 0x7fffffff;
+        }
+    } else
+    for (int v0 = tid; v0 < L.V4; v0 += 4 * CT) {
+        int o[4];
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = v0 + k * CT;
+            o[k] = v < V ? (vorder ? vorder[v] : v) : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = y[k] = z[k] = 3e18f;                                       // past the end: far away
+            if (o[k] >= 0) {                                                  // ONE 12-byte load per vertex (global_load_dwordx3): a scattered gather is bound by instructions x lanes, not bytes
+                typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
+                const f3v pv = *reinterpret_cast<const f3v *>(vf + 3 * o[k]);
+                x[k] = pv.x; y[k] = pv.y; z[k] = pv.z;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = v0 + k * CT;
+            if (v < L.V4) {
+                lds_rec_store(vs, v, x[k], y[k], z[k]);
+                reinterpret_cast<int *>(vs + 2 * (v >> 1) + 1)[2 + (v & 1)] = o[k] >= 0 ? o[k] : 0x7fffffff;
+            }
+        }
     }
     if (tid < MAXM) flags[tid] = 0;
     // gridDim.y workgroups share a frame's tasks (OPT: 320 frames on 256 CUs would otherwise take two full rounds)
@@ -286,11 +345,14 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     for (int i = tid; i < MAXP; i += CT) pl[i] = 0.f;
     __syncthreads();
     phase_done();                                                          // 1: records in LDS
-    if (!OPT && tid < M) {
-        const float3 mk = lds_rec(vs, markers_pos[tid]);
-        ms[tid] = make_float4(mk.x, mk.y, mk.z, 0.f);
-        float *mo = markers_out + ((size_t)n * M + tid) * 3;
-        mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
+    if (!OPT && tid < ((M + 1) & ~1)) {                                    // markers as PAIRS, like the vertex records: pair p = markers 2p, 2p + 1 -> {x0 x1 y0 y1}, {z0 z1 - -}; a missing second marker sits far away
+        float3 mk = make_float3(3e18f, 3e18f, 3e18f);
+        if (tid < M) {
+            mk = lds_rec(vs, my_marker_pos);
+            float *mo = markers_out + ((size_t)n * M + tid) * 3;
+            mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
+        }
+        lds_rec_store(ms, tid, mk.x, mk.y, mk.z);
     }
     if (do_nn) {
         // boxes: a wave takes the 64 record pairs of one super-block (8 blocks x 8 pairs), every lane the min / max of its pair; an 8-lane
@@ -326,18 +388,11 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
             lds_rec_store(sd, k, p.x, p.y, p.z);
         }
     }
-    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tr[3] = {0.f, 0.f, 0.f};
-    if constexpr (!OPT) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = objR[n * 9 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tr[k] = objT[n * 3 + k];
-    }
     const float *op = OPT ? pts_frame + (size_t)n * P * 3 : obj_points + (size_t)b * P * 3;
     const int ln = tid & 63, ntask = task1;
     __syncthreads();
     phase_done();                                                          // 2: boxes, markers
-    float mind = FLT_MAX;
+    float mind2 = FLT_MAX;                                                  // squared distance to the nearest marker over this thread's points
     unsigned n_exec = 0, n_test = 0, n_tasks = 0;
     for (;;) {
         int task = 0;
@@ -433,19 +488,17 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
             }
             // resolve inside the winning block: among the records at (or, defensively, below) the minimum the lowest ORIGINAL index
             int pos = bblk, org = 0x7fffffff;
+            auto resolve_pair = [&](int pr) {                 // record pair pr: the same packed distances as the scan (= dist2_exact), original ids from the pair's spare words (0x7fffffff past V)
+                const float4 xy = vs[2 * pr], zz = vs[2 * pr + 1];
+                const v2f d2 = pair_d2(xy, zz);
+                const int o0 = __builtin_bit_cast(int, zz.z), o1 = __builtin_bit_cast(int, zz.w);
+                if (d2.x <= best && o0 < org) { org = o0; pos = 2 * pr; }
+                if (d2.y <= best && o1 < org) { org = o1; pos = 2 * pr + 1; }
+            };
 #pragma unroll
-            for (int u = 0; u < CB; ++u) {
-                const int rp = bblk + u;
-                const float3 p = lds_rec(vs, rp);
-                const int o = rp < V ? (vorder ? vorder[rp] : rp) : 0x7fffffff;
-                if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) <= best && o < org) { org = o; pos = rp; }
-            }
+            for (int u = 0; u < CB / 2; ++u) resolve_pair((bblk >> 1) + u);
             if (tie) {                                    // the minimum was met again in a later block: settle it over all records
-                for (int rp = 0; rp < V; ++rp) {
-                    const float3 p = lds_rec(vs, rp);
-                    const int o = vorder ? vorder[rp] : rp;
-                    if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) <= best && o < org) { org = o; pos = rp; }
-                }
+                for (int pr = 0; pr < (V + 1) / 2; ++pr) resolve_pair(pr);
             }
             pos = min(pos, V - 1);
             if (org == 0x7fffffff) org = vorder ? vorder[pos] : pos;      // NaN input: nothing compared equal
@@ -491,12 +544,22 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
             }
         }
         if (!OPT && valid) {
-            for (int m = 0; m < M; ++m) {
-                const float4 mk = ms[m];
-                const float dx = mk.x - qx, dy = mk.y - qy, dz = mk.z - qz;
-                const float dm = sqrtf(dx * dx + dy * dy + dz * dz);
-                mind = fminf(mind, dm);
-                if (dm < 0.02f) flags[m] = 1;                                // benign race: all writers store 1
+            // Marker distances (eval_smpl_short.py:110-112: contact label = some object point within 2 cm of the marker; min over everything for the clip's condition),
+            // two markers per packed instruction, WITHOUT a square root per pair: sqrtf is monotone and correctly rounded, so min_m sqrtf(d2_m) = sqrtf(min_m d2_m)
+            // (one root per workgroup, below) and sqrtf(d2) < 0.02f <=> d2 < MARK_D2 -- the smallest float whose root is >= 0.02f (tests/test_abi_and_host.py re-derives it).
+            // d2 keeps the roundings the scalar form compiled to: fma(dy, dy, dx * dx) + dz * dz.  (Round 6: the correctly-rounded root, its fix-up and an exec-mask write
+            // per marker were 35 instructions x 67 markers per task, a quarter of the kernel.)
+#pragma clang fp contract(off)
+            const v2f QX = v2f{qx, qx}, QY = v2f{qy, qy}, QZ = v2f{qz, qz};
+            for (int p2 = 0; p2 < (M + 1) / 2; ++p2) {
+                const float4 xy = ms[2 * p2], zz = ms[2 * p2 + 1];
+                const v2f dx = v2f{xy.x, xy.y} - QX, dy = v2f{xy.z, xy.w} - QY, dz = v2f{zz.x, zz.y} - QZ;
+                const v2f d2 = __builtin_elementwise_fma(dy, dy, dx * dx) + dz * dz;
+                mind2 = fminf(fminf(mind2, d2.x), d2.y);
+                if (__builtin_amdgcn_ballot_w64(fminf(d2.x, d2.y) < MARK_D2) != 0ull) {      // wave-uniform, rare
+                    if (d2.x < MARK_D2) flags[2 * p2] = 1;                     // benign race: all writers store 1
+                    if (d2.y < MARK_D2) flags[2 * p2 + 1] = 1;                 // (the dummy of an odd count is infinitely far: never)
+                }
             }
         }
     }
@@ -521,13 +584,13 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
     }
     const float loss_total = red[0];
     __syncthreads();
-    red[tid] = mind;
+    red[tid] = mind2;
     __syncthreads();
     for (int s = CT / 2; s > 0; s >>= 1) {
         if (tid < s) red[tid] = fminf(red[tid], red[tid + s]);
         __syncthreads();
     }
-    if (tid == 0) { loss_sum[n] = loss_total; min_dist[n] = red[0]; }
+    if (tid == 0) { loss_sum[n] = loss_total; min_dist[n] = red[0] == FLT_MAX ? FLT_MAX : sqrtf(red[0]); }      // the one root of the frame (monotone: = the minimum of the roots)
     if (tid < M) label[(size_t)n * M + tid] = flags[tid];
     phase_done();                                                          // 5: reductions
     if (stats && tid == 0 && do_nn) atomicAdd(stats + 3, 1ull);            // workgroups counted
@@ -553,7 +616,7 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
     static std::atomic<uint64_t> lds_ok{0};
     if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<false>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel<false>, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, porder, objR, objT, faces,
-                       c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
+                       c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, c->vrank, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
                        stats, nn_from, nullptr, 0);
     return IDF_OK;
 }
@@ -734,7 +797,7 @@ int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *
     static std::atomic<uint64_t> lds_ok{0};
     if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<true>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel<true>, dim3((unsigned)N, 2), dim3(CT), lds, s, verts, V, obj_points, P, porder, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, c->vorder, nullptr, 0, B, nullptr, nullptr, nullptr, nullptr, nullptr, yidx, nullptr, (int64_t)0,
+                       nullptr, nullptr, nullptr, nullptr, c->vorder, c->vrank, nullptr, 0, B, nullptr, nullptr, nullptr, nullptr, nullptr, yidx, nullptr, (int64_t)0,
                        pts_frame, frames_per_clip);
     return IDF_OK;
 }

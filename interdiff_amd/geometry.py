@@ -49,7 +49,7 @@ class MeshTopology:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.V = V
         self.faces, self.adj_ptr, self.adj_face, self.adj_corner = t(f.astype(np.int32)), t(ptr), t(adj_face), t(adj_corner)
-        self.vorder = self.faces_scan = self.rank = self.adj_pair_scan = None
+        self.vorder = self.faces_scan = self.rank = self.adj_pair_scan = self.vrank = None
         # per adjacency entry (vertex v, face, corner c) the other two corners (a, b) with normal contribution (a - v) x (b - v):
         # data/tools.py:27-39 accumulates cross(v2 - v1, v0 - v1) at corner 1, cross(v0 - v2, v1 - v2) at 2, cross(v1 - v0, v2 - v0) at 0
         fa, co = adj_face.astype(np.int64), adj_corner.astype(np.int64)
@@ -63,6 +63,7 @@ class MeshTopology:
             self.rank = rank                                        # vertex -> scan position (host)
             self.vorder, self.faces_scan = t(order.astype(np.int32)), t(rank[f].astype(np.int32))
             self.adj_pair_scan = t(rank[pair].astype(np.int32))
+            self.vrank = t(rank.astype(np.int32))                    # vertex -> scan position on the device: the contact scan reads a frame's vertices coalesced and scatters them
 
     def scan_positions(self, vertex_ids, device):
         """Scan positions of the given vertices (e.g. the marker set) as a device int32 tensor."""

@@ -35,6 +35,7 @@ class PhysicsOptimizer:
             self._markers_scan = self.topo.scan_positions([0], self.device)
             geo.vorder, geo.faces_scan, geo.adj_pair_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.topo.adj_pair_scan.data_ptr()
             geo.markers_scan = self._markers_scan.data_ptr()
+            geo.vrank = self.topo.vrank.data_ptr()
         self.geo = geo
         # constants of the backward pass: the blend basis transposed (k-major rows, zero padded to the split-K slice) and
         # the skinning weights regrouped by joint

@@ -655,3 +655,22 @@ def test_qkv_plane_bounds_hold_and_keep_the_split_in_range():
     W3[5] *= 8.0                                                   # one outlier row inside a head: 8x is within the slack that is tolerated (3 of 22 bits)
     assert qkv_bounds_usable(W3, b, qkv_bounds(W3, b))
     assert not qkv_bounds_usable(W * np.float32(1e25), b, qkv_bounds(W * np.float32(1e25), b))      # far from overflow, as before
+
+
+def test_marker_contact_threshold_constant_is_the_exact_one():
+    """csrc/correction.hip tests d2 < MARK_D2 instead of sqrtf(d2) < 0.02f (eval_smpl_short.py:110-112) -- valid because a correctly rounded square root is monotone:
+    MARK_D2 must be THE smallest float whose root is >= 0.02f.  Re-derived here from the definition and compared with the literal in the source; a neighbourhood of
+    floats around it is checked element by element."""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'interdiff_amd', 'csrc', 'correction.hip')).read()
+    lit = np.float32(float(re.search(r'constexpr float MARK_D2 = ([0-9.eE+-]+)f;', src).group(1)))
+    t = np.float32(0.02)
+    x = np.float32(t * t)
+    while np.sqrt(x, dtype=np.float32) >= t:
+        x = np.nextafter(x, np.float32(0), dtype=np.float32)
+    theta = np.nextafter(x, np.float32(1), dtype=np.float32)
+    assert lit.view(np.uint32) == theta.view(np.uint32) == 0x39d1b716
+    bits = np.arange(int(theta.view(np.uint32)) - 2000, int(theta.view(np.uint32)) + 2000, dtype=np.uint32)
+    d2 = bits.view(np.float32)
+    assert np.array_equal(np.sqrt(d2, dtype=np.float32) < t, d2 < theta)
+    assert np.array_equal(np.sqrt(d2.astype(np.float64)).astype(np.float32) < t, d2 < theta)      # (a double root rounded to float is the correctly rounded float root)

@@ -19,7 +19,7 @@ def morton(p, bits=10):
             code |= ((q[:, a] >> b) & 1) << (3*b + a)
     return np.argsort(code, kind='stable')
 
-def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, seedmode='rep'):
+def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, seedmode='rep', order='scan', SBLK=8):
     verts = smpl_forward(model, pose, betas, trans)[0].numpy().astype(np.float32)   # [N,V,3]
     vt = model['v_template'].numpy()
     vord = morton(vt)
@@ -53,7 +53,19 @@ def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, se
             sl = slice(128*w, 128*w+128)
             best = best0[sl].copy()
             ne = 0
-            for cb in range(nCB):
+            visit = range(nCB)
+            if order != 'scan':                        # start at the super-block of the seed nearest to the task's closest point and walk outwards (super-block granularity, round 6)
+                seeds = d2p[sl][:, ::4, 0]                                    # the kernel's seed records: first record of every 4th block
+                lane = seeds.min(1).argmin()
+                sb0 = (int(seeds[lane].argmin()) * 4) // SBLK
+                nSB = (nCB + SBLK - 1) // SBLK
+                sbs = [sb0]
+                for k in range(1, nSB):
+                    for c in (sb0 + k, sb0 - k):
+                        if 0 <= c < nSB:
+                            sbs.append(c)
+                visit = [cb for sb in sbs for cb in range(sb * SBLK, min((sb + 1) * SBLK, nCB))]
+            for cb in visit:
                 need = lb[sl, cb] <= best
                 if need.any():
                     ne += 1; lane_need += need.sum()
@@ -64,6 +76,7 @@ def sim(model, pose, betas, trans, objR, objT, pts, CB=16, coherent_pts=True, se
 if __name__ == '__main__':
     coherent = 'coherent' in sys.argv[1:]
     SEED = 'perfect' if 'perfect' in sys.argv[1:] else 'rep'
+    ORDER = 'outward' if 'outward' in sys.argv[1:] else 'scan'
     kw = dict(coherent=True) if coherent else {}
     model = {k: torch.from_numpy(v) for k, v in syn.smplh_model(7, **kw).items()}
     bt = syn.make_clip_batch(seed=233, B=4, T=100, n_points=2048)
@@ -82,10 +95,10 @@ if __name__ == '__main__':
         trans = torch.stack([x[t, b, 132:135] for t, b in fr])
         objR = R.rotation_6d_to_matrix(torch.stack([x[t, b, 135:141] for t, b in fr])).numpy()
         objT = torch.stack([x[t, b, 141:144] for t, b in fr]).numpy()
-        for CB in (8, 16, 32):
+        for CB in ((16,) if ORDER != 'scan' else (8, 16, 32)):
             fs = []
             for i, (t, b) in enumerate(fr):
-                f = sim(model, pose[i:i+1], betas[i:i+1], trans[i:i+1], objR[i:i+1], objT[i:i+1], bt['obj_points'][b], CB=CB, seedmode=SEED)
+                f = sim(model, pose[i:i+1], betas[i:i+1], trans[i:i+1], objR[i:i+1], objT[i:i+1], bt['obj_points'][b], CB=CB, seedmode=SEED, order=ORDER)
                 fs.append(f)
             fs = np.array(fs)
             print(mode, 'coherent' if coherent else 'default', 'CB', CB, 'exec frac mean %.3f min %.3f max %.3f | lane-need %.3f' % (fs[:,0].mean(), fs[:,0].min(), fs[:,0].max(), fs[:,1].mean()))

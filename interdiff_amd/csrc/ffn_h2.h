@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
     // (argument order: the first 14 dwords -- what the weight stream and the row requests need -- arrive preloaded in SGPRs: build.py)
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     asm volatile("" ::: "v255");                       // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
-    float *Xs = smem, *ring = smem + QBM * 256, *Sc = ring + 3 * (QSTEP / 4);      // Sc [32]: 2^e of every row
+    float *Xs = smem, *ring = smem + QBM * 256, *Sc = ring + 3 * (QSTEP / 4), *Sd = Sc + QBM;      // Sc [32]: 2^e of every row; Sd [32][8] (PLANES): the row's q / k / v dividers and their inverses
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int mt, sl;
@@ -669,23 +669,31 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
             }
         }
     }
+    if constexpr (PLANES) {
+        // the three powers of two a row's q / k / v outputs are divided by depend on the ROW alone (its input scale and the layer's static bounds): derived ONCE per row here, by the
+        // row's own thread, next to the staging writes (round 5 derived all three in every 8-output item of the pass below: ~20 of its ~50 instructions)
+        if (tid < QBM) {
+            const float wq = bnd6[0], wk = bnd6[1], wv = bnd6[2], bq = bnd6[3], bk = bnd6[4], bvv = bnd6[5];
+            auto down = [](float bound, float &up) {                         // bound < 2^E: multiplier 2^(15 - E) (|v| 2^(15 - E) < 2^15) and, through `up`, 2^(E - 15)
+                const int E = (int)((__builtin_bit_cast(uint32_t, fmaxf(bound, 1e-30f)) >> 23) & 0xff) - 126;
+                up = __builtin_bit_cast(float, (uint32_t)((127 + E - 15) << 23));
+                return __builtin_bit_cast(float, (uint32_t)((127 + 15 - E) << 23));
+            };
+            const float e2 = Sc[tid];
+            float uq, uk, uv;
+            const float dq = down(e2 * wq + bq, uq), dk = down(e2 * wk + bk, uk), dv = down(e2 * wv + bvv, uv);
+            *reinterpret_cast<float4 *>(Sd + 8 * tid) = make_float4(dq, dk, dv, 0.f);
+            *reinterpret_cast<float4 *>(Sd + 8 * tid + 4) = make_float4(uq, uk, uv, 0.f);
+        }
+    }
     __syncthreads();
     if constexpr (PLANES) {
-        const float wq = bnd6[0], wk = bnd6[1], wv = bnd6[2], bq = bnd6[3], bk = bnd6[4], bvv = bnd6[5];
-        auto down = [](float bound, float &up) {                         // bound < 2^E: multiplier 2^(15 - E) (|v| 2^(15 - E) < 2^15) and, through `up`, 2^(E - 15)
-            const int E = (int)((__builtin_bit_cast(uint32_t, fmaxf(bound, 1e-30f)) >> 23) & 0xff) - 126;
-            up = __builtin_bit_cast(float, (uint32_t)((127 + E - 15) << 23));
-            return __builtin_bit_cast(float, (uint32_t)((127 + 15 - E) << 23));
-        };
 #pragma unroll
         for (int it = 0; it < (QBM * (QHS / 8) + NT - 1) / NT; ++it) {
             const int idx = tid + it * NT, row = idx / (QHS / 8), c8 = (idx - row * (QHS / 8)) << 3, gr = m0 + row, gc = n0 + c8;
             if (idx < QBM * (QHS / 8) && gr < M && gc < N) {
                 const int t = gc >> 8, grp = gc >> 6, o = gc & 63;
-                const float e2 = Sc[row];
-                float uq, uk, uv;
-                const float dq = down(e2 * wq + bq, uq), dk = down(e2 * wk + bk, uk), dv = down(e2 * wv + bvv, uv);
-                const float dn = t == 0 ? dq : (t == 1 ? dk : dv);
+                const float dn = Sd[8 * row + t];
                 const float4 v0 = *reinterpret_cast<const float4 *>(Cs + row * QCS + c8), v1 = *reinterpret_cast<const float4 *>(Cs + row * QCS + c8 + 4);
                 uint2 h0, l0, h1, l1;
                 split4_pk(make_float4(v0.x * dn, v0.y * dn, v0.z * dn, v0.w * dn), h0, l0);
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
                 float *dst = planes_out + ((size_t)gr * 12 + grp) * 64 + (o >> 1);      // (float words: 128 halves per (row, group); hi plane first)
                 idf_store16_wt(dst, __builtin_bit_cast(float4, make_uint4(h0.x, h0.y, h1.x, h1.y)));
                 idf_store16_wt(dst + 32, __builtin_bit_cast(float4, make_uint4(l0.x, l0.y, l1.x, l1.y)));
-                if (sl == 0 && c8 == 0) idf_store16_wt(scales_out + (size_t)gr * 4, make_float4(uq, uk, uv, 0.f));
+                if (sl == 0 && c8 == 0) idf_store16_wt(scales_out + (size_t)gr * 4, *reinterpret_cast<const float4 *>(Sd + 8 * row + 4));
             }
         }
     } else {

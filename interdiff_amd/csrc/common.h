@@ -124,7 +124,7 @@ static inline int idf_exclusive_cu(const void *fn, const char *name, int threads
         e.dyn_lds = IDF_CU_LDS_BYTES - e.static_lds;
         if (e.dyn_lds >= 0 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.dyn_lds) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&e.blocks_per_cu, fn, threads, (size_t)e.dyn_lds) == hipSuccess)
-            e.ok = e.blocks_per_cu == 1 && e.num_regs >= 256 ? 1 : 0;
+            e.ok = e.blocks_per_cu == 1 && e.num_regs >= (threads > 512 ? 128 : 256) ? 1 : 0;      // (a 1024-thread workgroup is four waves per SIMD: 4 x 128 = the file)
     }
     (void)hipGetLastError();                             // a refused attribute must not surface as the next launch's error
     if (e.ok && idf_excl_denied(name)) { e.ok = 0; e.denied = 1; }

@@ -32,7 +32,7 @@
 static inline int idf_launch_layer_ffn(hipStream_t s, const idf_mdm_layer &ly, const float *ar, const int32_t *tune, const float *x2, int M, float *parts) {
     int rows = idf_ffn::ffn_rows_of_tune(tune[IDF_TUNE_FFN]);
     if (tune[IDF_TUNE_FFN_MATH] != 0 && ly.ffn_pack_h2 != 0) {
-        const int rc = idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows ? rows : idf_ffn::ffn_tile_for_rows(M), tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : (tune[IDF_TUNE_MISC] == 6 ? 3 : 0)));      // (MISC = 2 / 3 / 6: slice-major affine ids / plain ids / three ring slots, A/B only: ffn_h2.h)
+        const int rc = idf_ffn_h2::launch_ffn_h2(s, x2, M, ar + ly.ffn_pack_h2, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows ? rows : idf_ffn::ffn_tile_for_rows(M), tune[IDF_TUNE_MISC] == 2 ? 1 : (tune[IDF_TUNE_MISC] == 3 ? 2 : (tune[IDF_TUNE_MISC] == 6 ? 3 : (tune[IDF_TUNE_MISC] == 10 ? 4 : 0))));      // (MISC = 2 / 3 / 6 / 10: slice-major affine ids / plain ids / three ring slots / eight waves without loaders, A/B only: ffn_h2.h)
         if (rc != IDF_NOT_EXCLUSIVE) return rc;        // (the kernel does not get its CU on this device -- common.h idf_exclusive_cu: the exact kernel below)
     }
     idf_ffn::launch_ffn(s, x2, M, ar + ly.ffn_pack, ar + ly.ffn_b1p, ar + ly.ff2_b, parts, rows);
@@ -1650,7 +1650,7 @@ template __global__ void rowblock8_kernel<true, NSL, MEM, 8>(const float *, int,
                                                              const float *);
 }  // namespace
 template __global__ void idf_attn_h2::self_attn_h2_kernel<0, true>(const float *, int, int, const float *, float *, size_t, const float *);
-template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0>(const float *, int, int, const float *, const float *, const float *, float *, int);
+template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0, 8>(const float *, int, int, const float *, const float *, const float *, float *, int);
 template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
                                                                   int64_t *, int64_t *, float *, float *);
 template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int,
@@ -2119,6 +2119,7 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
         using namespace idf_ffn_h2;
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<1, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<16 rows>", NT, c[0]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<32 rows>", NT, c[1]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0, 8>), "ffn_h2_kernel<32 rows, loader waves>", NT + 512, c[6]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<4, 2, 0>), "ffn_h2_kernel<64 rows>", NT, c[2]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1, false>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES, false>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);

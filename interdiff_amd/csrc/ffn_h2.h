@@ -160,8 +160,12 @@ __device__ __forceinline__ void idf_sload16(const float *p, f4s &a, f4s &b, f4s 
 // LDS: BM KiB of planes + S x 32 KiB ring = 144 / 160 / 128 KiB (the launcher asks for all 160 either way: exclusive CU).
 // MODE 0 is the product kernel; 1 = no MFMAs, 2 = no DMA after the prologue, 3 = phase stamps of thread 0 behind the slabs, 4 = no slab stores
 // (tools/ffn_h2_probe.hip only; `if constexpr` keeps every trace of them out of MODE 0).
-template <int TT, int S, int MODE = 0>
-__global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2, int M, int nwg, const float *__restrict__ pack,
+// LW = LOADER waves (round 6; 0 or 8): with 8, the workgroup is sixteen waves at 128 registers each (still the whole register file) and the weight ring is fed by waves 8..15 alone --
+// they issue every LDS-DMA piece of a step (three or four each) and own every vmcnt wait -- while waves 0..7 compute exactly as before without ever touching the vector-memory issue:
+// a wave that issues a 1-KiB piece SITS in its issue slot until the CU's request path takes it (60-100 cycles apiece with eight waves asking), which is what a K step cost beyond its
+// 192-384 MFMA cycles (tools/experiments/ffn_h2f.h measured it).  Same instructions per accumulator: same bits.
+template <int TT, int S, int MODE = 0, int LW = 0>
+__global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__restrict__ x2, int M, int nwg, const float *__restrict__ pack,
                                                      const float *__restrict__ b1p, const float *__restrict__ b2,
                                                      float *__restrict__ parts, int order) {
     constexpr int BM = 16 * TT;
@@ -169,13 +173,19 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     static_assert(BM * 1024 + S * SLOT <= 160 * 1024, "LDS");
     static_assert(TT == 4 ? BM * CSS * 4 <= BM * 1024 + S * SLOT : BM * CSS * 4 <= 2 * SLOT, "output staging");
     extern __shared__ __attribute__((aligned(1024))) float smem[];
-    asm volatile("" ::: "v255");                       // the whole register file: see EXCLUSIVE CU below
+    static_assert(LW == 0 || LW == 8, "loader waves");
+    if constexpr (LW == 0) asm volatile("" ::: "v255");            // the whole register file: see EXCLUSIVE CU below
+    else asm volatile("" ::: "v127");                              // (sixteen waves: four per SIMD x 128)
+    constexpr int NTH = NT + 64 * LW;                              // threads of the workgroup
     float *Xs = smem;                                              // planes: row r at r KiB = [hi 512 B | lo' 512 B]
     float *ring = smem + BM * 256;                  // (the slice's linear1 bias comes through the scalar cache: with four ring slots the planes and the ring are the whole 160 KiB)
     // (all 13 argument dwords -- the grid size among them, instead of gridDim.x from the hidden block -- arrive preloaded in SGPRs: build.py; no argument-segment read before the first DMA)
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= NW;                      // waves 8..15: the weight stream and nothing else
+    const bool issues = LW == 0 || loader;                         // this wave issues (and waits for) ring pieces
+    const int iw = LW > 0 ? (wave & 7) : wave;                     // its index among the issuing waves
     long long *stamps = nullptr;
     int n_stamp = 0;
     if constexpr (MODE == 3) stamps = reinterpret_cast<long long *>(parts + (size_t)NSL * M * D) + (size_t)blockIdx.x * 32;
@@ -199,12 +209,12 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     const int sl = order == 1 ? wg / nmt : (order == 2 ? id % NSL : wg % NSL), mt = order == 1 ? wg - sl * nmt : (order == 2 ? id / NSL : wg / NSL), m0 = mt * BM;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * SLICE_FLOATS);
     const uint32_t lane16 = lane << 4;
-    const uint32_t vsrc = (uint32_t)(wave * 1024) + lane16;                 // this lane's 16 B inside a step: instruction wave + 8 j adds 8192 j
-    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);     // LDS byte address of this wave's first instruction in slot 0
-    const bool lt2 = wave < 2;                                              // 26 = 3 * 8 + 2: waves 0 and 1 issue a 4th instruction for a phase-1 step
+    const uint32_t vsrc = (uint32_t)(iw * 1024) + lane16;                   // this lane's 16 B inside a step: instruction iw + 8 j adds 8192 j
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(iw * 1024);       // LDS byte address of this wave's first instruction in slot 0
+    const bool lt2 = iw < 2;                                                // 26 = 3 * 8 + 2: issuing waves 0 and 1 issue a 4th instruction for a phase-1 step
 
-    auto issue_step = [&](int P) {                    // DMA instructions of step P: instruction i = wave + 8 j copies stream bytes [step_off + 1024 i, +1024) to slot P % S
-        if (P >= NPAIR) return;
+    auto issue_step = [&](int P) {                    // DMA instructions of step P: instruction i = iw + 8 j copies stream bytes [step_off + 1024 i, +1024) to slot P % S
+        if (P >= NPAIR || !issues) return;
         if constexpr (MODE == 2) { if (P >= S - 1) return; }
         const int nins = step_ins(P);
         const uint32_t so = (uint32_t)step_off(P), dof = (uint32_t)((P % S) * SLOT);
@@ -226,23 +236,26 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
                 ragged += step_ins(Q) % 8 != 0 ? 1 : 0;
             }
         }
+        if (!issues) return;
         if (lt2) wait_vmcnt(flying + ragged);
         else wait_vmcnt(flying);
     };
 
     // ---- prologue: bias slice, x2 rows (fp32, row r at r KiB, linear), the first S - 1 steps
     const uint32_t xs_lds = idf_lds_addr(Xs);
+    if (!loader) {
 #pragma unroll
-    for (int j = 0; j < BM / NW; ++j) {
-        const int i = wave + NW * j;
-        idf_dma16_s(idf_uniform_ptr(x2 + (size_t)min(m0 + i, M - 1) * D), lane16, xs_lds + (uint32_t)(i * 1024));
+        for (int j = 0; j < BM / NW; ++j) {
+            const int i = wave + NW * j;
+            idf_dma16_s(idf_uniform_ptr(x2 + (size_t)min(m0 + i, M - 1) * D), lane16, xs_lds + (uint32_t)(i * 1024));
+        }
     }
 #pragma unroll
     for (int P = 0; P < S - 1; ++P) issue_step(P);
     // linear1 bias of this wave's one or two hidden tiles (phase 1 tile map below: 2 w, 2 w + 1 for waves 0..4, else 5 + w): sixteen floats each, through the scalar cache,
     // behind the DMA issue (the wave is about to wait for its rows anyway); b1p carries 256 spare floats, so the second tile's address is valid for every wave
     f4s bias_s[2][4];
-    {
+    if (!loader) {
         const int hb = wave < 5 ? 2 * wave : 5 + wave;
         idf_sload16(b1p + sl * HS + hb * 16, bias_s[0][0], bias_s[0][1], bias_s[0][2], bias_s[0][3]);
         idf_sload16(b1p + sl * HS + (hb + 1) * 16, bias_s[1][0], bias_s[1][1], bias_s[1][2], bias_s[1][3]);
@@ -251,19 +264,25 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         int younger = 0;
 #pragma unroll
         for (int P = 0; P < S - 1; ++P) younger += step_ins(P) / 8;         // + 1 for waves 0, 1 per ragged step
-        if (lt2) wait_vmcnt(younger + (S - 1));
-        else wait_vmcnt(younger);
+        if constexpr (LW > 0) {
+            if (!loader) wait_vmcnt(0);                                     // (a computing wave issued nothing but its rows)
+        } else {
+            if (lt2) wait_vmcnt(younger + (S - 1));
+            else wait_vmcnt(younger);
+        }
     }
     // split the rows this wave fetched, in place: lane l holds k = 4l .. 4l+3 of row r -> chunk l >> 1, half (l & 1)
+    if (!loader) {
 #pragma unroll
-    for (int j = 0; j < BM / NW; ++j) {
-        const int r = wave + NW * j;
-        const float4 v = *reinterpret_cast<const float4 *>(Xs + r * 256 + lane * 4);
-        uint2 hi, lo;
-        split4_pk(v, hi, lo);
-        float *dst = Xs + r * 256 + ((((lane >> 1) ^ (r & 15)) << 2)) + ((lane & 1) << 1);
-        *reinterpret_cast<uint2 *>(dst) = hi;
-        *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        for (int j = 0; j < BM / NW; ++j) {
+            const int r = wave + NW * j;
+            const float4 v = *reinterpret_cast<const float4 *>(Xs + r * 256 + lane * 4);
+            uint2 hi, lo;
+            split4_pk(v, hi, lo);
+            float *dst = Xs + r * 256 + ((((lane >> 1) ^ (r & 15)) << 2)) + ((lane & 1) << 1);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        }
     }
 
     // ---- tile maps.  Phase 1: 13 hidden tiles: waves 0..4 own two (2w, 2w+1), waves 5..7 one (10, 11, 12); every wave covers all TT
@@ -342,18 +361,20 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     // The DMA issue is what a K step costs now (26 - 32 instructions per step at the CU's ~20 cycles apiece; the MFMAs of a step are 192
     // cycles per wave), and a wave sits in its own issue: the two waves of a SIMD (w, w + 4) therefore take turns -- waves 0..3 refill
     // the ring BEFORE their fragment reads and MFMAs, waves 4..7 AFTER theirs -- so that one wave's issue runs beside the other's matrix work.
-    const bool early = S == 2 || wave < NW / 2;       // (a two-slot ring has no slack for the late group: its refill would land just before the wait for it)
+    const bool early = LW > 0 || S == 2 || wave < NW / 2;       // (a two-slot ring has no slack for the late group: its refill would land just before the wait for it; loader waves: nothing to wait behind)
     stamp();                                          // 1: x2 rows fetched and split
 #pragma unroll
     for (int P = 0; P < KS1; ++P) {
         publish(P);                                   // (P = 0: also publishes the planes)
         stamp();                                      // 2 + P: step P published
         if (early) issue_step(P + S - 1);             // into the slot of step P - 1
-        read1(P, F[P & 1]);
-        if (P > 0) mma(F[(P - 1) & 1], two1);
+        if (!loader) {
+            read1(P, F[P & 1]);
+            if (P > 0) mma(F[(P - 1) & 1], two1);
+        }
         if (!early) issue_step(P + S - 1);
     }
-    mma(F[(KS1 - 1) & 1], two1);
+    if (!loader) mma(F[(KS1 - 1) & 1], two1);
 
     // ---- hid = gelu(acc + b1), split, over the x2 planes (every wave is past its last read of them behind the next barrier)
     publish(KS1);                                     // first phase-2 step has landed too
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     issue_step(KS1 + S - 1);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        if (a == 0 || two1) {
+        if (!loader && (a == 0 || two1)) {
             const f4s bsel = g == 0 ? bias_s[a][0] : (g == 1 ? bias_s[a][1] : (g == 2 ? bias_s[a][2] : bias_s[a][3]));      // lane group g takes hidden units 4 g .. 4 g + 3 of the tile
             const float4 bv = make_float4(bsel[0], bsel[1], bsel[2], bsel[3]);
             const int chunk = 2 * (h0 + a) + (g >> 1);
@@ -394,8 +415,8 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     stamp();                                          // 11: GELU phase done
 
     // ---- phase 2: part^T[out][token] = W2[:, slice] . hid^T
-    read2(0, F[0]);
-    constexpr int NST = BM * (D / 4) / NT;            // float4 stores per thread
+    if (!loader) read2(0, F[0]);
+    constexpr int NST = BM * (D / 4) / NTH, NWT = NTH / 64;            // float4 stores per thread; waves of the workgroup
     float4 xres[NST], bres = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 1; q < KS2; ++q) {
@@ -406,13 +427,15 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
             bres = *reinterpret_cast<const float4 *>(b2 + ((tid & 63) << 2));
 #pragma unroll
             for (int it = 0; it < NST; ++it)
-                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + (tid >> 6) + it * NW, M - 1) * D + ((tid & 63) << 2));
+                xres[it] = *reinterpret_cast<const float4 *>(x2 + (size_t)min(m0 + (tid >> 6) + it * NWT, M - 1) * D + ((tid & 63) << 2));
         }
-        read2(q, F[q & 1]);
-        mma(F[(q - 1) & 1], true);
+        if (!loader) {
+            read2(q, F[q & 1]);
+            mma(F[(q - 1) & 1], true);
+        }
         if (!early) issue_step(KS1 + q + S - 1);
     }
-    mma(F[(KS2 - 1) & 1], true);
+    if (!loader) mma(F[(KS2 - 1) & 1], true);
 
     // ---- partial tile leaves through LDS as 16-byte row stores.  TT <= 2: staged in ring slots 0 / 1 (the last step, still being read by
     // slower waves, sits in slot (NPAIR - 1) % 3 = 2); TT = 4: over the planes and slot 0, once every wave is done reading them.
@@ -421,6 +444,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
     }
+    if (!loader)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(NT) void ffn_h2_kernel(const float *__restrict__ x2
     float *out = parts + (size_t)sl * M * D;
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
-        const int row = (tid >> 6) + it * NW, c4 = (tid & 63) << 2, gr = m0 + row;
+        const int row = (tid >> 6) + it * NWT, c4 = (tid & 63) << 2, gr = m0 + row;
         if (gr >= M) continue;
         float4 v = *reinterpret_cast<const float4 *>(Cs + row * CSS + c4);
         if (sl == 0) {
@@ -464,14 +488,16 @@ constexpr int LDS_REQUEST = 160 * 1024;
 #define IDF_FFN_H2_SLOTS 4
 #endif
 constexpr int FFN_H2_SLOTS = IDF_FFN_H2_SLOTS;            // ring slots of the 16- and 32-row kernels: 4 = planes + ring fill the CU's LDS exactly (3: rounds 4a; -D for A/B)
-template <int TT, int S>
+template <int TT, int S, int LW = 0>
 inline int launch_h2_tt(hipStream_t s, const float *x2, int M, const float *pack, const float *b1p, const float *b2, float *parts, int order) {
     constexpr int BM = 16 * TT;
     static_assert(BM * 1024 + S * SLOT <= LDS_REQUEST, "LDS");
     static idf_excl_cache excl;
-    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0>), TT == 1 ? "ffn_h2_kernel<16 rows>" : (TT == 2 ? "ffn_h2_kernel<32 rows>" : "ffn_h2_kernel<64 rows>"), NT, excl);
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, 0, LW>),
+                                     LW ? (TT == 1 ? "ffn_h2_kernel<16 rows, loader waves>" : (TT == 2 ? "ffn_h2_kernel<32 rows, loader waves>" : "ffn_h2_kernel<64 rows, loader waves>"))
+                                        : (TT == 1 ? "ffn_h2_kernel<16 rows>" : (TT == 2 ? "ffn_h2_kernel<32 rows>" : "ffn_h2_kernel<64 rows>")), NT + 64 * LW, excl);
     if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;            // (the kernel has no static LDS: its dynamic request IS the CU's 160 KiB)
-    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT), LDS_REQUEST, s, x2, M, (int)(idf_cdiv(M, BM) * NSL), pack, b1p, b2, parts, order);
+    hipLaunchKernelGGL((ffn_h2_kernel<TT, S, 0, LW>), dim3((unsigned)(idf_cdiv(M, BM) * NSL)), dim3(NT + 64 * LW), LDS_REQUEST, s, x2, M, (int)(idf_cdiv(M, BM) * NSL), pack, b1p, b2, parts, order);
     return IDF_OK;
 }
 // rows: 16 / 32 / 64 = the M tile (csrc/ffn.h ffn_tile_for_rows picks it from the launch's rows when 0); all three produce the same bits
@@ -484,7 +510,11 @@ inline int launch_ffn_h2(hipStream_t s, const float *x2, int M, const float *pac
     }
     if (rows == 16) return launch_h2_tt<1, FFN_H2_SLOTS>(s, x2, M, pack, b1p, b2, parts, order);
     if (rows == 64) return launch_h2_tt<4, 2>(s, x2, M, pack, b1p, b2, parts, order);
-    return launch_h2_tt<2, FFN_H2_SLOTS>(s, x2, M, pack, b1p, b2, parts, order);
+    // 32 rows: sixteen waves, eight of them loaders (round 6: -5.5 % per launch back to back, 10.5 -> 9.9 us: shorter prologue, 16 waves on the slab stores, the GELU phase with the ring kept full;
+    // the K steps themselves do not move: they run at the ~45 B/clk a CU gets from its XCD's L2 -- profiles/r06_ffn_loader_waves.txt).  The 16-row tile gains 1 %, the 64-row tile does not fit
+    // 128 registers: both keep eight waves.  order 4 (A/B only, tune[IDF_TUNE_MISC] = 10): the eight-wave form of rounds 4-5.
+    if (order == 4) return launch_h2_tt<2, FFN_H2_SLOTS>(s, x2, M, pack, b1p, b2, parts, 0);
+    return launch_h2_tt<2, FFN_H2_SLOTS, 8>(s, x2, M, pack, b1p, b2, parts, order);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -14,12 +14,12 @@ void idf_prof_mark_slow(int, hipStream_t) {}
 using namespace idf_ffn_h2;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int TT, int S, int MODE>
+template <int TT, int S, int MODE, int LW = 0>
 float run(const float *x2, int M, const float *pack, const float *b1, const float *b2, float *parts, int reps, int layers) {
     constexpr int BM = 16 * TT;
     const dim3 grid((unsigned)(idf_cdiv(M, BM) * NSL));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQUEST));
-    auto go = [&](int i) { hipLaunchKernelGGL((ffn_h2_kernel<TT, S, MODE>), grid, dim3(NT), LDS_REQUEST, 0, x2, M, (int)grid.x, pack + (size_t)(i % layers) * NSL * SLICE_FLOATS, b1, b2, parts, 0); };
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_h2_kernel<TT, S, MODE, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQUEST));
+    auto go = [&](int i) { hipLaunchKernelGGL((ffn_h2_kernel<TT, S, MODE, LW>), grid, dim3(NT + 64 * LW), LDS_REQUEST, 0, x2, M, (int)grid.x, pack + (size_t)(i % layers) * NSL * SLICE_FLOATS, b1, b2, parts, 0); };
     for (int i = 0; i < 10; ++i) go(i);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -50,6 +50,33 @@ void probe(int M) {
     printf("  %-40s %8.2f us\n", "no DMA after the prologue", run<TT, S, 2>(x2, M, pack, b1, b2, parts, 400, layers));
     printf("  %-40s %8.2f us\n", "no slab stores", run<TT, S, 4>(x2, M, pack, b1, b2, parts, 400, layers));
     printf("  %-40s %8.2f us\n", "product again", run<TT, S, 0>(x2, M, pack, b1, b2, parts, 400, layers));
+    {   // eight loader waves (16-wave workgroup): bits against the 8-wave kernel, time, stamps
+        std::vector<float> a((size_t)NSL * M * D), b(a.size());
+        CK(hipMemset(parts, 0xff, a.size() * 4));
+        run<TT, S, 0>(x2, M, pack, b1, b2, parts, 1, 1);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(a.data(), parts, a.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(parts, 0xff, a.size() * 4));
+        run<TT, S, 0, 8>(x2, M, pack, b1, b2, parts, 1, 1);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(b.data(), parts, b.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (size_t i = 0; i < a.size(); ++i) diff += std::memcmp(&a[i], &b[i], 4) ? 1 : 0;
+        printf("  loader-wave form vs 8-wave form: %zu of %zu elements differ\n", diff, a.size());
+        for (int rep = 0; rep < 3; ++rep) {
+            printf("  %-40s %8.2f us\n", "8 waves, 8 weight streams", run<TT, S, 0>(x2, M, pack, b1, b2, parts, 400, layers));
+            printf("  %-40s %8.2f us\n", "8 + 8 loader waves, 8 weight streams", run<TT, S, 0, 8>(x2, M, pack, b1, b2, parts, 400, layers));
+        }
+        run<TT, S, 3, 8>(x2, M, pack, b1, b2, parts, 20, layers);
+        std::vector<long long> st8((size_t)nwg * 32);
+        CK(hipMemcpy(st8.data(), reinterpret_cast<char *>(parts) + (size_t)NSL * M * D * 4, st8.size() * 8, hipMemcpyDeviceToHost));
+        double acc8[32] = {0};
+        for (int w = 0; w < nwg; ++w)
+            for (int i = 1; i < 20; ++i) acc8[i] += (double)(st8[(size_t)w * 32 + i] - st8[(size_t)w * 32 + i - 1]);
+        printf("  stamped run, loader-wave form:\n   ");
+        for (int i = 1; i < 20; ++i) printf(" %d:%.0f", i, acc8[i] / nwg);
+        printf("\n");
+    }
     run<TT, S, 3>(x2, M, pack, b1, b2, parts, 20, layers);
     std::vector<long long> st((size_t)nwg * 32);
     CK(hipMemcpy(st.data(), reinterpret_cast<char *>(parts) + (size_t)NSL * M * D * 4, st.size() * 8, hipMemcpyDeviceToHost));

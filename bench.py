@@ -48,8 +48,8 @@ FFN_FLOP_PER_TOKEN = 2 * 2 * 256 * 1024                     # linear1 + linear2 
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0                               # MI355X_MICROARCH.md: f16 / bf16 MFMA, dense
 MALL_STREAM_TBPS = 12 * 256 * 2.4e9 / 1e12                  # Infinity-Cache-resident private streams: 12 B/clk/CU measured (tools/dma_ceiling.hip, profiles/r02_dma_ceiling.txt) = 7.4 TB/s
-DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r05'        # the build the roofline block (and profiles/traffic.json) speaks about
-ROCPROF_STATS = 'profiles/r05_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r05.sh)
+DOMINANT_KERNEL_ID = 'idf_ffn_h2::ffn_h2_kernel r06 (8 computing + 8 loader waves)'        # the build the roofline block (and profiles/traffic.json) speaks about
+ROCPROF_STATS = 'profiles/r06_kernel_stats_bench.txt'       # rocprofv3 --kernel-trace --stats of `python bench.py` on the same build (tools/profile_round_r06.sh)
 
 
 def ffn_issued_f16_flop(rows, tile):

@@ -1651,9 +1651,9 @@ template __global__ void rowblock8_kernel<true, NSL, MEM, 8>(const float *, int,
 }  // namespace
 template __global__ void idf_attn_h2::self_attn_h2_kernel<0, true>(const float *, int, int, const float *, float *, size_t, const float *);
 template __global__ void idf_ffn_h2::ffn_h2_kernel<2, 4, 0, 8>(const float *, int, int, const float *, const float *, const float *, float *, int);
-template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<1, true, IDF_QKV_LOADER_WAVES>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int, int, float *,
                                                                   int64_t *, int64_t *, float *, float *);
-template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES, true>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int,
+template __global__ void idf_ffn_h2::ln_linear_h2_kernel<IDF_FFN_SLICES, true, IDF_QKV_LOADER_WAVES>(const float *, size_t, int, int, const float *, const float *, const float *, int, int, const float *, float *, int,
                                                                                int, float *, int64_t *, int64_t *, float *, float *);
 template __global__ void idf_tail_h2::step_tail_h2_kernel<3, false>(const float *, size_t, const float *, int, int, int, int, const idf_tail_h2::TailArgs);
 
@@ -2121,8 +2121,8 @@ extern "C" int interdiff_exclusive_cu_report(char *buf, int32_t cap) {
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0>), "ffn_h2_kernel<32 rows>", NT, c[1]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<2, FFN_H2_SLOTS, 0, 8>), "ffn_h2_kernel<32 rows, loader waves>", NT + 512, c[6]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&ffn_h2_kernel<4, 2, 0>), "ffn_h2_kernel<64 rows>", NT, c[2]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1, false>), "ln_linear_h2_kernel<1 slab>", NT, c[3]);
-        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES, false>), "ln_linear_h2_kernel<5 slabs>", NT, c[4]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<1, false, IDF_QKV_LOADER_WAVES>), "ln_linear_h2_kernel<1 slab>", NT + 64 * IDF_QKV_LOADER_WAVES, c[3]);
+        idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<IDF_FFN_SLICES, false, IDF_QKV_LOADER_WAVES>), "ln_linear_h2_kernel<5 slabs>", NT + 64 * IDF_QKV_LOADER_WAVES, c[4]);
         idf_exclusive_cu(reinterpret_cast<const void *>(&idf_attn_h2::self_attn_h2_kernel<0, false>), "self_attn_h2_kernel", idf_attn_h2::NTH, c[5]);
     }
     qkv_planes_ok(1, 1, 16);

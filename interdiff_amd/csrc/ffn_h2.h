@@ -539,27 +539,34 @@ constexpr int QBM = 32;
 // fetch planes instead of each splitting K and V again.  The power of two a row is divided by needs no look at the OUTPUT: the kernel already divides every INPUT row by its own
 // 2^e (Sc[row]; |x'| < 1), so |v_c| <= 2^e ||W_c||_1 + |b_c| -- a bound every slice of the launch computes identically from three static L1 norms and three bias maxima per layer
 // (the six floats behind the packed stream: mdm.py qkv_bounds).  scales_out[row][4] = the three 2^(E - 15) the attention multiplies back (q, k, v; written by slice 0).
-template <int NP, bool PLANES = false>
-__global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, int M, int nwg, const float *__restrict__ pack,
+// LW = loader waves (round 6; 0 or 8), as in ffn_h2_kernel: with 8 the workgroup is sixteen waves at 128 registers; every wave takes two of the 32 rows through the slab sum / LayerNorm /
+// split prologue (a row is one wave's latency chain: four rows per wave were four chains in a row), waves 8..15 then feed the ring, waves 0..7 multiply, all sixteen store.  Same bits.
+template <int NP, bool PLANES = false, int LW = 0>
+__global__ __launch_bounds__(NT + 64 * LW) void ln_linear_h2_kernel(const float *__restrict__ A, size_t a_pstride, int M, int nwg, const float *__restrict__ pack,
                                                            const float *__restrict__ lnw, const float *__restrict__ lnb, int nsl_grid, int step_B,
                                                            const float *__restrict__ bias, float *__restrict__ C, int ldc, int N,
                                                            float *__restrict__ xn_out, int64_t *__restrict__ step_state,
                                                            int64_t *__restrict__ step_ts, float *__restrict__ planes_out, float *__restrict__ scales_out) {
     // (argument order: the first 14 dwords -- what the weight stream and the row requests need -- arrive preloaded in SGPRs: build.py)
     extern __shared__ __attribute__((aligned(1024))) float smem[];
-    asm volatile("" ::: "v255");                       // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
+    static_assert(LW == 0 || LW == 8, "loader waves");
+    if constexpr (LW == 0) asm volatile("" ::: "v255");            // exclusive CU, like the feed-forward kernel (see launch_h2_tt)
+    else asm volatile("" ::: "v127");
+    constexpr int NTH = NT + 64 * LW, NWT = NTH / 64;
     float *Xs = smem, *ring = smem + QBM * 256, *Sc = ring + 3 * (QSTEP / 4), *Sd = Sc + QBM;      // Sc [32]: 2^e of every row; Sd [32][8] (PLANES): the row's q / k / v dividers and their inverses
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= NW, issues = LW == 0 || loader;
+    const int iw = LW > 0 ? (wave & 7) : wave;          // index among the waves that feed the ring
     int mt, sl;
     idf_ffn::xcd_affine_tile(nwg, blockIdx.x, nsl_grid, mt, sl);
     const int m0 = mt * QBM, n0 = sl * QHS;
     const float *stream = idf_uniform_ptr(pack + (size_t)sl * QSLICE_FLOATS);
-    const uint32_t vsrc = (uint32_t)(wave * 1024) + (uint32_t)(lane << 4);
-    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(wave * 1024);
-    const bool low = wave < NW / 2;                       // waves 0..3: a third DMA instruction per step
+    const uint32_t vsrc = (uint32_t)(iw * 1024) + (uint32_t)(lane << 4);
+    const uint32_t sdst = idf_lds_addr(ring) + (uint32_t)(iw * 1024);
+    const bool low = iw < NW / 2;                         // issuing waves 0..3: a third DMA instruction per step
     auto issue_step = [&](int P) {
-        if (P >= 8) return;
+        if (P >= 8 || !issues) return;
         const uint32_t so = (uint32_t)(P * QSTEP), dof = (uint32_t)((P % 3) * QSTEP);
         idf_dma16_s(stream, vsrc + so, sdst + dof);
         idf_dma16_s(stream, vsrc + so + 8192u, sdst + dof + 8192u);
@@ -580,14 +587,14 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
     {   // rows: slab sum, LayerNorm (null lnw: layer 0 takes the embedding as it is), residual copy, row scale, split into the plane image
         const float4 gw = lnw ? *reinterpret_cast<const float4 *>(lnw + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 gb = lnw ? *reinterpret_cast<const float4 *>(lnb + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v[QBM / NW];
+        float4 v[QBM / NWT];
 #pragma unroll
-        for (int i = 0; i < QBM / NW; ++i) v[i] = ld4_sum<NP>(A + (size_t)min(m0 + wave + NW * i, M - 1) * D + lane * 4, a_pstride);
+        for (int i = 0; i < QBM / NWT; ++i) v[i] = ld4_sum<NP>(A + (size_t)min(m0 + wave + NWT * i, M - 1) * D + lane * 4, a_pstride);
         idf_args_now(bias, C, ldc, N, xn_out, step_state, step_ts);      // the rest of the argument segment, behind the requests
         if (step_state && blockIdx.x == 0 && threadIdx.x == 0) sampler_prepare_step(step_state, step_ts, step_B);
 #pragma unroll
-        for (int i = 0; i < QBM / NW; ++i) {
-            const int row = wave + NW * i;
+        for (int i = 0; i < QBM / NWT; ++i) {
+            const int row = wave + NWT * i;
             float4 x = v[i];
             if (lnw) {
                 float mean, rstd;
@@ -672,10 +679,12 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
             __builtin_amdgcn_s_barrier();
         }
         issue_step(P + 2);
-        rd(P, F[P & 1]);
-        if (P > 0) mma(F[(P - 1) & 1]);
+        if (!loader) {
+            rd(P, F[P & 1]);
+            if (P > 0) mma(F[(P - 1) & 1]);
+        }
     }
-    mma(F[1]);
+    if (!loader) mma(F[1]);
     // epilogue: x 2^e of the row, + bias, through LDS (over the ring, once every wave is done reading it), 16-byte row stores (write-through)
     constexpr int QCS = QHS + 4;
     float *Cs = ring;
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        if (a == 0 || two) {
+        if (!loader && (a == 0 || two)) {
             const int col = (c0 + a) * 16 + 4 * g;
             float4 bv;
             bv.x = bias[min(n0 + col, N - 1)]; bv.y = bias[min(n0 + col + 1, N - 1)]; bv.z = bias[min(n0 + col + 2, N - 1)]; bv.w = bias[min(n0 + col + 3, N - 1)];
@@ -719,8 +728,8 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
     __syncthreads();
     if constexpr (PLANES) {
 #pragma unroll
-        for (int it = 0; it < (QBM * (QHS / 8) + NT - 1) / NT; ++it) {
-            const int idx = tid + it * NT, row = idx / (QHS / 8), c8 = (idx - row * (QHS / 8)) << 3, gr = m0 + row, gc = n0 + c8;
+        for (int it = 0; it < (QBM * (QHS / 8) + NTH - 1) / NTH; ++it) {
+            const int idx = tid + it * NTH, row = idx / (QHS / 8), c8 = (idx - row * (QHS / 8)) << 3, gr = m0 + row, gc = n0 + c8;
             if (idx < QBM * (QHS / 8) && gr < M && gc < N) {
                 const int t = gc >> 8, grp = gc >> 6, o = gc & 63;
                 const float dn = Sd[8 * row + t];
@@ -736,31 +745,36 @@ __global__ __launch_bounds__(NT) void ln_linear_h2_kernel(const float *__restric
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < (QBM * (QHS / 4) + NT - 1) / NT; ++it) {
-            const int idx = tid + it * NT, row = idx / (QHS / 4), c4 = (idx - row * (QHS / 4)) << 2, gr = m0 + row;
+        for (int it = 0; it < (QBM * (QHS / 4) + NTH - 1) / NTH; ++it) {
+            const int idx = tid + it * NTH, row = idx / (QHS / 4), c4 = (idx - row * (QHS / 4)) << 2, gr = m0 + row;
             if (idx < QBM * (QHS / 4) && gr < M && n0 + c4 < N) idf_store16_wt(C + (size_t)gr * ldc + n0 + c4, *reinterpret_cast<const float4 *>(Cs + row * QCS + c4));
         }
     }
 }
 
+#ifndef IDF_QKV_LOADER_WAVES
+#define IDF_QKV_LOADER_WAVES 0            // 0 (shipped): eight waves; 8: sixteen waves, eight of them loaders -- built and measured in round 6 (-DIDF_QKV_LOADER_WAVES=8): the same time in situ
+#endif                                    // (8.45 / 7.47 vs 8.49 / 7.63 us and 8.53 / 7.57 vs 8.46 / 7.51 us, whole samples within 0.2 %: profiles/r06_qkv_waves_ab.txt) -- unlike the feed-forward block,
+                                          // this kernel has only 160 KiB of stream and a 20-KiB epilogue per workgroup for the extra waves to shorten
 template <int NP>
 inline int launch_ln_linear_h2(hipStream_t s, const float *A, size_t a_pstride, const float *lnw, const float *lnb, int M, int N,
                                const float *pack, const float *bias, float *C, int ldc, float *xn_out, int64_t *step_state = nullptr,
                                int64_t *step_ts = nullptr, int step_B = 0, float *planes_out = nullptr, float *scales_out = nullptr) {
+    constexpr int LW = IDF_QKV_LOADER_WAVES, NTH = NT + 64 * LW;
     static idf_excl_cache excl, excl_p;
     if (planes_out) {                                  // the plane-pair output of the QKV projection (N = 768, the bounds behind the stream): see the kernel
-        const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, true>), NP == 1 ? "ln_linear_h2_kernel<1 slab, planes out>" : "ln_linear_h2_kernel<5 slabs, planes out>", NT, excl_p);
+        const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, true, LW>), NP == 1 ? "ln_linear_h2_kernel<1 slab, planes out>" : "ln_linear_h2_kernel<5 slabs, planes out>", NTH, excl_p);
         if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
         if (!A) return IDF_OK;                         // (availability query: nothing to launch)
         const int nsl = (int)idf_cdiv(N, QHS);
-        hipLaunchKernelGGL((ln_linear_h2_kernel<NP, true>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
+        hipLaunchKernelGGL((ln_linear_h2_kernel<NP, true, LW>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NTH), LDS_REQUEST, s, A, a_pstride, M,
                            (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts, planes_out, scales_out);
         return IDF_OK;
     }
-    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, false>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NT, excl);
+    const int dyn = idf_exclusive_cu(reinterpret_cast<const void *>(&ln_linear_h2_kernel<NP, false, LW>), NP == 1 ? "ln_linear_h2_kernel<1 slab>" : "ln_linear_h2_kernel<5 slabs>", NTH, excl);
     if (dyn != LDS_REQUEST) return IDF_NOT_EXCLUSIVE;
     const int nsl = (int)idf_cdiv(N, QHS);
-    hipLaunchKernelGGL((ln_linear_h2_kernel<NP, false>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NT), LDS_REQUEST, s, A, a_pstride, M,
+    hipLaunchKernelGGL((ln_linear_h2_kernel<NP, false, LW>), dim3((unsigned)(idf_cdiv(M, QBM) * nsl)), dim3(NTH), LDS_REQUEST, s, A, a_pstride, M,
                        (int)(idf_cdiv(M, QBM) * nsl), pack, lnw, lnb, nsl, step_B, bias, C, ldc, N, xn_out, step_state, step_ts, (float *)nullptr, (float *)nullptr);
     return IDF_OK;
 }

@@ -37,12 +37,15 @@ constexpr int VRS = HD + 8;                              // row stride (halves) 
 constexpr int MAX_T = 192, NIT = (MAX_T * 16 + NTH - 1) / NTH;      // float4 sweeps of a K / V tile per thread: 6 (the planes of a longer clip do not fit the CU's LDS: the fp32 kernel takes it)
 constexpr int NIT0 = 4;                                  // sweeps that cover T <= 128: requested unconditionally; the rest sit behind ONE workgroup-uniform branch
 constexpr int WO_H2_FLOATS = H * 16 * 2 * 2 * 64 * 4;      // 32768
+constexpr int OCS = D + 4;                               // row stride (floats) of the out-projection's staging tile [32][OCS] (33 280 B)
 
 // halves of the region that holds the K planes and later the probability planes
 __host__ __device__ inline int k_region_halves(int TP, int TPP) { return 2 * TP * KHS > 2 * QT * (TPP + 8) ? 2 * TP * KHS : 2 * QT * (TPP + 8); }
+// the out-projection's staging tile [32][OCS] sits over the K / V planes when they are large enough to hold it (T > 32), else behind the Q planes
+__host__ __device__ inline bool stage_over_kv(int TP, int TPP) { return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * TPP * VRS * 2 >= (size_t)QT * OCS * 4; }
 inline size_t lds_bytes(int T) {
     const int TP = (T + 15) & ~15, TPP = (T + 31) & ~31;
-    return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * TPP * VRS * 2 + (size_t)QT * (TP + 4) * 4 + (size_t)2 * QT * KHS * 2 + 64;
+    return (size_t)k_region_halves(TP, TPP) * 2 + (size_t)2 * TPP * VRS * 2 + (size_t)QT * (TP + 4) * 4 + (size_t)2 * QT * KHS * 2 + 64 + (stage_over_kv(TP, TPP) ? 0 : (size_t)QT * OCS * 4);
 }
 
 // The P V operand of one K step from the row-major V planes: four transposing LDS reads (ds_read_b64_tr_b16, four halves each: keys k0 .. k0 + 3 and k0 + 4 .. k0 + 7 of the
@@ -363,18 +366,28 @@ __global__ __launch_bounds__(NTH) void self_attn_h2_kernel(const float *__restri
                 }
             }
         }
-        float *slab = slabs + (size_t)h * pstride;
+        // The [32 x 256] partial leaves through LDS as 16-byte row stores (round 6; staged over the K / V planes, which nobody reads past the barrier above).  Rounds 4-5 stored it
+        // straight from the accumulators, one dword per lane and instruction: 8 192 four-byte write-through stores per workgroup, each its own fabric write (MI355X_MICROARCH.md:
+        // a dword sc1 store costs ~6x a dwordx4's time per byte).
+        float *Cs = stage_over_kv(TP, TPP) ? reinterpret_cast<float *>(smraw) : reinterpret_cast<float *>(ql + QT * KHS);       // [32][OCS]
+        const float osc = PLANES_IN ? red[0][0] : uv;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = q0 + rt * 16 + kq * 4 + r;
-                if (t < T) {
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        idf_store4_wt(slab + (rowbase + t) * D + (2 * wave + c) * 16 + li, (om[rt][c][r] + oc[rt][c][r] * idf_ffn_h2::LO_UNSCALE) * (PLANES_IN ? red[0][0] : uv));
-                }
-            }
+                for (int c = 0; c < 2; ++c)
+                    Cs[(rt * 16 + kq * 4 + r) * OCS + (2 * wave + c) * 16 + li] = (om[rt][c][r] + oc[rt][c][r] * idf_ffn_h2::LO_UNSCALE) * osc;
+    }
+    __syncthreads();
+    {
+        float *slab = slabs + (size_t)h * pstride;
+        const float *Cs = stage_over_kv(TP, TPP) ? reinterpret_cast<const float *>(smraw) : reinterpret_cast<const float *>(ql + QT * KHS);
+#pragma unroll
+        for (int it = 0; it < QT * (D / 4) / NTH; ++it) {
+            const int row = (tid >> 6) + it * NWV, c4 = (tid & 63) << 2, t = q0 + row;
+            if (t < T) idf_store16_wt(slab + (rowbase + t) * D + c4, *reinterpret_cast<const float4 *>(Cs + row * OCS + c4));
+        }
     }
     IDF_AH2_STAMP(6);                                    // out-projection + stores issued
 }

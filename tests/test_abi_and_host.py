@@ -580,8 +580,8 @@ def test_io_smplh_npz_and_dataset_batch_adaptor(tmp_path):
 
 
 def test_documents_quote_the_measurement_files():
-    """DESIGN.md / BASELINE.md / README.md carry their measured tables between GENERATED markers, rendered by tools/render_tables.py from profiles/r05_bench.json,
-    parity_r05.json and r05_kernel_stats_bench.txt: the committed documents must be exactly what the committed measurement files render to (no hand-typed numbers)."""
+    """DESIGN.md / BASELINE.md / README.md carry their measured tables between GENERATED markers, rendered by tools/render_tables.py from profiles/r06_bench.json,
+    parity_r06.json and r06_kernel_stats_bench.txt: the committed documents must be exactly what the committed measurement files render to (no hand-typed numbers)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'render_tables.py'), '--check'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     for doc in ('DESIGN.md', 'BASELINE.md', 'README.md'):

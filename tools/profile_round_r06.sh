@@ -8,8 +8,8 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"; mkdir -p gpurun_out
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 SQV="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
-INTERDIFF_CHAINS=1 IDF_STEP_MARKER="ln_linear_h2_kernel<1>" tools/gpu_prof.sh ${tag}_bench python bench.py --no-cpu-baseline --no-kernel-profile --no-postopt --no-extra-configs > /dev/null
-IDF_STEP_MARKER="ln_linear_h2_kernel<1>" tools/gpu_prof.sh ${tag}_bench_two_chains python bench.py --no-cpu-baseline --no-kernel-profile --no-postopt --no-extra-configs > /dev/null
+INTERDIFF_CHAINS=1 IDF_STEP_MARKER="ln_linear_h2_kernel<1," tools/gpu_prof.sh ${tag}_bench python bench.py --no-cpu-baseline --no-kernel-profile --no-postopt --no-extra-configs > /dev/null
+IDF_STEP_MARKER="ln_linear_h2_kernel<1," tools/gpu_prof.sh ${tag}_bench_two_chains python bench.py --no-cpu-baseline --no-kernel-profile --no-postopt --no-extra-configs > /dev/null
 tools/gpu_pmc.sh ${tag}_fetch_size_kbench FETCH_SIZE python tools/kbench.py --reps 3 > /dev/null
 tools/gpu_pmc.sh ${tag}_write_size_kbench WRITE_SIZE python tools/kbench.py --reps 3 > /dev/null
 tools/gpu_pmc.sh ${tag}_sq_kbench "$SQ" python tools/kbench.py --reps 3 > /dev/null

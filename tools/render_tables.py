@@ -1,6 +1,6 @@
 """Regenerate every measured number the documents quote from the measurement files (not product code).
 
-    python tools/render_tables.py [--round r05] [--check]
+    python tools/render_tables.py [--round r06] [--check]
 
 Inputs (all under profiles/): <round>_bench.json (the bench line of tools/profile_round_<round>.sh), parity_<round>.json (worst errors recorded by the GPU suite),
 <round>_kernel_stats_bench.txt (rocprofv3 kernel stats of the same bench command, with its launch-order table).
@@ -66,8 +66,10 @@ def legs(b):
     cb = b.get('cpu_baseline') or {}
     if cb:
         out.append('')
-        out.append('CPU baseline (`cpu_baseline.kind = "%s"`, %s threads): %s frame-steps/s blended over the 989 + 11 step mix (GPU / CPU %sx), denoiser alone %s frame-steps/s (%sx).'
-                   % (cb.get('kind'), cb.get('cores'), f(cb.get('value'), '%.0f'), f(cb.get('gpu_over_cpu_blended'), '%.0f'), f(g(cb, 'plain_only', 'value'), '%.0f'), f(g(cb, 'plain_only', 'gpu_over_cpu'), '%.0f')))
+        out.append('CPU baseline (`cpu_baseline.kind = "%s"`, %s threads): plain denoising steps %s frame-steps/s -- **GPU / CPU %sx, the quotable ratio** --; blended over the 989 + 11 step mix %s frame-steps/s '
+                   '(%sx: dominated by the oracle\'s brute-force nearest-neighbour search).  Port vs the reference\'s own source on the same cores (recorded, build container, %s threads): %s (plain step) / %s (correction call).'
+                   % (cb.get('kind'), cb.get('cores'), f(g(cb, 'plain_only', 'value'), '%.0f'), f(g(cb, 'plain_only', 'gpu_over_cpu'), '%.0f'), f(cb.get('value'), '%.0f'), f(cb.get('gpu_over_cpu_blended'), '%.0f'),
+                      g(cb, 'port_vs_reference', 'threads'), f(g(cb, 'port_vs_reference', 'plain_step'), '%.2f'), f(g(cb, 'port_vs_reference', 'correction_call'), '%.2f')))
     return '\n'.join(out)
 
 
@@ -76,17 +78,18 @@ def roofline(b):
     sr = b.get('step_roofline') or {}
     out = ['| quantity | value |', '|---|---|',
            '| dominant kernel | `%s` (`%s`), %s µs per launch live (best burst %s) |' % (r.get('kernel'), r.get('kernel_id'), f(r.get('us_per_launch'), '%.2f'), f(r.get('us_per_launch_best'), '%.2f')),
-           '| bound / peak | %s, %s %s (f16 dense MFMA: the instruction the kernel issues) |' % (r.get('bound'), f(r.get('peak'), '%.0f'), r.get('unit')),
-           '| achieved (f16 FLOP issued / duration) | %s %s = **frac %s** |' % (f(r.get('achieved'), '%.1f'), r.get('unit'), f(r.get('frac'), '%.3f')),
+           '| bound / peak | %s, %s %s (f16 dense MFMA peak / 3: the roof of an fp32-grade product on the pipe the kernel issues on) |' % (r.get('bound'), f(r.get('peak'), '%.0f'), r.get('unit')),
+           '| achieved (ALGORITHMIC fp32 FLOP per launch / duration) | %s %s = **frac %s** |' % (f(r.get('achieved'), '%.1f'), r.get('unit'), f(r.get('frac'), '%.3f')),
            '| rocprofv3 in-situ (recorded) | %s µs -> frac %s |' % (f(g(r, 'rocprofv3_in_situ', 'us_per_launch'), '%.2f'), f(g(r, 'rocprofv3_in_situ', 'frac'), '%.3f')),
+           '| f16 FLOP issued (3 products + zero padding; secondary) | %s TFLOP/s = %s of the f16 dense peak; recorded PMC matrix-pipe busy share %s |'
+           % (f(g(r, 'issued_f16', 'achieved_tflops'), '%.1f'), f(g(r, 'issued_f16', 'frac_of_f16_dense_peak'), '%.3f'), f(g(r, 'mfma_busy_share', 'recorded_pmc'), '%.3f')),
            '| binding resource | weight stream %s GB/s per CU of a ~%s GB/s L2-fed DMA ceiling + fixed phases |' % (f(g(r, 'binding_resource', 'weight_stream_gb_per_s_per_cu'), '%.1f'), f(g(r, 'binding_resource', 'l2_fed_dma_ceiling_gb_per_s_per_cu'), '%.0f')),
-           '| fp32-equivalent work | %s TFLOP/s = %s of the split-f16 roof (%s TFLOP/s) |' % (f(g(r, 'fp32_equivalent', 'achieved_tflops'), '%.1f'), f(g(r, 'fp32_equivalent', 'frac_of_split_f16_roof'), '%.3f'), f(g(r, 'fp32_equivalent', 'split_f16_roof_tflops'), '%.0f')),
            '| traffic per launch (PMC, recorded) | %s B vs %s B algorithmic |' % (r.get('traffic'), g(r, 'traffic_vs_algorithmic', 'algorithmic_bytes')),
            '| exact-fp32 kernel, same process | %s µs, frac %s of the fp32-MFMA peak |' % (f(g(r, 'exact_fp32_kernel', 'us_per_launch'), '%.2f'), f(g(r, 'exact_fp32_kernel', 'frac'), '%.3f')),
            '| whole step vs the chip | %s µs per step; matrix roof %s µs (%s), memory roof %s µs (%s): **step frac %s** |'
            % (f(sr.get('us_per_step'), '%.1f'), f(g(sr, 'matrix_roof', 'us'), '%.1f'), f(g(sr, 'matrix_roof', 'frac_of_step'), '%.3f'), f(g(sr, 'memory_roof', 'us'), '%.1f'), f(g(sr, 'memory_roof', 'frac_of_step'), '%.3f'), f(sr.get('frac'), '%.3f'))]
     worst = max([v for v in [r.get('frac'), g(r, 'one_layer_burst', 'frac'), g(r, 'two_chain_form', 'frac'), g(r, 'small_batch_16_row_tile', 'frac'), g(r, 'large_batch_64_row_tile', 'frac'),
-                             g(r, 'exact_fp32_kernel', 'frac'), g(r, 'fp32_equivalent', 'frac_of_split_f16_roof'), sr.get('frac')] if isinstance(v, (int, float))] or [0])
+                             g(r, 'exact_fp32_kernel', 'frac'), g(r, 'issued_f16', 'frac_of_f16_dense_peak'), sr.get('frac')] if isinstance(v, (int, float))] or [0])
     out.append('| largest fraction anywhere in the block | %s (none may exceed 1) |' % f(worst, '%.3f'))
     ex = b.get('exclusive_cu') or {}
     if ex:
@@ -161,7 +164,7 @@ def parity_misc(p):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--round', default='r05')
+    ap.add_argument('--round', default='r06')
     ap.add_argument('--check', action='store_true')
     a = ap.parse_args()
     tag = a.round

@@ -252,13 +252,23 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
     }
 #pragma unroll
     for (int P = 0; P < S - 1; ++P) issue_step(P);
-    // linear1 bias of this wave's one or two hidden tiles (phase 1 tile map below: 2 w, 2 w + 1 for waves 0..4, else 5 + w): sixteen floats each, through the scalar cache,
+    // linear1 bias of this wave's hidden tiles (phase-1 ownership below): sixteen floats each, through the scalar cache,
     // behind the DMA issue (the wave is about to wait for its rows anyway); b1p carries 256 spare floats, so the second tile's address is valid for every wave
+    // Phase-1 ownership.  With loader waves (TT = 2, LW = 8) the 26 (hidden tile, token tile) UNITS are spread 4 + 3 | 4 + 3 | 3 + 3 | 3 + 3 over the SIMDs' computing wave pairs
+    // (w, w + 4): every wave owns hidden tile ta with both token tiles and tile tb with both (waves 0, 1) or with ONE token tile (waves 2..7: tiles 5, 9 and 12 are shared by two
+    // waves, odd waves take token tile 1).  Whole tiles per wave (two for waves 0..4, one for 5..7) put 8 units on SIMD 0 and 6 on the others, and SIMD 0 sets the length of the
+    // VALU-bound GELU phase (~430 cycles per unit and SIMD).  In the eight-wave form this balance measured WORSE (the waves that refill the ring after their matrix work must stay the
+    // light ones: profiles/r06_ffn_balanced_units_not_adopted.txt); with the DMA issue on the loader waves that constraint is gone.  A unit's arithmetic is what it was: same bits.
+    constexpr bool BAL = TT == 2 && LW == 8;
+    const int ta = BAL ? (int)((0x7BA86420u >> (4 * (wave & 7))) & 15u) : (wave < 5 ? 2 * wave : 5 + wave);
+    const int tb = BAL ? (int)((0xCC995531u >> (4 * (wave & 7))) & 15u) : ta + 1;
+    const bool has_b = BAL || wave < 5;                                    // this wave multiplies for a second hidden tile (accumulator slot 1)
+    const bool full_b = BAL ? wave < 2 : wave < 5;                         // ... with every token tile
+    const bool sel1 = BAL && wave >= 2 && (wave & 1);                      // ... with ONE token tile: tile 1 (odd waves) or 0, kept in accumulator slot [1][0]
     f4s bias_s[2][4];
     if (!loader) {
-        const int hb = wave < 5 ? 2 * wave : 5 + wave;
-        idf_sload16(b1p + sl * HS + hb * 16, bias_s[0][0], bias_s[0][1], bias_s[0][2], bias_s[0][3]);
-        idf_sload16(b1p + sl * HS + (hb + 1) * 16, bias_s[1][0], bias_s[1][1], bias_s[1][2], bias_s[1][3]);
+        idf_sload16(b1p + sl * HS + ta * 16, bias_s[0][0], bias_s[0][1], bias_s[0][2], bias_s[0][3]);
+        idf_sload16(b1p + sl * HS + tb * 16, bias_s[1][0], bias_s[1][1], bias_s[1][2], bias_s[1][3]);
     }
     {   // the x2 rows are older than this wave's share of the steps just issued
         int younger = 0;
@@ -285,12 +295,10 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
         }
     }
 
-    // ---- tile maps.  Phase 1: 13 hidden tiles: waves 0..4 own two (2w, 2w+1), waves 5..7 one (10, 11, 12); every wave covers all TT
-    // token tiles for its hidden tiles (a weight fragment is read once per workgroup).  Phase 2: 16 output tiles, wave w owns 2w, 2w+1.
-    const bool two1 = wave < 5;
-    const int h0 = two1 ? 2 * wave : 5 + wave;
+    // ---- tile maps.  Phase 1: above (ta, tb, has_b, full_b, sel1).  Phase 2: 16 output tiles, wave w owns 2w, 2w+1 with every token tile.
+    const bool two1 = has_b;
     const int o0 = 2 * wave;
-    f32x4 accM[2][TT], accC[2][TT];
+    f32x4 accM[2][TT], accC[2][TT];                   // phase 1: [0] = tile ta, [1] = tile tb (balanced map, one token tile only: slot [1][0] holds token tile sel1)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -309,13 +317,13 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
             f.xl[t] = ld8(row + 128);
         }
     };
-    auto read1 = [&](int s, Frags &f) {               // A operand: hidden tiles h0 (, h0 + 1) of step s
-        const float *sb = ring + (s % S) * (SLOT / 4) + h0 * 512 + lane * 4;
-        f.wh[0] = ld8(sb);
-        f.wl[0] = ld8(sb + 256);
+    auto read1 = [&](int s, Frags &f) {               // A operand: hidden tiles ta (, tb) of step s
+        const float *sb = ring + (s % S) * (SLOT / 4) + lane * 4;
+        f.wh[0] = ld8(sb + ta * 512);
+        f.wl[0] = ld8(sb + ta * 512 + 256);
         if (two1) {
-            f.wh[1] = ld8(sb + 512);
-            f.wl[1] = ld8(sb + 768);
+            f.wh[1] = ld8(sb + tb * 512);
+            f.wl[1] = ld8(sb + tb * 512 + 256);
         }
         read_x(s, f);
     };
@@ -351,6 +359,26 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
             for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[1][t], f.wl[1], f.xh[t]);
         }
     };
+    // phase 1 of the balanced map: tile ta x both token tiles, tile tb x (both | the one token tile sel1, in accumulator slot [1][0]).  Per accumulator the same three MFMAs per K step, in the same order.
+    auto mma1 = [&](const Frags &f) {
+        if constexpr (!BAL) {
+            mma(f, two1);
+        } else {
+            const h8 xbh = sel1 ? f.xh[TT - 1] : f.xh[0], xbl = sel1 ? f.xl[TT - 1] : f.xl[0];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accM[0][t], f.wh[0], f.xh[t]);
+            IDF_H2_MFMA(accM[1][0], f.wh[1], xbh);
+            if (full_b) IDF_H2_MFMA(accM[1][TT - 1], f.wh[1], f.xh[TT - 1]);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[0][t], f.wh[0], f.xl[t]);
+            IDF_H2_MFMA(accC[1][0], f.wh[1], xbl);
+            if (full_b) IDF_H2_MFMA(accC[1][TT - 1], f.wh[1], f.xl[TT - 1]);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) IDF_H2_MFMA(accC[0][t], f.wl[0], f.xh[t]);
+            IDF_H2_MFMA(accC[1][0], f.wl[1], xbh);
+            if (full_b) IDF_H2_MFMA(accC[1][TT - 1], f.wl[1], f.xh[TT - 1]);
+        }
+    };
     auto publish = [&](int P) {                       // step P has landed for every wave, and every wave is done with step P - 1's slot
         wait_step(P);
         __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0) as a builtin: the compiler then KNOWS the LDS queue is empty
@@ -370,11 +398,11 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
         if (early) issue_step(P + S - 1);             // into the slot of step P - 1
         if (!loader) {
             read1(P, F[P & 1]);
-            if (P > 0) mma(F[(P - 1) & 1], two1);
+            if (P > 0) mma1(F[(P - 1) & 1]);
         }
         if (!early) issue_step(P + S - 1);
     }
-    if (!loader) mma(F[(KS1 - 1) & 1], two1);
+    if (!loader) mma1(F[(KS1 - 1) & 1]);
 
     // ---- hid = gelu(acc + b1), split, over the x2 planes (every wave is past its last read of them behind the next barrier)
     publish(KS1);                                     // first phase-2 step has landed too
@@ -385,9 +413,11 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
         if (!loader && (a == 0 || two1)) {
             const f4s bsel = g == 0 ? bias_s[a][0] : (g == 1 ? bias_s[a][1] : (g == 2 ? bias_s[a][2] : bias_s[a][3]));      // lane group g takes hidden units 4 g .. 4 g + 3 of the tile
             const float4 bv = make_float4(bsel[0], bsel[1], bsel[2], bsel[3]);
-            const int chunk = 2 * (h0 + a) + (g >> 1);
+            const int chunk = 2 * (a ? tb : ta) + (g >> 1);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
+                if (BAL && a == 1 && t > 0 && !full_b) continue;               // tile tb of waves 2..7: the one unit in slot [1][0]
+                const int tt = (BAL && a == 1 && t == 0 && sel1) ? TT - 1 : t;  // ... which is token tile sel1
                 const f2 m01 = {accM[a][t][0], accM[a][t][1]}, m23 = {accM[a][t][2], accM[a][t][3]};
                 const f2 c01 = {accC[a][t][0], accC[a][t][1]}, c23 = {accC[a][t][2], accC[a][t][3]};
                 const f2 b01 = {bv.x, bv.y}, b23 = {bv.z, bv.w};
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(NT + 64 * LW) void ffn_h2_kernel(const float *__res
                 const float4 v = make_float4(g01.x, g01.y, g23.x, g23.y);
                 uint2 hi, lo;
                 split4_pk(v, hi, lo);
-                float *dst = Xs + (16 * t + n) * 256 + ((chunk ^ n) << 2) + ((g & 1) << 1);
+                float *dst = Xs + (16 * tt + n) * 256 + ((chunk ^ n) << 2) + ((g & 1) << 1);
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 128) = lo;
             }

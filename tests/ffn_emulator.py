@@ -391,8 +391,18 @@ def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
         return acc + np.einsum('gij,gnj->in', A, B)
 
     res = {}                                               # phase-1 results: (wave, a, t) -> [16 hidden][16 token]
-    hid_tiles = {w: ([2 * w, 2 * w + 1] if w < 5 else [5 + w]) for w in range(NW)}
-    accs = {(w, a, t): [np.zeros((16, 16)), np.zeros((16, 16))] for w in range(NW) for a in range(len(hid_tiles[w])) for t in range(tt_n)}
+    if tt_n == 2:
+        # csrc/ffn_h2.h, 32-row tile in its shipped sixteen-wave form (round 6): the computing waves 0..7 own (hidden tile, token tile) UNITS balanced over the SIMDs' wave pairs --
+        # tile ta with both token tiles, tile tb with both (waves 0, 1) or with the ONE token tile w & 1 (waves 2..7: tiles 5, 9, 12 are shared by two waves).  (The DMA issue modelled
+        # below is the eight-wave form's; the loader waves of the shipped form issue the same pieces into the same slots.)
+        TA, TB = [0, 2, 4, 6, 8, 10, 11, 7], [1, 3, 5, 5, 9, 9, 12, 12]
+        hid_tiles = {w: [TA[w], TB[w]] for w in range(NW)}
+        units = {(w, a): (list(range(tt_n)) if (a == 0 or w < 2) else [w & 1]) for w in range(NW) for a in range(2)}
+    else:
+        hid_tiles = {w: ([2 * w, 2 * w + 1] if w < 5 else [5 + w]) for w in range(NW)}
+        units = {(w, a): list(range(tt_n)) for w in range(NW) for a in range(len(hid_tiles[w]))}
+    assert sorted((hid_tiles[w][a], t) for (w, a), ts in units.items() for t in ts) == [(h, t) for h in range(HS // 16) for t in range(tt_n)]      # every unit exactly once
+    accs = {(w, a, t): [np.zeros((16, 16)), np.zeros((16, 16))] for (w, a), ts in units.items() for t in ts}
     frag_prev = None
     for P in range(H2_KS1 + 1):
         if P < H2_KS1:
@@ -404,7 +414,7 @@ def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
             xs_p, ws_p = frag_prev
             for w in range(NW):
                 for a, (wh, wl) in enumerate(ws_p[w]):
-                    for t in range(tt_n):
+                    for t in units[(w, a)]:
                         xh, xl = xs_p[t]
                         m, c = accs[(w, a, t)]
                         accs[(w, a, t)] = [mfma(m, wh, xh), mfma(mfma(c, wh, xl), wl, xh)]
@@ -414,7 +424,7 @@ def emulate_h2_workgroup(x2, pack_words, b1p, b2, mt, sl, late, bm):
     bias = np.asarray(b1p, np.float64)[sl * HS:sl * HS + HS]
     for w in range(NW):
         for a, h in enumerate(hid_tiles[w]):
-            for t in range(tt_n):
+            for t in units[(w, a)]:
                 m, c = accs[(w, a, t)]
                 pre = (m + c / 2048.0) + bias[16 * h:16 * h + 16, None]            # [hidden i][token nn]
                 hid = _gelu(pre).astype(np.float32)

@@ -164,17 +164,19 @@ __global__ __launch_bounds__(1024) void corr_point_order_kernel(const float *__r
 // EXACT block culling (round 3).  The vertex records sit in LDS in SCAN ORDER -- the Morton order of the REST pose, chosen at
 // pack time (ctx->vorder): skinning is spatially smooth, so CB consecutive records stay a compact clump under any pose -- and
 // each block of CB = 16 records gets its axis-aligned box, built in-kernel from the frame's posed vertices.  Per point:
-//   seed    best = the distance to the FIRST record of every 4th block (108 real distances: a valid upper bound of the minimum),
-//           bumped by one ulp so that the first block that attains it still registers;
+//   seed    the distance to the FIRST record of every 4th block (108 real distances: a valid upper bound of the minimum), widened by the scan's margin;
 //   scan    two levels: super-blocks of SB = 8 blocks (128 records) are tested first, their blocks only if some point needs them.
-//           For a box: lower bound lb = |max(lo - q, q - hi, 0)|^2 in the SAME operation order as the distance -- fp32
-//           subtraction, multiplication and addition are monotone, so the rounded lb never exceeds the rounded distance of any
-//           vertex inside the box.  A box is skipped iff lb > best (STRICTLY) for every point of the WAVE (one ballot, one
-//           uniform branch): a block holding a vertex at exactly the minimum is never skipped, ties included.  An executed block
-//           is scored like the brute force (v_min3_f32 over vertex pairs), index bookkeeping once per block.
-//   resolve the winning block is re-scored; among its records at the minimum the LOWEST ORIGINAL vertex index wins.  A point that
-//           met its minimum again in a later block (bm == best: ~1e-5 of the points) is flagged and rescanned over all records
-//           for the lowest original index: exactly the brute force's lowest-index-wins rule, independent of the scan order.
+//           For a box: lower bound lb = |max(lo - q, q - hi, 0)|^2 -- fp32 subtraction is monotone, so each component is at most that of
+//           any vertex inside the box.  A box is skipped iff lb > thr (STRICTLY) for every point of the WAVE (one ballot, one uniform
+//           branch).  Rounds 3-5 scored with the exact distance E = (dx dx + dy dy) + dz dz and compared lb <= best bit for bit; round 6
+//           RANKS with A = fma(dz, dz, fma(dy, dy, dx dx)) (7 instead of 9 instructions per record pair; |A / E - 1| <= 6 ulp-halves, both being
+//           three roundings of the same non-negative sum) and carries a margin of 2^-18 (+1e-37) in every comparison that drops something:
+//           thr = min(seed, smallest block minimum so far) x (1 + 2^-18).  An executed block is scored with v_min3_f32 over vertex pairs,
+//           index bookkeeping once per block; a block whose minimum comes within the margin of the smallest one is remembered as the runner-up.
+//   resolve the winning block -- and the runner-up, ~1e-4 of the points -- is re-scored with the EXACT E; among the records at the exact minimum
+//           the LOWEST ORIGINAL vertex index wins.  A point with more than one runner-up (~1e-8) is rescanned over all records with E.  Exactly
+//           the brute force's lowest-index-wins rule, independent of the scan order and of the ranking distance.  (A rescan costs its
+//           workgroup as much as the whole frame: with every near-tie rescanned the kernel was 10 % SLOWER than the exact-ranked scan.)
 // Then the normal of the nearest vertex from its incident faces (adjacency as (a, b) record pairs: ONE 8-byte load per face instead
 // of face id -> corner -> three vertex ids), the signed distance, the marker distances.  The per-point loss goes to LDS by scan
 // position and is reduced in a fixed tree: deterministic whatever wave scored the point.
@@ -420,22 +422,31 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                 const v2f dx = QX - v2f{xy.x, xy.y}, dy = QY - v2f{xy.z, xy.w}, dz = QZ - v2f{zz.x, zz.y};
                 return (dx * dx + dy * dy) + dz * dz;
             };
-            // ---- seed
-            float best = FLT_MAX;
+            // The SCAN ranks vertices by a cheaper distance (round 6): A = fma(dz, dz, fma(dy, dy, dx * dx)) -- 7 instead of 9 instructions per record pair, 3 roundings like the
+            // exact E = (dx * dx + dy * dy) + dz * dz over the same rounded differences, so |A / E - 1| <= 6 u (u = 2^-24; all terms non-negative, no cancellation).  It only FILTERS:
+            // every comparison that could drop a vertex carries the margin SCAN_M = 1 + 2^-18 (64 u) plus 1e-37 for the subnormal range, the winning block is re-scored with E, and a
+            // point whose runner-up block came within the margin is rescanned over all records with E -- the answer is the brute force's (lowest original index at the exact minimum).
+            auto pair_a2 = [&](const float4 xy, const float2 zz) {
+                const v2f dx = QX - v2f{xy.x, xy.y}, dy = QY - v2f{xy.z, xy.w}, dz = QZ - v2f{zz.x, zz.y};
+                return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            };
+            constexpr float SCAN_M = 1.000003814697265625f, SCAN_ABS = 1e-37f;
+            // ---- seed: an upper bound of the minimum of A, widened by the margin: the cull threshold before any block has been scored
+            float seed = FLT_MAX;
             for (int k = 0; k < (L.nSeed + 1) / 2; k += 4) {
-                float4 xy[4], zz[4];
+                float4 xy[4]; float2 zz[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { xy[u] = sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1)]; zz[u] = sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1) + 1]; }
+                for (int u = 0; u < 4; ++u) { xy[u] = sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1)]; zz[u] = *reinterpret_cast<const float2 *>(&sd[2 * min(k + u, (L.nSeed + 1) / 2 - 1) + 1]); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const v2f d2 = pair_d2(xy[u], zz[u]);
-                    best = fminf(fminf(best, d2.x), d2.y);
+                    const v2f a2 = pair_a2(xy[u], zz[u]);
+                    seed = fminf(fminf(seed, a2.x), a2.y);
                 }
             }
-            // one ulp up (a normal number at least): the first block that attains the seed must still satisfy bm < best
-            best = best < 1.17549435e-38f ? 1.17549435e-38f : __builtin_bit_cast(float, __builtin_bit_cast(int, best) + 1);
-            bool tie = false;
-            int bblk = 0;                                  // first record of the block that last lowered the minimum
+            float thr = __builtin_fmaf(seed, SCAN_M, SCAN_ABS);      // boxes with lb > thr hold no vertex within the margin of the minimum
+            float best = FLT_MAX, bthr = FLT_MAX;                    // smallest block minimum of A so far, and the same widened by the margin
+            int tie = 0;                                   // runner-up blocks within the margin of the smallest: 0, 1 (bblk2), 2 = more than one
+            int bblk = 0, bblk2 = 0;                                  // first record of the block that last lowered the minimum
             // lower bounds of the point to a PAIR of boxes
             auto pair_lb = [&](const float4 a, const float4 bq, const float4 c) {
 #pragma clang fp contract(off)
@@ -445,33 +456,40 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                 const v2f ex = v2f{fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};       // v_max3_f32
                 const v2f ey = v2f{fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
                 const v2f ez = v2f{fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-                return (ex * ex + ey * ey) + ez * ez;
+                // ex <= |dx| of every vertex in the box (subtraction is monotone), so the REAL sum of squares is a lower bound of every vertex's; three roundings here (<= 3 u up)
+                // against three in E and A: far inside the margin of thr
+                return __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
             };
             auto score_block = [&](int cb) {
                 ++n_exec;
                 const int v0 = cb * CB;
-                float4 xy[CB / 2], zz[CB / 2];
+                float4 xy[CB / 2]; float2 zz[CB / 2];
 #pragma unroll
-                for (int u = 0; u < CB / 2; ++u) { xy[u] = vs[v0 + 2 * u]; zz[u] = vs[v0 + 2 * u + 1]; }
+                for (int u = 0; u < CB / 2; ++u) { xy[u] = vs[v0 + 2 * u]; zz[u] = *reinterpret_cast<const float2 *>(&vs[v0 + 2 * u + 1]); }
                 float bm = FLT_MAX;
 #pragma unroll
                 for (int u = 0; u < CB / 2; ++u) {
-                    const v2f d2 = pair_d2(xy[u], zz[u]);
-                    bm = fminf(fminf(bm, d2.x), d2.y);                          // v_min3_f32
+                    const v2f a2 = pair_a2(xy[u], zz[u]);
+                    bm = fminf(fminf(bm, a2.x), a2.y);                          // v_min3_f32
                 }
-                if (bm < best) { best = bm; bblk = v0; tie = false; }
-                else if (bm == best) tie = true;
+                // a new smallest block: the previous one stays a candidate iff it is within the margin of this one; otherwise a block within the margin of the smallest is one.
+                // ONE runner-up block is remembered (bblk2); a second one (tie == 2: ~1e-8 of the points) sends the point to the rescan over all records.
+                if (bm < best) {
+                    const float w = __builtin_fmaf(bm, SCAN_M, SCAN_ABS);
+                    if (best <= w) { tie = tie ? 2 : 1; bblk2 = bblk; } else tie = 0;
+                    best = bm; bblk = v0; bthr = w; thr = fminf(thr, w);
+                } else if (bm <= bthr) { tie = tie ? 2 : 1; bblk2 = v0; }
             };
             auto scan_super = [&](int sb) {                 // the blocks of super-block sb, two box tests per instruction
-                const int cb0 = sb * SB;
+                const int cb0 = sb * SB;                    // (fetching 2 or 4 box pairs ahead of their tests: no difference, profiles/r06_contact_bound.txt)
 #pragma unroll
                 for (int j = 0; j < SB / 2; ++j) {
                     const int cb = cb0 + 2 * j;             // boxes past nCB are dummies (lo = +max: lb = inf, never needed)
                     const float4 *bx = bb + 3 * (cb >> 1);
                     const v2f lb = pair_lb(bx[0], bx[1], bx[2]);
                     n_test += 2;
-                    if (__builtin_amdgcn_ballot_w64(valid && lb.x <= best) != 0ull) score_block(cb);
-                    if (__builtin_amdgcn_ballot_w64(valid && lb.y <= best) != 0ull) score_block(cb + 1);     // best may just have dropped
+                    if (__builtin_amdgcn_ballot_w64(valid && lb.x <= thr) != 0ull) score_block(cb);
+                    if (__builtin_amdgcn_ballot_w64(valid && lb.y <= thr) != 0ull) score_block(cb + 1);     // thr may just have dropped
                 }
             };
             if (!vorder) {
@@ -483,21 +501,28 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                 const float4 *bx = sbb + 3 * (sb >> 1);
                 const v2f lb = pair_lb(bx[0], bx[1], bx[2]);
                 n_test += 2;
-                if (__builtin_amdgcn_ballot_w64(valid && lb.x <= best) != 0ull) scan_super(sb);              // wave-uniform branches
-                if (__builtin_amdgcn_ballot_w64(valid && lb.y <= best) != 0ull) scan_super(sb + 1);
+                if (__builtin_amdgcn_ballot_w64(valid && lb.x <= thr) != 0ull) scan_super(sb);              // wave-uniform branches
+                if (__builtin_amdgcn_ballot_w64(valid && lb.y <= thr) != 0ull) scan_super(sb + 1);
             }
-            // resolve inside the winning block: among the records at (or, defensively, below) the minimum the lowest ORIGINAL index
+            // resolve with the EXACT distance: inside the winning block (no other block came within the margin), else over all records (~1e-5 of the points): the smallest E, and among
+            // the records that attain it the lowest ORIGINAL index -- the brute force's rule, whatever the scan order
             int pos = bblk, org = 0x7fffffff;
-            auto resolve_pair = [&](int pr) {                 // record pair pr: the same packed distances as the scan (= dist2_exact), original ids from the pair's spare words (0x7fffffff past V)
+            float ebest = FLT_MAX;
+            auto resolve_pair = [&](int pr) {                 // record pair pr: E = dist2_exact, original ids from the pair's spare words (0x7fffffff past V; those records sit at 3e18)
                 const float4 xy = vs[2 * pr], zz = vs[2 * pr + 1];
                 const v2f d2 = pair_d2(xy, zz);
                 const int o0 = __builtin_bit_cast(int, zz.z), o1 = __builtin_bit_cast(int, zz.w);
-                if (d2.x <= best && o0 < org) { org = o0; pos = 2 * pr; }
-                if (d2.y <= best && o1 < org) { org = o1; pos = 2 * pr + 1; }
+                if (d2.x < ebest || (d2.x == ebest && o0 < org)) { ebest = d2.x; org = o0; pos = 2 * pr; }
+                if (d2.y < ebest || (d2.y == ebest && o1 < org)) { ebest = d2.y; org = o1; pos = 2 * pr + 1; }
             };
+            if (tie < 2) {
 #pragma unroll
-            for (int u = 0; u < CB / 2; ++u) resolve_pair((bblk >> 1) + u);
-            if (tie) {                                    // the minimum was met again in a later block: settle it over all records
+                for (int u = 0; u < CB / 2; ++u) resolve_pair((bblk >> 1) + u);
+                if (tie) {                                // ~1e-4 of the points: the runner-up block as well
+#pragma unroll
+                    for (int u = 0; u < CB / 2; ++u) resolve_pair((bblk2 >> 1) + u);
+                }
+            } else {
                 for (int pr = 0; pr < (V + 1) / 2; ++pr) resolve_pair(pr);
             }
             pos = min(pos, V - 1);

@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--B', type=int, default=16)
     ap.add_argument('--T', type=int, default=100)
+    ap.add_argument('--only', default='', help='scan_order | identity_order: run one variant (counter passes)')
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     lib = _lib.load()
@@ -37,6 +38,8 @@ def main():
     out = {}
     ref = None
     for name, so, tune in (('scan_order', True, 0), ('identity_order', False, 0)):
+        if args.only and name != args.only:
+            continue
         corr = mk(so)
         corr.ctx.tune = tune
         corr.debug = {}

@@ -364,7 +364,8 @@ typedef struct {
     const int32_t *adj_ptr, *adj_face, *adj_corner;
     const int32_t *markers_idx;
     int32_t n_markers, n_points, past_len;
-    int32_t tune;              /* reserved (rounds 1-2: shape of the contact scan), ignored */
+    int32_t tune;              /* A/B only, 0 in the product.  Bit 1 (value 2): the hook launches the one-launch predictor after the contact scan; default: the predictor's three
+                                  stacks ride in the scan's launch as leading workgroups and a pick kernel follows the labels (csrc/correction.hip correction_impl; same bits) */
     /* Scan order of the exact nearest-vertex scans (all four or none; NULL = identity order: same results, no culling benefit).
      * vorder [V]: scan position -> vertex, a permutation that keeps blocks of 16 consecutive positions spatially compact under any
      * pose (the host uses the Morton order of the rest pose, interdiff_amd/correction.py scan_order); faces_scan [F][3] and

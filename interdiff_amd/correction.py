@@ -2,6 +2,7 @@
 ``interdiff_correction`` entry point.  ``HipCorrection`` owns the packed SMPL model, mesh adjacency,
 ObjProjector and workspace; calling it mutates and returns ``x`` like the reference does (:129-130)."""
 import ctypes as C
+import os
 import itertools
 import numpy as np
 import torch
@@ -44,6 +45,7 @@ class HipCorrection:
             ctx.vorder, ctx.faces_scan, ctx.markers_scan = self.topo.vorder.data_ptr(), self.topo.faces_scan.data_ptr(), self.markers_scan.data_ptr()
             ctx.adj_pair_scan = self.topo.adj_pair_scan.data_ptr()
             ctx.vrank = self.topo.vrank.data_ptr()
+        ctx.tune = 2 if os.environ.get('INTERDIFF_HOOK_ONE_STREAM') == '1' else 0      # A/B only (tools/): the one-launch predictor after the scan instead of inside its launch
         self.ctx = ctx
         self._ws = {}
         self.debug = None            # set to {} to receive condition/contact/distance/loss of the last call

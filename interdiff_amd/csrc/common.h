@@ -227,6 +227,12 @@ int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *
 int idf_near_mask_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *verts, int V, const float *pts_frame, int P, const int32_t *porder,
                       const int32_t *vorder, float *psort, float *pbox, int32_t *near);
 
+// the contact-frame predictor as the correction hook runs it (objproj.hip / objproj.h): its three stacks ride in the contact scan's launch (csrc/objproj.h objproj_body<1> ->
+// keep [B][idf_objproj_keep_floats()]), then the selected node's IDCT once the contact labels exist.  Together bit-identical to interdiff_objprojector_sample.
+size_t idf_objproj_keep_floats();
+int idf_objproj_check(const idf_objproj *op);
+int idf_objproj_pick(const idf_objproj *op, const float *keep, const int32_t *contact, int B, float *out, hipStream_t s);
+
 // profiling hook (prof.hip): no-op unless interdiff_profile_begin() armed it
 extern bool g_idf_prof_on;
 void idf_prof_mark_slow(int kind, hipStream_t s);

@@ -12,6 +12,7 @@
 //   - reduces loss / min-distance / contact flags in LDS and writes a few floats per frame.
 // Frame index n = t*B + b everywhere (the reference's .view(T*B, ...)).
 #include "common.h"
+#include "objproj.h"
 #include "rot_math.h"
 #include <float.h>
 
@@ -194,7 +195,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // 2j, 2j+1 -> {lox0 lox1 loy0 loy1}, {loz0 loz1 hix0 hix1}, {hiy0 hiy1 hiz0 hiz1}.
 struct ContactLds {
     int V4, nCB, nSB, nSeed;
-    int rec, mark, box, sbox, seed, total;         // offsets in float4 units
+    int rec, mark, box, sbox, seed, flags, red, pl, total;         // offsets in float4 units
     __host__ __device__ explicit ContactLds(int V) {
         V4 = (V + CB - 1) / CB * CB; nCB = V4 / CB; nSB = (nCB + SB - 1) / SB; nSeed = (nCB + SEED_STRIDE - 1) / SEED_STRIDE;
         rec = 0;
@@ -202,7 +203,10 @@ struct ContactLds {
         box = mark + MAXM;
         sbox = box + 3 * (nSB * SB / 2);             // block boxes as pairs, padded with dummies to whole super-blocks
         seed = sbox + 3 * ((nSB + 2) / 2);
-        total = seed + 2 * ((nSeed + 1) / 2);
+        flags = seed + 2 * ((nSeed + 1) / 2);        // [MAXM] int, [CT] float, [MAXP] float: in the dynamic region since round 6 (the launch that carries the predictor's
+        red = flags + MAXM / 4;                      // workgroups shares ONE LDS size between both roles: statics of one role would sit on top of the other's 152 KB)
+        pl = red + CT / 4;
+        total = pl + MAXP / 4;
     }
 };
 
@@ -231,7 +235,18 @@ __device__ __forceinline__ void lds_box_load(const float4 *bx, int k, float3 &lo
 // OPT = the instantiation of the physics post-optimisation (optimize.hip, optimization.py:64-65): the object points come already
 // transformed per frame (pts_frame [N][P][3]), frames are clip-major (clip = n / frames_per_clip) and the only output is the nearest
 // vertex of every point -- no normals, markers or loss (the per-vertex contact-radius mask of :74-75 is its own kernel there).
-template <bool OPT>
+// WITH_PRED (the correction hook, round 6): the launch carries `pred.nclips` extra LEADING workgroups that run the contact-frame predictor's three stacks (csrc/objproj.h PART 1: one
+// clip each, 250 us, markers gathered from the posed vertices) beside the scan's N frame workgroups -- the predictor needs the markers only, the contact labels only pick which node's
+// IDCT is evaluated afterwards (idf_objproj_pick).  Leading, so they are dispatched first; one launch, so nothing depends on a second queue (a side stream was tried first: its
+// blocked barrier packet cost the caller's queue ~1 us per kernel launch for as long as the host ran ahead -- +27 us per step inside the sampler, profiles/r06_hook_overlap.txt).
+struct PredArgs {
+    idf_objproj op;
+    const float *obj_angles, *obj_trans;      // [T][B][6], [T][B][3]
+    const int32_t *markers_idx;               // [M] original vertex ids
+    float *markers, *keep;                    // [N][M][3] (written here, frames time-major), [B][idf_objproj_keep_floats()]
+    int nclips;
+};
+template <bool OPT, bool WITH_PRED = false>
 __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restrict__ verts, int V,
                                                           const float *__restrict__ obj_points, int P,
                                                           const int32_t *__restrict__ porder /* nullable [B][P]: scan position -> point */,
@@ -250,16 +265,34 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
                                                           int32_t *__restrict__ idx_out /* nullable [N][P]: nearest vertex */,
                                                           unsigned long long *__restrict__ stats /* nullable [IDF_CONTACT_STATS]: see interdiff_contact_nn */,
                                                           int64_t nn_from /* frames below it skip the NN scan */,
-                                                          const float *__restrict__ pts_frame /* OPT: [N][P][3] */, int frames_per_clip /* OPT */) {
+                                                          const float *__restrict__ pts_frame /* OPT: [N][P][3] */, int frames_per_clip /* OPT */,
+                                                          const PredArgs pred) {
     extern __shared__ __attribute__((aligned(16))) float4 vs[];
+    if constexpr (WITH_PRED) {
+        if ((int)blockIdx.x < pred.nclips) {
+            // predictor role: this clip's markers out of the posed vertices (what the scan's workgroups also write when asked to), then the three stacks
+            const int b = blockIdx.x, Tn = pred.op.T;
+            for (int i = threadIdx.x; i < Tn * M; i += CT) {
+                const int t = i / M, m = i - t * M;
+                const size_t nfr = (size_t)t * B + b;
+                const float *v = verts + (nfr * V + pred.markers_idx[m]) * 3;
+                float *o = pred.markers + (nfr * M + m) * 3;
+                o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+            }
+            __threadfence();
+            __syncthreads();
+            idf_objproj_dev::objproj_body<1>(reinterpret_cast<float *>(vs), pred.op, pred.obj_angles, pred.obj_trans, pred.markers, nullptr, B, b, pred.keep, nullptr);
+            return;
+        }
+    }
     const ContactLds L(V);
     const int nCB = L.nCB, nSB = L.nSB;
     float4 *ms = vs + L.mark, *bb = vs + L.box, *sbb = vs + L.sbox, *sd = vs + L.seed;
-    __shared__ int flags[MAXM];
-    __shared__ float red[CT];
-    __shared__ float pl[MAXP];                                             // per-point loss by scan position
+    int *flags = reinterpret_cast<int *>(vs + L.flags);
+    float *red = reinterpret_cast<float *>(vs + L.red);
+    float *pl = reinterpret_cast<float *>(vs + L.pl);                       // per-point loss by scan position
     __shared__ int next_task;
-    const int64_t n = blockIdx.x;
+    const int64_t n = WITH_PRED ? (int64_t)blockIdx.x - pred.nclips : (int64_t)blockIdx.x;
     const int b = OPT ? (int)(n / frames_per_clip) : (int)(n % B), tid = threadIdx.x;
     const float *vf = verts + (size_t)n * V * 3;
     const bool do_nn = n >= nn_from;
@@ -351,8 +384,10 @@ __global__ __launch_bounds__(CT) void corr_contact_kernel(const float *__restric
         float3 mk = make_float3(3e18f, 3e18f, 3e18f);
         if (tid < M) {
             mk = lds_rec(vs, my_marker_pos);
-            float *mo = markers_out + ((size_t)n * M + tid) * 3;
-            mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
+            if (markers_out) {                                             // (the hook's overlapped route gathers them in corr_markers_kernel, ahead of this kernel)
+                float *mo = markers_out + ((size_t)n * M + tid) * 3;
+                mo[0] = mk.x; mo[1] = mk.y; mo[2] = mk.z;
+            }
         }
         lds_rec_store(ms, tid, mk.x, mk.y, mk.z);
     }
@@ -629,7 +664,7 @@ size_t contact_lds_bytes(int V) { return (size_t)ContactLds(V).total * sizeof(fl
 
 int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const float *obj_points, int P, int32_t *porder,
                    const float *objR, const float *objT, const idf_correction_ctx *c, int B, float *markers, float *loss_sum,
-                   float *min_dist, int32_t *label, float *o2h, int32_t *idx, unsigned long long *stats, int64_t nn_from) {
+                   float *min_dist, int32_t *label, float *o2h, int32_t *idx, unsigned long long *stats, int64_t nn_from, const PredArgs *pred = nullptr) {
     const int M = c->n_markers;
     const size_t lds = contact_lds_bytes(V);
     if (lds > 160 * 1024 - 16384 || P > MAXP) return IDF_E_INVAL;
@@ -638,11 +673,22 @@ int launch_contact(hipStream_t s, int64_t N, const float *verts, int V, const fl
     if (ordered != (c->faces_scan != nullptr) || ordered != (c->markers_scan != nullptr) || ordered != (c->adj_pair_scan != nullptr)) return IDF_E_INVAL;
     const int32_t *faces = ordered ? c->faces_scan : c->faces, *mpos = ordered ? c->markers_scan : c->markers_idx;
     if (porder) hipLaunchKernelGGL(corr_point_order_kernel, dim3((unsigned)B), dim3(1024), 0, s, obj_points, P, porder);
+    if (pred) {
+        // one LDS size for both roles (the predictor's stacks need 152 KB, the scan less); the predictor's workgroups lead the grid
+        const size_t lds2 = (pred->nclips > 0 && lds < idf_objproj_dev::OBJPROJ_LDS) ? idf_objproj_dev::OBJPROJ_LDS : lds;
+        static std::atomic<uint64_t> lds_ok2{0};
+        if (lds2 > 160 * 1024 - 2048) return IDF_E_INVAL;
+        if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<false, true>), 160 * 1024 - 2048, lds_ok2) != IDF_OK) return IDF_E_LAUNCH;
+        hipLaunchKernelGGL((corr_contact_kernel<false, true>), dim3((unsigned)(N + pred->nclips)), dim3(CT), lds2, s, verts, V, obj_points, P, porder, objR, objT, faces,
+                           c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, c->vrank, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
+                           stats, nn_from, nullptr, 0, *pred);
+        return IDF_OK;
+    }
     static std::atomic<uint64_t> lds_ok{0};
     if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<false>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel<false>, dim3((unsigned)N), dim3(CT), lds, s, verts, V, obj_points, P, porder, objR, objT, faces,
                        c->adj_ptr, c->adj_face, c->adj_corner, c->adj_pair_scan, c->vorder, c->vrank, mpos, M, B, markers, loss_sum, min_dist, label, o2h, idx,
-                       stats, nn_from, nullptr, 0);
+                       stats, nn_from, nullptr, 0, PredArgs{});
     return IDF_OK;
 }
 
@@ -694,7 +740,7 @@ __global__ __launch_bounds__(256) void corr_blend_kernel(float *__restrict__ x0,
 }
 
 struct CorrWs {
-    float *pose, *trans, *objR, *objT, *gt_angles, *gt_trans, *verts, *jtr, *markers, *loss_sum, *min_dist, *proj;
+    float *pose, *trans, *objR, *objT, *gt_angles, *gt_trans, *verts, *jtr, *markers, *loss_sum, *min_dist, *proj, *proj_keep;
     int32_t *label, *contact, *porder;
     uint8_t *condition;
     void *smpl_ws;
@@ -724,6 +770,7 @@ CorrWs carve(const idf_correction_ctx *c, int B, int T, void *ws) {
     w.contact = (int32_t *)take((size_t)B * M * 4);
     w.condition = (uint8_t *)take(B);
     w.porder = (int32_t *)take((size_t)B * c->n_points * 4);
+    w.proj_keep = (float *)take((size_t)B * idf_objproj_keep_floats() * 4);
     w.smpl_ws_bytes = interdiff_smpl_workspace_bytes(c->smpl, N);
     w.smpl_ws = take(w.smpl_ws_bytes);
     w.total = off;
@@ -823,7 +870,7 @@ int idf_nn_scan_opt(hipStream_t s, int64_t N, int frames_per_clip, const float *
     if (idf_opt_in_lds(reinterpret_cast<const void *>(corr_contact_kernel<true>), 160 * 1024 - 16384, lds_ok) != IDF_OK) return IDF_E_LAUNCH;
     hipLaunchKernelGGL(corr_contact_kernel<true>, dim3((unsigned)N, 2), dim3(CT), lds, s, verts, V, obj_points, P, porder, nullptr, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, c->vorder, c->vrank, nullptr, 0, B, nullptr, nullptr, nullptr, nullptr, nullptr, yidx, nullptr, (int64_t)0,
-                       pts_frame, frames_per_clip);
+                       pts_frame, frames_per_clip, PredArgs{});
     return IDF_OK;
 }
 
@@ -840,6 +887,7 @@ int idf_near_mask_opt(hipStream_t s, int64_t N, int frames_per_clip, const float
 }
 
 namespace {
+
 }  // namespace
 
 extern "C" size_t interdiff_correction_workspace_bytes(const idf_correction_ctx *c, int32_t B, int32_t T) {
@@ -860,21 +908,39 @@ static int correction_impl(const idf_correction_ctx *c, float *x0, const float *
     if (ws_bytes < w.total) return IDF_E_NOMEM;
     hipStream_t s = idf_stream(stream);
     const int64_t N = (int64_t)B * T;
+    // Round 6: the predictor's three stacks need the markers only -- the contact labels pick which node's IDCT is evaluated at the very end -- so they ride in the contact scan's
+    // launch as B leading workgroups (corr_contact_kernel<false, true>) and only the pick + IDCT kernel follows the labels.  ctx.tune & 2 (A/B, tests): scan, then the one-launch
+    // predictor.  Same arithmetic either way: same bits.
+    const bool fused = (c->tune & 2) == 0 && idf_objproj_check(c->objproj) == IDF_OK;
     idf_prof_mark(IDF_K_CORR_PREPARE, s);
     hipLaunchKernelGGL(corr_prepare_kernel, dim3((unsigned)idf_cdiv(N * 24, 256)), dim3(256), 0, s, x0, gt, hand_pose, B, T, w.pose,
                        w.trans, w.objR, w.objT, w.gt_angles, w.gt_trans);
     int rc = interdiff_smpl_forward(c->smpl, w.pose, beta, w.trans, N, w.verts, w.jtr, nullptr, w.smpl_ws, w.smpl_ws_bytes, stream);
     if (rc) return rc;
     idf_prof_mark(IDF_K_CORR_CONTACT, s);
-    rc = launch_contact(s, N, w.verts, V, obj_points, P, w.porder, w.objR, w.objT, c, B, w.markers, w.loss_sum, w.min_dist, w.label, nullptr,
-                        nullptr, nullptr, (int64_t)c->past_len * B);
+    PredArgs pred{};
+    if (fused) {
+        pred.op = *c->objproj;
+        pred.obj_angles = w.gt_angles; pred.obj_trans = w.gt_trans;
+        pred.markers_idx = c->markers_idx; pred.markers = w.markers; pred.keep = w.proj_keep;
+        pred.nclips = B;
+    }
+    // (the hook always launches the instantiation that CAN carry the predictor, with no predictor workgroups in the A/B form: two instantiations of the same source were seen to
+    // differ in the last bit of a frame's loss -- the compiler contracts the normal / signed-distance expressions per instantiation)
+    rc = launch_contact(s, N, w.verts, V, obj_points, P, w.porder, w.objR, w.objT, c, B, fused ? nullptr : w.markers, w.loss_sum, w.min_dist, w.label, nullptr,
+                        nullptr, nullptr, (int64_t)c->past_len * B, &pred);
     if (rc) return rc;
     uint8_t *cond = condition ? condition : w.condition;
     int32_t *cont = contact ? contact : w.contact;
     idf_prof_mark(IDF_K_CORR_REDUCE, s);
     hipLaunchKernelGGL(corr_reduce_kernel, dim3(B), dim3(128), 2 * (size_t)T * sizeof(float), s, w.loss_sum, w.min_dist, w.label, B, T, c->past_len, P, M, cond,
                        cont, distance, loss);
-    rc = interdiff_objprojector_sample(c->objproj, w.gt_angles, w.gt_trans, w.markers, cont, B, w.proj, stream);
+    if (fused) {
+        idf_prof_mark(IDF_K_OBJPROJ, s);
+        rc = idf_objproj_pick(c->objproj, w.proj_keep, cont, B, w.proj, s);
+    } else {
+        rc = interdiff_objprojector_sample(c->objproj, w.gt_angles, w.gt_trans, w.markers, cont, B, w.proj, stream);
+    }
     if (rc) return rc;
     idf_prof_mark(IDF_K_CORR_BLEND, s);
     hipLaunchKernelGGL(corr_blend_kernel, dim3((unsigned)idf_cdiv((int64_t)B * CTOK * T, 256)), dim3(256), 0, s, x0, w.proj, cond, B, T,

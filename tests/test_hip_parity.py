@@ -1497,6 +1497,62 @@ def test_correction_edge_sizes(smpl, T, B, P):
 
 
 @pytest.mark.gpu
+def test_hook_with_the_predictor_inside_the_scan_launch_equals_the_serial_one(smpl):
+    """Round 6: the contact-frame predictor's three stacks ride in the contact scan's launch as leading workgroups (they need the markers only) and a small kernel picks the node
+    once the labels exist (csrc/correction.hip correction_impl, corr_contact_kernel<false, true>, csrc/objproj.h).  Same bits as the scan followed by the one-launch predictor
+    (ctx.tune = 2), outputs and decisions, called eagerly, on a non-default stream, and replayed from a captured graph; repeated calls do not disturb each other."""
+    T, B, P = 14, 3, 300
+    bt = fx._clip(4242, B, T, P)
+    y = dev(fx.model_kwargs_y(bt, T))
+    rs = np.random.RandomState(7)
+    xs = [(bt['gt'] + 0.05 * fx._randn(rs, *bt['gt'].shape)).to(DEV) for _ in range(3)]
+
+    def run(tune, x):
+        corr = make_correction(smpl, T, P)
+        corr.ctx.tune = tune
+        corr.debug = {}
+        out = corr.apply(x.clone(), 250, y)
+        return out, corr.debug['condition'].clone(), corr.debug['contact'].clone(), corr.debug['distance'].clone(), corr.debug['loss'].clone()
+
+    for x in xs:
+        a, b = run(0, x), run(2, x)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    # the device-scalar form (what the sampler's graphs capture): eager on a side stream, then captured and replayed twice
+    table = torch.zeros(1000, 4, device=DEV)
+    table[:, 3] = torch.linspace(0.1, 0.9, 1000, device=DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    state[0] = 250
+    outs = {}
+    for tune in (0, 2):
+        corr = make_correction(smpl, T, P)
+        corr.ctx.tune = tune
+        ws = corr.workspace_for(B, T) if hasattr(corr, 'workspace_for') else None
+        st = torch.cuda.Stream()
+        res = []
+        with torch.cuda.stream(st):
+            ws = corr._workspace(B, T) if ws is None else ws
+            x = xs[0].clone()
+            corr.apply_dev(x, table, state, y, ws)           # eager (creates the side stream outside any capture)
+            res.append(x.clone())
+        st.synchronize()
+        xg = xs[1].clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                corr.apply_dev(xg, table, state, y, ws)
+        for k in (1, 2):
+            xg.copy_(xs[k])
+            g.replay()
+            torch.cuda.synchronize()
+            res.append(xg.clone())
+        outs[tune] = res
+    for u, v in zip(outs[0], outs[2]):
+        assert torch.equal(u, v)
+    assert not torch.equal(outs[0][1], outs[0][2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('T,P', [(3, 5), (7, 300)])
 def test_optimize_edge_sizes_vs_oracle(phys, T, P):
     """Shortest clip the smoothness terms are defined for (T = 3) and ragged point counts: loss parts and gradients of one

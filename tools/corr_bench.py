@@ -1,5 +1,6 @@
 """Correction-hook timing on one MI355X (not product code): the fused denoised_fn call at B clips x T frames, per-kernel event
-times, for both shapes of the contact scan (idf_correction_ctx.tune = 0: 16 waves x 2 points, 1: 8 waves x 4 points).
+times for the scan-order and the brute-force (identity-order) contact scan (the scan's figure includes the predictor's stacks, which ride in its launch; `objproj` is the pick
+kernel), then the whole call in the product form and with the predictor launched after the scan (idf_correction_ctx.tune = 0 / 2).
     python tools/corr_bench.py [--B 16] [--T 100]"""
 import argparse
 import ctypes as C
@@ -59,6 +60,21 @@ def main():
         cnt = (C.c_int64 * len(_lib.KERNEL_KINDS))()
         _lib.check(lib.interdiff_profile_end(ms, cnt))
         out[name] = dict(identical_to_first=same, **{k: round(1e3 * ms[i] / cnt[i], 1) for i, k in enumerate(_lib.KERNEL_KINDS) if cnt[i]})
+        # the whole call, as the sampler issues it (per-kernel profile off): the predictor's stacks inside the scan's launch (product) against scan, then one-launch predictor
+        for label, tn in (('hook_us', 0), ('hook_us_predictor_after_the_scan', 2)):
+            corr.ctx.tune = tn
+            for _ in range(3):
+                corr.apply(x.clone(), 250, y)
+            xs = [x.clone() for _ in range(10)]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for xx in xs:
+                corr.apply(xx, 250, y)
+            e1.record()
+            torch.cuda.synchronize()
+            out[name][label] = round(1e3 * e0.elapsed_time(e1) / len(xs), 1)
+        corr.ctx.tune = tune
     print(json.dumps(out))
 
 

@@ -1,4 +1,5 @@
-"""The correction hook replayed from a captured graph, overlapped route vs one-stream route (not product code):
+"""The correction hook replayed from a captured graph, product form (tune 0: the predictor's stacks inside the scan's launch; in the round-6 experiment this was the side-stream
+form, profiles/r06_hook_overlap.txt) vs the predictor launched after the scan (tune 2) (not product code):
     python tools/hook_timeline.py            -> us per replay of a graph holding ONE hook call, both routes (torch events)
     python tools/hook_timeline.py --db X.db  -> from a rocprofv3 kernel trace of the run above: the launches of the last replays with start / end relative to the first"""
 import argparse
@@ -64,7 +65,7 @@ def main():
             g.replay()
         e1.record()
         torch.cuda.synchronize()
-        print('tune %d (%s): %.1f us per replayed hook call' % (tune, 'one stream' if tune else 'overlapped', 1e3 * e0.elapsed_time(e1) / 10))
+        print('tune %d (%s): %.1f us per replayed hook call' % (tune, 'predictor after the scan' if tune else 'product form', 1e3 * e0.elapsed_time(e1) / 10))
 
 
 if __name__ == '__main__':

@@ -1,4 +1,6 @@
-"""Does using the hook's side stream change how the PLAIN steps run afterwards?  (not product code)
+"""Round-6 experiment, kept for the record (profiles/r06_hook_overlap.txt): written when the hook ran the predictor on a library-owned SIDE STREAM (ctx.tune 0 then; the shipped
+library has no side stream any more -- tune 0 is now the one-launch form -- so re-running this compares that form).
+Does using the hook's side stream change how the PLAIN steps run afterwards?  (not product code)
     python tools/side_stream_probe.py
 Times 490 plain steps (no hook; graphs of 49) before and after one overlapped hook call, one one-stream hook call, and a pure torch fork / join on a fresh stream."""
 import os
